@@ -1,0 +1,221 @@
+/*
+ * searchlite_gpu.h — C ABI of the MI355X (gfx950) batched BM25 top-k scorer + vector rerank.
+ *
+ * This is the drop-in boundary for ONE path of davidkelley/searchlite: the per-segment
+ * top-k scorer that `IndexReader::search_segment` calls
+ * (searchlite-core/src/api/reader.rs:3075-3099 ->
+ *  execute_top_k_with_stats_and_mode_internal, searchlite-core/src/query/wand.rs:398-412),
+ * the cross-segment merge that follows it (api/reader.rs:2776-2778, query/sort.rs:80-93),
+ * and the rerank slot `gpu::rerank` (searchlite-core/src/gpu/rerank.rs:3) behind the
+ * `gpu` cargo feature (searchlite-core/src/lib.rs:11-12, Cargo.toml:13).
+ *
+ * Conventions follow searchlite's own C FFI (searchlite-ffi/searchlite.h:12-18,
+ * searchlite-ffi/src/lib.rs:24-43,58-91): opaque handles, NULL / negative int on error,
+ * caller-owned output buffers, no exceptions or panics across the boundary, and a
+ * thread-local last-error string.  Plain pointers and sizes only.
+ *
+ * Eligibility (the caller keeps every other request shape on searchlite's CPU scorer;
+ * SURVEY.md section 8b): ScoreMode::Score, sort = _score desc, no collector/aggs, no
+ * score_adjust/explain, no cursor, no filter, matcher = pure disjunction, ScorePlan =
+ * Sum of leaves with leaf i == query term i.  accept() is then `!is_deleted(doc)`.
+ */
+#ifndef SEARCHLITE_GPU_H
+#define SEARCHLITE_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLG_ABI_VERSION 1u
+#define SLG_NO_TERM 0xFFFFFFFFu      /* term absent from a segment (api/reader.rs:2989) */
+#define SLG_NO_VECTOR 0xFFFFFFFFu    /* vectors/mod.rs:65-67 (u32::MAX offset) */
+#define SLG_MAX_QUERY_TERMS 32u      /* scored terms per query per segment */
+#define SLG_MAX_K 1024u              /* k = limit+1 handed to the scorer (api/reader.rs:2618) */
+#define SLG_BLOCK_SIZE 128u          /* index/postings.rs:11 DEFAULT_BLOCK_SIZE */
+
+/* return codes (searchlite-ffi/src/lib.rs returns NULL / -1..-5 / 0) */
+enum {
+  SLG_OK = 0,
+  SLG_ERR_INVALID = -1,     /* bad argument / malformed arrays */
+  SLG_ERR_DEVICE = -2,      /* HIP runtime error, no gfx950 device */
+  SLG_ERR_OOM = -3,         /* host or device allocation failed */
+  SLG_ERR_UNSUPPORTED = -4, /* request shape outside the eligibility predicate */
+  SLG_ERR_INTERNAL = -5
+};
+
+/* api/types.rs:6-13 ExecutionStrategy.  All three return the exhaustive-exact top-k
+ * (the reference's own parity standard: tests/pruning.rs:44-104 Bm25 == Wand == Bmw). */
+enum { SLG_STRATEGY_BM25 = 0, SLG_STRATEGY_WAND = 1, SLG_STRATEGY_BMW = 2 };
+
+/* index/manifest.rs VectorMetric */
+enum { SLG_METRIC_COSINE = 0, SLG_METRIC_L2 = 1 };
+
+typedef struct slg_index slg_index; /* device-resident index (all segments of one shard) */
+typedef struct slg_batch slg_batch; /* one prepared query batch */
+
+/*
+ * One searchlite segment, in exactly the decoded form `search_segment` hands the scorer
+ * (api/reader.rs:2985-3000): per-term posting lists (PostingsReader, index/postings.rs:133-139)
+ * as a CSR over terms, per-field dense doc-length vectors (field_lengths_for,
+ * api/reader.rs:3604-3621), avg field length (index/segment.rs:848), live_docs, and the
+ * index-wide BM25 parameters (IndexOptions, api/types.rs:16-26).
+ * All host arrays are borrowed for the duration of slg_index_create only.
+ */
+typedef struct {
+  uint32_t n_docs;               /* seg.meta.doc_count */
+  uint32_t n_terms;              /* V: number of "field:term" keys */
+  const uint64_t *term_offsets;  /* [V+1] postings CSR; df(t) = off[t+1]-off[t] */
+  const uint32_t *doc_ids;       /* [P] strictly increasing within a term */
+  const uint32_t *tfs;           /* [P] term_freq */
+  const uint16_t *term_field;    /* [V] field id of each term, NULL => field 0 */
+  uint32_t n_fields;
+  const float *const *field_doc_len; /* [n_fields] each f32[n_docs] (0 => missing) or NULL */
+  const float *field_avgdl;          /* [n_fields] seg.avg_field_length(field) */
+  float docs;                        /* seg.live_docs() as f32 */
+  float k1, b;                       /* options.bm25_k1 / bm25_b */
+  const uint8_t *deleted;            /* bitmap, bit (d&7) of byte d>>3; NULL => none */
+  /* optional vector field for slg_rerank_batch (vectors/mod.rs:10-17 VectorStore) */
+  uint32_t vec_dim;                  /* 0 => no vectors */
+  int32_t vec_metric;                /* SLG_METRIC_* */
+  const uint32_t *vec_offsets;       /* [n_docs] row index or SLG_NO_VECTOR */
+  const float *vec_values;           /* [vec_rows * vec_dim] row-major (cosine: pre-normalized,
+                                        index/segment.rs:508-510) */
+  uint32_t vec_rows;
+} slg_segment_desc;
+
+/* query/wand.rs:45-50 QueryStats, per query (brute-force accounting, wand.rs:472,500-503) */
+typedef struct {
+  uint64_t scored_docs;
+  uint64_t candidates_examined;
+  uint64_t postings_advanced;
+} slg_stats;
+
+/* One query = the folded term list search_segment builds (api/reader.rs:2971-3000):
+ * distinct terms, weight = summed boost, term i is ScorePlan leaf i. */
+typedef struct {
+  uint32_t n_terms;
+  const uint32_t *term_ids; /* [n_terms * n_segs]: entry [i*n_segs + s] = id of term i in
+                               segment s's dictionary, or SLG_NO_TERM */
+  const float *weights;     /* [n_terms] */
+} slg_query;
+
+/* ---- lifecycle ------------------------------------------------------------------- */
+
+uint32_t slg_abi_version(void);
+
+/* Thread-local description of the last failure on this thread ("" if none). */
+const char *slg_last_error(void);
+
+/* Number of visible HIP devices, or negative error. */
+int slg_device_count(void);
+
+/*
+ * Stage segments into HBM on `device` and precompute per-posting BM25 impacts
+ * (query/bm25.rs:1-6 + query/wand.rs:269-286 with weight factored out).  Returns NULL on
+ * error (see slg_last_error).  The handle may be used from several host threads; calls
+ * on one handle are serialized internally.
+ */
+slg_index *slg_index_create(const slg_segment_desc *segs, uint32_t n_segs, int device);
+void slg_index_destroy(slg_index *index);
+
+/* Bytes of HBM held by the index; total postings; segments. */
+int slg_index_info(const slg_index *index, uint32_t *n_segs, uint64_t *n_postings,
+                   uint64_t *device_bytes);
+
+/* Use an external HIP stream (hipStream_t) for all work of this index, e.g. the
+ * current PyTorch stream so RCCL collectives order after the kernels.  NULL restores
+ * the index's own stream. */
+int slg_index_set_stream(slg_index *index, void *hip_stream);
+
+/* ---- one-shot search (what a searchlite `gpu` shim calls) -------------------------- */
+
+/*
+ * Replaces, for a batch of eligible queries, the per-segment scorer call plus the
+ * cross-segment sort: for every query, top-k by (score desc [f32 total_cmp],
+ * segment_ord asc, doc_id asc) over all segments of the index.
+ * Outputs are caller-owned host arrays of nq*k (out_count: nq); row q holds
+ * out_count[q] <= k hits.  Blocks until the results are in the output arrays.
+ */
+int slg_search_batch(slg_index *index, const slg_query *queries, uint32_t nq, uint32_t k,
+                     int strategy, uint32_t *out_doc, uint32_t *out_seg, float *out_score,
+                     uint32_t *out_count, slg_stats *stats_or_null);
+
+/* ---- prepared batches (device-resident inputs; used for steady-state serving) ------ */
+
+/*
+ * Queries in CSR form: q_offsets[nq+1] indexes q_weights and the rows of q_term_ids
+ * ([total_terms * n_segs], same layout as slg_query.term_ids).  Plans the batch on the
+ * host, uploads the descriptors and allocates all device work buffers.
+ */
+slg_batch *slg_batch_prepare(slg_index *index, uint32_t nq, const uint32_t *q_offsets,
+                             const uint32_t *q_term_ids, const float *q_weights, uint32_t k,
+                             int strategy);
+/* Enqueue the partition / score / merge kernels on the index stream (asynchronous). */
+int slg_batch_run(slg_batch *batch);
+/* Wait for everything enqueued for this batch. */
+int slg_batch_sync(slg_batch *batch);
+/* Copy results to host arrays (nq*k, nq); waits for completion. */
+int slg_batch_fetch(slg_batch *batch, uint32_t *out_doc, uint32_t *out_seg, float *out_score,
+                    uint32_t *out_count, slg_stats *stats_or_null);
+/* Device pointers of the result arrays (u32[nq*k], u32[nq*k], f32[nq*k], u32[nq]) for
+ * device-side consumers (RCCL all-gather of per-shard top-k, rerank). */
+int slg_batch_device_results(slg_batch *batch, void **d_doc, void **d_seg, void **d_score,
+                             void **d_count);
+/* Planning facts: total postings the batch scores, number of work slices, and the
+ * algorithmic byte count 12*postings + 8*k*nq. */
+int slg_batch_info(const slg_batch *batch, uint64_t *n_postings, uint32_t *n_slices,
+                   uint64_t *algorithmic_bytes);
+void slg_batch_destroy(slg_batch *batch);
+
+/*
+ * Merge per-shard results gathered from several indexes/GPUs (device arrays, as produced
+ * by slg_batch_device_results and concatenated shard-major: [n_shards][nq*k]) into the
+ * global top-k by (score desc, shard_ord asc, segment asc, doc asc).  out_seg receives
+ * shard_ord * seg_stride + seg.  All pointers are device pointers on `index`'s device.
+ */
+int slg_merge_shards_device(slg_index *index, uint32_t n_shards, uint32_t nq, uint32_t k,
+                            const uint32_t *d_doc, const uint32_t *d_seg, const float *d_score,
+                            const uint32_t *d_count, uint32_t seg_stride, uint32_t *d_out_doc,
+                            uint32_t *d_out_seg, float *d_out_score, uint32_t *d_out_count);
+
+/* ---- profiling hooks (bench.py roofline) -------------------------------------------- */
+
+/* When enabled, every slg_batch_run brackets its scoring kernel with HIP events on the
+ * launch stream. */
+int slg_profile_enable(slg_index *index, int on);
+/* Sum of scoring-kernel durations and number of launches since the last reset; waits
+ * for the recorded events.  Resets the accumulators. */
+int slg_profile_read(slg_index *index, uint32_t *n_launches, float *total_ms);
+
+/* ---- rerank (fills gpu::rerank, gpu/rerank.rs:3) ------------------------------------- */
+
+/*
+ * For each query: candidates (cand_doc, cand_seg, cand_bm25)[cand_count[q] <= max_cand] ->
+ * vector similarity against qvecs[q] (vectors/mod.rs:107-120: cosine = dot of
+ * pre-normalized vectors, NaN -> 0; L2 = -sqrt(sum d^2)), blended as
+ * compute_hybrid_score does for one clause (api/reader.rs:225-254; missing vector =>
+ * -1.0 / f32::MIN, api/reader.rs:217-223), then top-k_out by (blended desc, seg asc, doc asc).
+ * Host arrays in and out; blocks.
+ */
+int slg_rerank_batch(slg_index *index, uint32_t nq, const float *qvecs, const float *alpha,
+                     const uint32_t *cand_doc, const uint32_t *cand_seg, const float *cand_bm25,
+                     const uint32_t *cand_count, uint32_t max_cand, uint32_t k_out,
+                     uint32_t *out_doc, uint32_t *out_seg, float *out_score,
+                     float *out_vec_score, uint32_t *out_count);
+
+/* Same, all pointers device-resident and asynchronous on the index stream (chains after
+ * slg_batch_run without a host round trip). */
+int slg_rerank_batch_device(slg_index *index, uint32_t nq, const float *d_qvecs,
+                            const float *d_alpha, const uint32_t *d_cand_doc,
+                            const uint32_t *d_cand_seg, const float *d_cand_bm25,
+                            const uint32_t *d_cand_count, uint32_t max_cand, uint32_t k_out,
+                            uint32_t *d_out_doc, uint32_t *d_out_seg, float *d_out_score,
+                            float *d_out_vec_score, uint32_t *d_out_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEARCHLITE_GPU_H */

@@ -1,0 +1,228 @@
+"""ctypes wrapper around oracle/libslo_oracle.so — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  The product package (searchlite_amd/) never does.
+
+Segments are passed duck-typed: any object with the attributes
+  n_docs, term_offsets(u64[V+1]), doc_ids(u32[P]), tfs(u32[P]), term_field(u16[V]|None),
+  field_doc_len(list of f32[N]|None), field_avgdl(f32[F]), docs, k1, b, deleted(u8 bitmap|None)
+works (searchlite_amd.segment.Segment has exactly these).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libslo_oracle.so")
+
+BM25, WAND, BMW = 0, 1, 2
+COSINE, L2 = 0, 1
+NO_TERM = 0xFFFFFFFF
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "slo_oracle.c")
+    stale = (not os.path.exists(_LIB_PATH)
+             or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)
+             or os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "slo_oracle.h")))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libslo_oracle.so"])
+    return _LIB_PATH
+
+
+class _Term(C.Structure):
+    _fields_ = [("doc_ids", C.c_void_p), ("tfs", C.c_void_p), ("len", C.c_uint32),
+                ("weight", C.c_float), ("avgdl", C.c_float), ("docs", C.c_float),
+                ("k1", C.c_float), ("b", C.c_float), ("leaf", C.c_uint32),
+                ("doc_lengths", C.c_void_p), ("n_doc_lengths", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("scored_docs", C.c_uint64), ("candidates_examined", C.c_uint64),
+                ("postings_advanced", C.c_uint64)]
+
+
+class _Segment(C.Structure):
+    _fields_ = [("n_docs", C.c_uint32), ("n_terms", C.c_uint32),
+                ("term_offsets", C.c_void_p), ("doc_ids", C.c_void_p), ("tfs", C.c_void_p),
+                ("term_field", C.c_void_p), ("n_fields", C.c_uint32),
+                ("field_doc_len", C.c_void_p), ("field_avgdl", C.c_void_p),
+                ("docs", C.c_float), ("k1", C.c_float), ("b", C.c_float),
+                ("deleted", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        f32 = C.c_float
+        L.slo_bm25.restype = f32
+        L.slo_bm25.argtypes = [f32] * 7
+        L.slo_score_tf.restype = f32
+        L.slo_score_tf.argtypes = [f32] * 8
+        L.slo_upper_bound_tf.restype = f32
+        L.slo_upper_bound_tf.argtypes = [f32] * 8
+        L.slo_total_cmp.restype = C.c_int
+        L.slo_total_cmp.argtypes = [f32, f32]
+        L.slo_execute_top_k.restype = C.c_int
+        L.slo_execute_top_k.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32,
+                                        C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]
+        L.slo_search_batch.restype = C.c_int
+        L.slo_search_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_int,
+                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]
+        L.slo_normalize_in_place.restype = None
+        L.slo_normalize_in_place.argtypes = [C.c_void_p, C.c_uint32]
+        L.slo_metric_similarity.restype = f32
+        L.slo_metric_similarity.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.slo_blend_scores.restype = f32
+        L.slo_blend_scores.argtypes = [f32, f32, f32, C.c_int]
+        L.slo_missing_vector_score.restype = f32
+        L.slo_missing_vector_score.argtypes = [C.c_int]
+        L.slo_rerank.restype = C.c_int
+        L.slo_rerank.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                 C.c_void_p, f32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def bm25(tf, df, doc_len, avgdl, docs, k1, b) -> float:
+    return float(lib().slo_bm25(tf, df, doc_len, avgdl, docs, k1, b))
+
+
+def score_tf(tf, df, doc_len, avgdl, docs, k1, b, weight) -> float:
+    return float(lib().slo_score_tf(tf, df, doc_len, avgdl, docs, k1, b, weight))
+
+
+def upper_bound_tf(tf, df, doc_len, avgdl, docs, k1, b, weight) -> float:
+    return float(lib().slo_upper_bound_tf(tf, df, doc_len, avgdl, docs, k1, b, weight))
+
+
+def total_cmp(a, b) -> int:
+    return int(lib().slo_total_cmp(a, b))
+
+
+class ScoredTerm:
+    """query/wand.rs:65-75 (postings as two parallel arrays)."""
+
+    def __init__(self, doc_ids, tfs, weight=1.0, avgdl=1.0, docs=1.0, k1=1.2, b=0.75, leaf=0,
+                 doc_lengths=None):
+        self.doc_ids = np.ascontiguousarray(doc_ids, dtype=np.uint32)
+        self.tfs = np.ascontiguousarray(tfs, dtype=np.uint32)
+        assert self.doc_ids.shape == self.tfs.shape
+        self.weight, self.avgdl, self.docs, self.k1, self.b = weight, avgdl, docs, k1, b
+        self.leaf = leaf
+        self.doc_lengths = (None if doc_lengths is None
+                            else np.ascontiguousarray(doc_lengths, dtype=np.float32))
+
+
+def execute_top_k(terms, k, strategy=WAND, block_size=None, use_plan=False, deleted=None,
+                  min_len_cache=None, want_stats=False):
+    """query/wand.rs:338-456; returns [(doc, score)] (and Stats if want_stats)."""
+    arr = (_Term * max(len(terms), 1))()
+    for i, t in enumerate(terms):
+        arr[i] = _Term(_ptr(t.doc_ids), _ptr(t.tfs), len(t.doc_ids), t.weight, t.avgdl, t.docs,
+                       t.k1, t.b, t.leaf, _ptr(t.doc_lengths),
+                       0 if t.doc_lengths is None else len(t.doc_lengths))
+    out_doc = np.zeros(max(k, 1), dtype=np.uint32)
+    out_score = np.zeros(max(k, 1), dtype=np.float32)
+    st = Stats()
+    mlc = None if min_len_cache is None else np.ascontiguousarray(min_len_cache, dtype=np.float32)
+    n = lib().slo_execute_top_k(arr, len(terms), k, strategy, block_size or 0, int(use_plan),
+                                _ptr(deleted), _ptr(mlc), _ptr(out_doc), _ptr(out_score),
+                                C.addressof(st))
+    hits = [(int(out_doc[i]), float(out_score[i])) for i in range(n)]
+    return (hits, st) if want_stats else hits
+
+
+def _pack_segments(segments):
+    keep = []
+    arr = (_Segment * len(segments))()
+    for i, s in enumerate(segments):
+        nf = len(s.field_doc_len)
+        ptrs = (C.c_void_p * nf)(*[_ptr(a) for a in s.field_doc_len])
+        avg = np.ascontiguousarray(s.field_avgdl, dtype=np.float32)
+        keep += [ptrs, avg]
+        arr[i] = _Segment(s.n_docs, len(s.term_offsets) - 1, _ptr(s.term_offsets), _ptr(s.doc_ids),
+                          _ptr(s.tfs), _ptr(s.term_field), nf, C.addressof(ptrs), _ptr(avg),
+                          s.docs, s.k1, s.b, _ptr(s.deleted))
+    return arr, keep
+
+
+def search_batch(segments, q_offsets, q_terms, q_weights, k, strategy=WAND, block_size=None,
+                 n_threads=1, cache_min_len=False, want_stats=False):
+    """api/reader.rs search() over segments for a batch of pure-disjunction queries.
+
+    q_terms has shape [total_query_terms, n_segs] (per-segment term ids, NO_TERM if absent).
+    Returns (doc[nq,k], seg[nq,k], score[nq,k], count[nq]).
+    """
+    segs, keep = _pack_segments(segments)
+    q_offsets = np.ascontiguousarray(q_offsets, dtype=np.uint32)
+    q_terms = np.ascontiguousarray(q_terms, dtype=np.uint32).reshape(-1, len(segments))
+    q_weights = np.ascontiguousarray(q_weights, dtype=np.float32)
+    nq = len(q_offsets) - 1
+    out_doc = np.zeros((nq, k), dtype=np.uint32)
+    out_seg = np.zeros((nq, k), dtype=np.uint32)
+    out_score = np.zeros((nq, k), dtype=np.float32)
+    out_count = np.zeros(nq, dtype=np.uint32)
+    stats = (Stats * max(nq, 1))() if want_stats else None
+    rc = lib().slo_search_batch(segs, len(segments), nq, _ptr(q_offsets), _ptr(q_terms),
+                                _ptr(q_weights), k, strategy, block_size or 0, n_threads,
+                                int(cache_min_len), _ptr(out_doc), _ptr(out_seg), _ptr(out_score),
+                                _ptr(out_count), None if stats is None else C.addressof(stats))
+    if rc != 0:
+        raise RuntimeError(f"slo_search_batch failed: {rc}")
+    if want_stats:
+        return out_doc, out_seg, out_score, out_count, stats
+    return out_doc, out_seg, out_score, out_count
+
+
+def normalize_in_place(v):
+    assert v.dtype == np.float32 and v.flags.c_contiguous
+    lib().slo_normalize_in_place(_ptr(v), v.size)
+
+
+def metric_similarity(metric, a, b) -> float:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    return float(lib().slo_metric_similarity(metric, _ptr(a), _ptr(b), a.size))
+
+
+def blend_scores(bm25_score, vec, alpha, higher_is_better=True) -> float:
+    return float(lib().slo_blend_scores(bm25_score, vec, alpha, int(higher_is_better)))
+
+
+def missing_vector_score(metric) -> float:
+    return float(lib().slo_missing_vector_score(metric))
+
+
+def rerank(metric, vec_offsets, vec_values, qvec, alpha, cand_doc, cand_bm25, k_out):
+    vec_offsets = np.ascontiguousarray(vec_offsets, dtype=np.uint32)
+    vec_values = np.ascontiguousarray(vec_values, dtype=np.float32)
+    qvec = np.ascontiguousarray(qvec, dtype=np.float32)
+    cand_doc = np.ascontiguousarray(cand_doc, dtype=np.uint32)
+    cand_bm25 = np.ascontiguousarray(cand_bm25, dtype=np.float32)
+    dim = qvec.size
+    out_doc = np.zeros(max(k_out, 1), dtype=np.uint32)
+    out_score = np.zeros(max(k_out, 1), dtype=np.float32)
+    out_vec = np.zeros(max(k_out, 1), dtype=np.float32)
+    n = lib().slo_rerank(metric, dim, _ptr(vec_offsets), len(vec_offsets), _ptr(vec_values),
+                         _ptr(qvec), alpha, _ptr(cand_doc), _ptr(cand_bm25), len(cand_doc), k_out,
+                         _ptr(out_doc), _ptr(out_score), _ptr(out_vec))
+    return out_doc[:n].copy(), out_score[:n].copy(), out_vec[:n].copy()

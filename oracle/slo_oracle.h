@@ -1,0 +1,140 @@
+/*
+ * slo_oracle.h — CPU restatement ("oracle") of searchlite-core's BM25 top-k scorer.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under searchlite_amd/ (the product) may include,
+ * link or call this; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg use it, and only as the checker / CPU baseline.
+ *
+ * Every function cites the reference file:line (relative to /root/reference/) whose
+ * arithmetic and control flow it restates.  The reference is Rust and cannot be built
+ * in this image (no cargo/rustc), so this restatement is pinned by (a) the reference's
+ * own property tests replayed in tests/test_oracle.py (Bm25 == Wand == Bmw, tie order,
+ * cross-segment order, hybrid-blend ordering) and (b) hand-derived f32 known answers
+ * (SURVEY.md section 8c).  Absolute scores are NOT pinned by any reference-held golden
+ * vector (the reference has none): "parity unpinned" for absolute values, pinned for
+ * orderings/equivalences.
+ */
+#ifndef SLO_ORACLE_H
+#define SLO_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLO_DEFAULT_BLOCK_SIZE 128u /* index/postings.rs:11 */
+#define SLO_DOCID_END 0xFFFFFFFFu   /* query/wand.rs:12 */
+#define SLO_NO_TERM 0xFFFFFFFFu
+
+enum { SLO_BM25 = 0, SLO_WAND = 1, SLO_BMW = 2 }; /* api/types.rs:6-13 ExecutionStrategy */
+enum { SLO_COSINE = 0, SLO_L2 = 1 };              /* VectorMetric */
+
+/* query/wand.rs:65-75 ScoredTerm (postings held as SoA doc_ids/tfs instead of
+ * Vec<PostingEntry>; positions are never read on this path). */
+typedef struct {
+  const uint32_t *doc_ids;
+  const uint32_t *tfs;
+  uint32_t len;
+  float weight, avgdl, docs, k1, b;
+  uint32_t leaf;
+  const float *doc_lengths; /* NULL == None */
+  uint32_t n_doc_lengths;
+} slo_term;
+
+/* query/wand.rs:45-50 QueryStats */
+typedef struct {
+  uint64_t scored_docs, candidates_examined, postings_advanced;
+} slo_stats;
+
+/* query/bm25.rs:1-6 */
+float slo_bm25(float tf, float df, float doc_len, float avgdl, float docs, float k1, float b);
+/* query/wand.rs:269-286 */
+float slo_score_tf(float tf, float df, float doc_len, float avgdl, float docs, float k1, float b,
+                   float weight);
+/* query/wand.rs:289-303 */
+float slo_upper_bound_tf(float tf, float df, float doc_len, float avgdl, float docs, float k1,
+                         float b, float weight);
+/* f32::total_cmp: returns -1/0/1 */
+int slo_total_cmp(float a, float b);
+
+/*
+ * query/wand.rs:398-456 execute_top_k_with_stats_and_mode_internal, ScoreMode::Score,
+ * no collector, no score_adjust.  accept(doc,score) == !deleted[doc] (deleted is a
+ * bitmap, bit d of byte d/8; NULL accepts all) — api/reader.rs:3009-3012 with a pure
+ * disjunction and no filter/cursor.
+ *   use_plan != 0: a ScorePlan Sum(Leaf 0..leaf_count) is applied (planner.rs:354-360,
+ *   122-135), leaf_count = max(term.leaf)+1.  use_plan == 0: the no-plan paths
+ *   (wand.rs:524-541 / score_sum at :811).
+ *   block_size 0 == None (default 128).
+ *   min_len_cache: NULL => scan doc_lengths per term as TermState::new does
+ *   (wand.rs:111-125); else per-term precomputed min positive doc length (a cache the
+ *   reference does not have; used only by the generous CPU-baseline timing).
+ * Returns the number of hits written (<= k), sorted score desc, doc asc (wand.rs:918-926).
+ */
+int slo_execute_top_k(const slo_term *terms, uint32_t n_terms, uint32_t k, int strategy,
+                      uint32_t block_size, int use_plan, const uint8_t *deleted,
+                      const float *min_len_cache, uint32_t *out_doc, float *out_score,
+                      slo_stats *stats);
+
+/* One index segment in the layout the scorer consumes (api/reader.rs:2985-3000). */
+typedef struct {
+  uint32_t n_docs;
+  uint32_t n_terms;
+  const uint64_t *term_offsets; /* n_terms+1 */
+  const uint32_t *doc_ids;
+  const uint32_t *tfs;
+  const uint16_t *term_field; /* n_terms, NULL => field 0 */
+  uint32_t n_fields;
+  const float *const *field_doc_len; /* n_fields pointers, each f32[n_docs] or NULL */
+  const float *field_avgdl;          /* n_fields */
+  float docs;                        /* live docs (api/reader.rs:2985) */
+  float k1, b;                       /* IndexOptions (api/types.rs:16-26) */
+  const uint8_t *deleted;            /* bitmap or NULL */
+} slo_segment;
+
+/*
+ * api/reader.rs:2670-2745 + 2776-2778: for each query, run the scorer on every segment
+ * with k, concatenate, sort by (score desc total_cmp, segment_ord asc, doc asc)
+ * (query/sort.rs:80-93) and keep the first k.
+ *   q_offsets[nq+1] indexes q_terms/q_weights; q_terms holds n_segs term ids per query
+ *   term (entry [i*n_segs + s], SLO_NO_TERM if the term is absent from segment s —
+ *   api/reader.rs:2989 `if let Some(postings)`).  Term i of a query is leaf i.
+ *   n_threads: queries are spread over this many pthreads (each query stays
+ *   single-threaded, as in the reference).
+ *   cache_min_len != 0: per-field min positive doc length computed once per segment.
+ * Outputs are nq*k arrays; out_count[q] <= k.  Returns 0 on success.
+ */
+int slo_search_batch(const slo_segment *segs, uint32_t n_segs, uint32_t nq,
+                     const uint32_t *q_offsets, const uint32_t *q_terms, const float *q_weights,
+                     uint32_t k, int strategy, uint32_t block_size, int n_threads,
+                     int cache_min_len, uint32_t *out_doc, uint32_t *out_seg, float *out_score,
+                     uint32_t *out_count, slo_stats *stats_or_null);
+
+/* vectors/mod.rs:74-81 */
+void slo_normalize_in_place(float *v, uint32_t dim);
+/* vectors/mod.rs:107-120 */
+float slo_metric_similarity(int metric, const float *a, const float *b, uint32_t dim);
+/* vectors/mod.rs:122-129 */
+float slo_blend_scores(float bm25, float vector_score, float alpha, int higher_is_better);
+/* api/reader.rs:217-223 */
+float slo_missing_vector_score(int metric);
+/*
+ * The rerank the north-star puts in gpu::rerank's slot (gpu/rerank.rs:3): for each
+ * candidate (doc, bm25) compute metric_similarity(query, store.vector(doc))
+ * (vectors/mod.rs:63-71 offsets/values layout, u32::MAX == no vector), blend as
+ * compute_hybrid_score does for ONE clause (api/reader.rs:225-254: alpha>=1 => bm25,
+ * alpha<=0 => vec, else blend_scores; missing vector => missing_vector_score), then
+ * order by (blended desc total_cmp, doc asc) and keep k_out.
+ * Returns number written.
+ */
+int slo_rerank(int metric, uint32_t dim, const uint32_t *vec_offsets, uint32_t n_docs,
+               const float *vec_values, const float *qvec, float alpha, const uint32_t *cand_doc,
+               const float *cand_bm25, uint32_t n_cand, uint32_t k_out, uint32_t *out_doc,
+               float *out_score, float *out_vec_score);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,108 @@
+"""ctypes binding of include/searchlite_gpu.h.
+
+There is no fallback: if libsearchlite_gpu.so is missing the import of anything that needs
+it raises, and every call either runs the HIP kernels or raises SlgError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+NO_TERM = 0xFFFFFFFF
+NO_VECTOR = 0xFFFFFFFF
+MAX_QUERY_TERMS = 32
+MAX_K = 1024
+
+OK, ERR_INVALID, ERR_DEVICE, ERR_OOM, ERR_UNSUPPORTED, ERR_INTERNAL = 0, -1, -2, -3, -4, -5
+STRATEGY_BM25, STRATEGY_WAND, STRATEGY_BMW = 0, 1, 2
+METRIC_COSINE, METRIC_L2 = 0, 1
+
+
+class SlgError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"searchlite_gpu error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class SegmentDesc(C.Structure):
+    _fields_ = [("n_docs", C.c_uint32), ("n_terms", C.c_uint32),
+                ("term_offsets", C.c_void_p), ("doc_ids", C.c_void_p), ("tfs", C.c_void_p),
+                ("term_field", C.c_void_p), ("n_fields", C.c_uint32),
+                ("field_doc_len", C.c_void_p), ("field_avgdl", C.c_void_p),
+                ("docs", C.c_float), ("k1", C.c_float), ("b", C.c_float),
+                ("deleted", C.c_void_p),
+                ("vec_dim", C.c_uint32), ("vec_metric", C.c_int32),
+                ("vec_offsets", C.c_void_p), ("vec_values", C.c_void_p),
+                ("vec_rows", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("scored_docs", C.c_uint64), ("candidates_examined", C.c_uint64),
+                ("postings_advanced", C.c_uint64)]
+
+
+class Query(C.Structure):
+    _fields_ = [("n_terms", C.c_uint32), ("term_ids", C.c_void_p), ("weights", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _build.GPU_LIB
+
+
+def load():
+    """Load libsearchlite_gpu.so (built by searchlite_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            "searchlite_amd has no CPU fallback.")
+    L = C.CDLL(path)
+    vp, u32, i32, f32 = C.c_void_p, C.c_uint32, C.c_int, C.c_float
+    sigs = {
+        "slg_abi_version": (u32, []),
+        "slg_last_error": (C.c_char_p, []),
+        "slg_device_count": (i32, []),
+        "slg_index_create": (vp, [vp, u32, i32]),
+        "slg_index_destroy": (None, [vp]),
+        "slg_index_info": (i32, [vp, vp, vp, vp]),
+        "slg_index_set_stream": (i32, [vp, vp]),
+        "slg_search_batch": (i32, [vp, vp, u32, u32, i32, vp, vp, vp, vp, vp]),
+        "slg_batch_prepare": (vp, [vp, u32, vp, vp, vp, u32, i32]),
+        "slg_batch_run": (i32, [vp]),
+        "slg_batch_sync": (i32, [vp]),
+        "slg_batch_fetch": (i32, [vp, vp, vp, vp, vp, vp]),
+        "slg_batch_device_results": (i32, [vp, vp, vp, vp, vp]),
+        "slg_batch_info": (i32, [vp, vp, vp, vp]),
+        "slg_batch_destroy": (None, [vp]),
+        "slg_merge_shards_device": (i32, [vp, u32, u32, u32, vp, vp, vp, vp, u32, vp, vp, vp, vp]),
+        "slg_profile_enable": (i32, [vp, i32]),
+        "slg_profile_read": (i32, [vp, vp, vp]),
+        "slg_rerank_batch": (i32, [vp, u32, vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp, vp, vp]),
+        "slg_rerank_batch_device": (i32, [vp, u32, vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp,
+                                          vp, vp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(L, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return load().slg_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    if rc != OK:
+        raise SlgError(rc, last_error())

@@ -1,0 +1,68 @@
+"""Build the native pieces in-tree.
+
+* lib/libsearchlite_gpu.so — the product: HIP kernels + C ABI for gfx950 (hipcc).
+* lib/libslg_corpus.so     — harness tool: synthetic Zipf corpus generator (g++, host only).
+
+hipcc cross-compiles gfx950 without a GPU, so this runs in the build container; the built
+.so files travel to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIBDIR = os.path.join(_HERE, "lib")
+GPU_LIB = os.path.join(LIBDIR, "libsearchlite_gpu.so")
+CORPUS_LIB = os.path.join(LIBDIR, "libslg_corpus.so")
+
+GPU_SOURCES = ["slg_api.hip", "slg_kernels.hpp", "slg_rerank.hpp"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-ffp-contract=off",  # f32 ops rounded one by one, as the Rust reference does
+               "-Wall", "-Wno-unused-function"]
+
+
+def _newer(target: str, sources) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libsearchlite_gpu.so")
+
+
+def build_gpu(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in GPU_SOURCES]
+    srcs.append(os.path.join(_HERE, "..", "include", "searchlite_gpu.h"))
+    if force or _newer(GPU_LIB, srcs):
+        cmd = [_hipcc(), *HIPCC_FLAGS, "-o", GPU_LIB, os.path.join(CSRC, "slg_api.hip")]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return GPU_LIB
+
+
+def build_corpus_tool(force: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    src = os.path.join(CSRC, "tools", "corpus_gen.cpp")
+    if force or _newer(CORPUS_LIB, [src]):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread",
+                               "-o", CORPUS_LIB, src])
+    return CORPUS_LIB
+
+
+def build_all(force: bool = False, verbose: bool = False) -> None:
+    build_gpu(force, verbose)
+    build_corpus_tool(force)
+
+
+if __name__ == "__main__":
+    build_all(verbose=True)

@@ -1,0 +1,972 @@
+// slg_api.hip — host side of the C ABI declared in include/searchlite_gpu.h.
+//
+// Mirrors, for the GPU-eligible request shape, what IndexReader::search_segment does
+// before and after the scorer call (searchlite-core/src/api/reader.rs:2971-3000 build the
+// ScoredTerm list; :3075-3099 call the scorer; :2776-2778 merge across segments), but for
+// a whole batch of queries at once.  The product path has NO CPU fallback: every entry
+// point either runs the HIP kernels or fails with an error code.
+#include "../../include/searchlite_gpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "slg_kernels.hpp"
+#include "slg_rerank.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct SlgError : std::runtime_error {
+  int code;
+  SlgError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+#define SLG_HIP(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      int _code = (_e == hipErrorOutOfMemory) ? SLG_ERR_OOM : SLG_ERR_DEVICE;             \
+      throw SlgError(_code, std::string(#expr) + ": " + hipGetErrorString(_e));           \
+    }                                                                                     \
+  } while (0)
+
+#define SLG_REQUIRE(cond, msg)                              \
+  do {                                                      \
+    if (!(cond)) throw SlgError(SLG_ERR_INVALID, (msg));    \
+  } while (0)
+
+template <typename F>
+int guarded(F &&f) {
+  try {
+    g_last_error.clear();
+    f();
+    return SLG_OK;
+  } catch (const SlgError &e) {
+    g_last_error = e.what();
+    return e.code;
+  } catch (const std::bad_alloc &) {
+    g_last_error = "host allocation failed";
+    return SLG_ERR_OOM;
+  } catch (const std::exception &e) {
+    g_last_error = e.what();
+    return SLG_ERR_INTERNAL;
+  } catch (...) {
+    g_last_error = "unknown error";
+    return SLG_ERR_INTERNAL;
+  }
+}
+
+uint32_t env_u32(const char *name, uint32_t dflt) {
+  const char *v = std::getenv(name);
+  if (!v || !*v) return dflt;
+  return (uint32_t)std::strtoul(v, nullptr, 10);
+}
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  void alloc(size_t n) {
+    release();
+    if (n == 0) n = 16;
+    SLG_HIP(hipMalloc(&p, n));
+    bytes = n;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  ~DevBuf() { release(); }
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  template <typename T>
+  T *as() const {
+    return static_cast<T *>(p);
+  }
+};
+
+struct SegHost {
+  uint32_t n_docs = 0, n_terms = 0;
+  uint64_t n_postings = 0;
+  std::vector<uint64_t> term_offsets;
+  DevBuf d_docs, d_imps, d_deleted;
+  // vectors
+  uint32_t vec_dim = 0, vec_rows = 0;
+  int32_t vec_metric = 0;
+  DevBuf d_vec_offsets, d_vec_values;
+};
+
+}  // namespace
+
+struct slg_index {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::vector<std::unique_ptr<SegHost>> segs;
+  DevBuf d_segs;  // slg::SegDev[n_segs]
+  DevBuf d_vsegs; // slg::VecSegDev[n_segs]
+  uint64_t device_bytes = 0;
+  std::mutex mu;
+  // profiling of the scoring kernel
+  bool profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  size_t prof_used = 0;
+};
+
+struct slg_batch {
+  slg_index *idx = nullptr;
+  uint32_t nq = 0, k = 0;
+  int strategy = 0;
+  uint32_t n_sq = 0, n_slices = 0, n_terms = 0, n_bounds = 0;
+  uint64_t n_postings = 0;
+  std::vector<uint64_t> q_postings;  // per query (stats.postings_advanced)
+  DevBuf d_desc;                     // packed descriptors
+  const slg::SubQuery *d_sq = nullptr;
+  const slg::TermRef *d_terms = nullptr;
+  const uint32_t *d_slice_sq = nullptr;
+  const slg::QueryRef *d_queries = nullptr;
+  DevBuf d_bounds, d_slice_tk, d_slice_doc, d_q_scored;
+  DevBuf d_out_doc, d_out_seg, d_out_score, d_out_count;
+};
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    SLG_HIP(hipGetDevice(&prev));
+    if (prev != dev) SLG_HIP(hipSetDevice(dev));
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+int kregs_for(uint32_t k) {
+  if (k <= 64) return 1;
+  if (k <= 128) return 2;
+  if (k <= 256) return 4;
+  if (k <= 512) return 8;
+  return 16;
+}
+
+constexpr int kNSlot = 8;
+
+template <int KREGS>
+void launch_score_t(const slg::ScoreParams &sp, hipStream_t st) {
+  using Cfg = slg::ScoreCfg<kNSlot>;
+  const uint32_t blocks = (sp.n_slices + slg::kWavesPerBlock - 1) / slg::kWavesPerBlock;
+  const size_t lds = (size_t)slg::kWavesPerBlock * Cfg::kWaveLds;
+  hipLaunchKernelGGL((slg::score_slices_kernel<KREGS, kNSlot>), dim3(blocks), dim3(256), lds, st,
+                     sp);
+}
+void launch_score(const slg::ScoreParams &sp, hipStream_t st) {
+  switch (kregs_for(sp.k)) {
+    case 1: launch_score_t<1>(sp, st); break;
+    case 2: launch_score_t<2>(sp, st); break;
+    case 4: launch_score_t<4>(sp, st); break;
+    case 8: launch_score_t<8>(sp, st); break;
+    default: launch_score_t<16>(sp, st); break;
+  }
+  SLG_HIP(hipGetLastError());
+}
+
+template <int KREGS>
+void launch_merge_t(const slg::MergeParams &mp, hipStream_t st) {
+  const uint32_t blocks = (mp.nq + slg::kWavesPerBlock - 1) / slg::kWavesPerBlock;
+  hipLaunchKernelGGL((slg::merge_topk_kernel<KREGS>), dim3(blocks), dim3(256), 0, st, mp);
+}
+void launch_merge(const slg::MergeParams &mp, hipStream_t st) {
+  switch (kregs_for(mp.k)) {
+    case 1: launch_merge_t<1>(mp, st); break;
+    case 2: launch_merge_t<2>(mp, st); break;
+    case 4: launch_merge_t<4>(mp, st); break;
+    case 8: launch_merge_t<8>(mp, st); break;
+    default: launch_merge_t<16>(mp, st); break;
+  }
+  SLG_HIP(hipGetLastError());
+}
+
+template <int KREGS>
+void launch_shard_merge_t(const slg::ShardMergeParams &mp, hipStream_t st) {
+  const uint32_t blocks = (mp.nq + slg::kWavesPerBlock - 1) / slg::kWavesPerBlock;
+  hipLaunchKernelGGL((slg::merge_shards_kernel<KREGS>), dim3(blocks), dim3(256), 0, st, mp);
+}
+void launch_shard_merge(const slg::ShardMergeParams &mp, hipStream_t st) {
+  switch (kregs_for(mp.k)) {
+    case 1: launch_shard_merge_t<1>(mp, st); break;
+    case 2: launch_shard_merge_t<2>(mp, st); break;
+    case 4: launch_shard_merge_t<4>(mp, st); break;
+    case 8: launch_shard_merge_t<8>(mp, st); break;
+    default: launch_shard_merge_t<16>(mp, st); break;
+  }
+  SLG_HIP(hipGetLastError());
+}
+
+void validate_segment(const slg_segment_desc &d, uint32_t si) {
+  const std::string pfx = "segment " + std::to_string(si) + ": ";
+  SLG_REQUIRE(d.term_offsets != nullptr, pfx + "term_offsets is NULL");
+  SLG_REQUIRE(d.n_fields >= 1 && d.field_avgdl && d.field_doc_len, pfx + "field arrays missing");
+  SLG_REQUIRE(d.term_offsets[0] == 0, pfx + "term_offsets[0] != 0");
+  const uint64_t P = d.term_offsets[d.n_terms];
+  SLG_REQUIRE(P == 0 || (d.doc_ids && d.tfs), pfx + "doc_ids/tfs missing");
+  const bool deep = env_u32("SLG_VALIDATE", 1) != 0;
+  for (uint32_t t = 0; t < d.n_terms; t++) {
+    const uint64_t a = d.term_offsets[t], b = d.term_offsets[t + 1];
+    SLG_REQUIRE(b >= a, pfx + "term_offsets not monotone");
+    SLG_REQUIRE(b - a <= 0xFFFFFFFEull, pfx + "posting list too long");
+    if (d.term_field) SLG_REQUIRE(d.term_field[t] < d.n_fields, pfx + "term_field out of range");
+    if (deep) {
+      for (uint64_t i = a; i < b; i++) {
+        SLG_REQUIRE(d.doc_ids[i] != 0xFFFFFFFFu, pfx + "doc id u32::MAX is reserved");
+        SLG_REQUIRE(i == a || d.doc_ids[i] > d.doc_ids[i - 1],
+                    pfx + "doc ids not strictly increasing in term " + std::to_string(t));
+      }
+    }
+  }
+  if (d.vec_dim) {
+    SLG_REQUIRE(d.vec_offsets && (d.vec_values || d.vec_rows == 0), pfx + "vector arrays missing");
+    SLG_REQUIRE(d.vec_metric == SLG_METRIC_COSINE || d.vec_metric == SLG_METRIC_L2,
+                pfx + "bad vec_metric");
+    if (deep)
+      for (uint32_t i = 0; i < d.n_docs; i++)
+        SLG_REQUIRE(d.vec_offsets[i] == SLG_NO_VECTOR || d.vec_offsets[i] < d.vec_rows,
+                    pfx + "vec_offsets out of range");
+  }
+}
+
+void stage_segment(slg_index *ix, SegHost &sh, const slg_segment_desc &d) {
+  hipStream_t st = ix->stream;
+  sh.n_docs = d.n_docs;
+  sh.n_terms = d.n_terms;
+  sh.term_offsets.assign(d.term_offsets, d.term_offsets + d.n_terms + 1);
+  const uint64_t P = sh.term_offsets[d.n_terms];
+  sh.n_postings = P;
+
+  sh.d_docs.alloc(P * 4);
+  sh.d_imps.alloc(P * 4);
+  ix->device_bytes += sh.d_docs.bytes + sh.d_imps.bytes;
+  if (d.deleted) {
+    const size_t words = ((size_t)d.n_docs + 31) / 32;
+    std::vector<uint32_t> w(words ? words : 1, 0u);
+    std::memcpy(w.data(), d.deleted, ((size_t)d.n_docs + 7) / 8);
+    sh.d_deleted.alloc(w.size() * 4);
+    SLG_HIP(hipMemcpy(sh.d_deleted.p, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    ix->device_bytes += sh.d_deleted.bytes;
+  }
+  if (P > 0) {
+    // temporaries used only by the staging kernel
+    DevBuf d_tfs, d_offs, d_idf, d_tfield, d_avgdl, d_lenptrs;
+    std::vector<DevBuf> d_lens(d.n_fields);
+    d_tfs.alloc(P * 4);
+    SLG_HIP(hipMemcpyAsync(sh.d_docs.p, d.doc_ids, P * 4, hipMemcpyHostToDevice, st));
+    SLG_HIP(hipMemcpyAsync(d_tfs.p, d.tfs, P * 4, hipMemcpyHostToDevice, st));
+    d_offs.alloc(((size_t)d.n_terms + 1) * 8);
+    SLG_HIP(hipMemcpyAsync(d_offs.p, sh.term_offsets.data(), ((size_t)d.n_terms + 1) * 8,
+                           hipMemcpyHostToDevice, st));
+    // idf per term: query/bm25.rs:2 with df = postings.len() as f32 (wand.rs:108,471)
+    std::vector<float> idf(d.n_terms);
+    for (uint32_t t = 0; t < d.n_terms; t++) {
+      const float df = (float)(uint32_t)(sh.term_offsets[t + 1] - sh.term_offsets[t]);
+      idf[t] = fmaxf(logf((d.docs - df + 0.5f) / (df + 0.5f)), 0.0f) + 1.0f;
+    }
+    d_idf.alloc((size_t)d.n_terms * 4);
+    SLG_HIP(hipMemcpyAsync(d_idf.p, idf.data(), (size_t)d.n_terms * 4, hipMemcpyHostToDevice, st));
+    if (d.term_field) {
+      d_tfield.alloc((size_t)d.n_terms * 2);
+      SLG_HIP(hipMemcpyAsync(d_tfield.p, d.term_field, (size_t)d.n_terms * 2,
+                             hipMemcpyHostToDevice, st));
+    }
+    d_avgdl.alloc((size_t)d.n_fields * 4);
+    SLG_HIP(hipMemcpyAsync(d_avgdl.p, d.field_avgdl, (size_t)d.n_fields * 4,
+                           hipMemcpyHostToDevice, st));
+    std::vector<const float *> lenptrs(d.n_fields, nullptr);
+    for (uint32_t f = 0; f < d.n_fields; f++) {
+      if (d.field_doc_len[f] && d.n_docs) {
+        d_lens[f].alloc((size_t)d.n_docs * 4);
+        SLG_HIP(hipMemcpyAsync(d_lens[f].p, d.field_doc_len[f], (size_t)d.n_docs * 4,
+                               hipMemcpyHostToDevice, st));
+        lenptrs[f] = d_lens[f].as<float>();
+      }
+    }
+    d_lenptrs.alloc((size_t)d.n_fields * sizeof(float *));
+    SLG_HIP(hipMemcpyAsync(d_lenptrs.p, lenptrs.data(), (size_t)d.n_fields * sizeof(float *),
+                           hipMemcpyHostToDevice, st));
+    slg::StageParams sp{};
+    sp.n_postings = P;
+    sp.n_terms = d.n_terms;
+    sp.n_docs = d.n_docs;
+    sp.term_offsets = d_offs.as<uint64_t>();
+    sp.docs = sh.d_docs.as<uint32_t>();
+    sp.tfs = d_tfs.as<uint32_t>();
+    sp.term_idf = d_idf.as<float>();
+    sp.term_field = d.term_field ? d_tfield.as<uint16_t>() : nullptr;
+    sp.field_doc_len = d_lenptrs.as<const float *>();
+    sp.field_avgdl = d_avgdl.as<float>();
+    sp.k1 = d.k1;
+    sp.b = d.b;
+    sp.imps = sh.d_imps.as<float>();
+    const uint64_t want = (P + 255) / 256;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(want, 256ull * 32);
+    hipLaunchKernelGGL(slg::stage_impacts_kernel, dim3(blocks), dim3(256), 0, st, sp);
+    SLG_HIP(hipGetLastError());
+    SLG_HIP(hipStreamSynchronize(st));  // temporaries die here
+  }
+  if (d.vec_dim) {
+    sh.vec_dim = d.vec_dim;
+    sh.vec_rows = d.vec_rows;
+    sh.vec_metric = d.vec_metric;
+    sh.d_vec_offsets.alloc((size_t)d.n_docs * 4);
+    if (d.n_docs)
+      SLG_HIP(hipMemcpy(sh.d_vec_offsets.p, d.vec_offsets, (size_t)d.n_docs * 4,
+                        hipMemcpyHostToDevice));
+    const size_t vb = (size_t)d.vec_rows * d.vec_dim * 4;
+    sh.d_vec_values.alloc(vb);
+    if (vb) SLG_HIP(hipMemcpy(sh.d_vec_values.p, d.vec_values, vb, hipMemcpyHostToDevice));
+    ix->device_bytes += sh.d_vec_offsets.bytes + sh.d_vec_values.bytes;
+  }
+}
+
+template <typename T>
+size_t place(size_t &cursor, size_t count) {
+  cursor = (cursor + 15) & ~(size_t)15;
+  size_t at = cursor;
+  cursor += count * sizeof(T);
+  return at;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t slg_abi_version(void) { return SLG_ABI_VERSION; }
+
+const char *slg_last_error(void) { return g_last_error.c_str(); }
+
+int slg_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    g_last_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+    return SLG_ERR_DEVICE;
+  }
+  return n;
+}
+
+slg_index *slg_index_create(const slg_segment_desc *segs, uint32_t n_segs, int device) {
+  slg_index *ix = nullptr;
+  int rc = guarded([&] {
+    SLG_REQUIRE(segs != nullptr && n_segs >= 1, "segs is NULL or n_segs == 0");
+    for (uint32_t s = 0; s < n_segs; s++) validate_segment(segs[s], s);
+    int ndev = 0;
+    SLG_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev)
+      throw SlgError(SLG_ERR_DEVICE, "no such HIP device " + std::to_string(device));
+    ix = new slg_index();
+    ix->device = device;
+    DeviceGuard g(device);
+    hipDeviceProp_t prop;
+    SLG_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && env_u32("SLG_ALLOW_ANY_ARCH", 0) == 0)
+      throw SlgError(SLG_ERR_DEVICE,
+                     std::string("device is ") + prop.gcnArchName + ", this library targets gfx950");
+    SLG_HIP(hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking));
+    ix->stream = ix->own_stream;
+    for (uint32_t s = 0; s < n_segs; s++) {
+      ix->segs.emplace_back(new SegHost());
+      stage_segment(ix, *ix->segs[s], segs[s]);
+    }
+    std::vector<slg::SegDev> sd(n_segs);
+    std::vector<slg::VecSegDev> vd(n_segs);
+    for (uint32_t s = 0; s < n_segs; s++) {
+      sd[s].docs = ix->segs[s]->d_docs.as<uint32_t>();
+      sd[s].imps = ix->segs[s]->d_imps.as<float>();
+      sd[s].deleted = ix->segs[s]->d_deleted.as<uint32_t>();
+      sd[s].n_docs = ix->segs[s]->n_docs;
+      sd[s].pad = 0;
+      vd[s].offsets = ix->segs[s]->d_vec_offsets.as<uint32_t>();
+      vd[s].values = ix->segs[s]->d_vec_values.as<float>();
+      vd[s].n_docs = ix->segs[s]->n_docs;
+      vd[s].dim = ix->segs[s]->vec_dim;
+      vd[s].metric = ix->segs[s]->vec_metric;
+      vd[s].pad = 0;
+    }
+    ix->d_segs.alloc(n_segs * sizeof(slg::SegDev));
+    SLG_HIP(hipMemcpy(ix->d_segs.p, sd.data(), n_segs * sizeof(slg::SegDev), hipMemcpyHostToDevice));
+    ix->d_vsegs.alloc(n_segs * sizeof(slg::VecSegDev));
+    SLG_HIP(hipMemcpy(ix->d_vsegs.p, vd.data(), n_segs * sizeof(slg::VecSegDev),
+                      hipMemcpyHostToDevice));
+  });
+  if (rc != SLG_OK) {
+    std::string keep = g_last_error;
+    if (ix) slg_index_destroy(ix);
+    g_last_error = keep;
+    return nullptr;
+  }
+  return ix;
+}
+
+void slg_index_destroy(slg_index *ix) {
+  if (!ix) return;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  (void)hipSetDevice(ix->device);
+  if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+  for (auto &pr : ix->prof_events) {
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  ix->segs.clear();
+  ix->d_segs.release();
+  ix->d_vsegs.release();
+  if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
+  delete ix;
+  if (prev >= 0) (void)hipSetDevice(prev);
+}
+
+int slg_index_info(const slg_index *ix, uint32_t *n_segs, uint64_t *n_postings,
+                   uint64_t *device_bytes) {
+  return guarded([&] {
+    SLG_REQUIRE(ix != nullptr, "index is NULL");
+    uint64_t P = 0;
+    for (auto &s : ix->segs) P += s->n_postings;
+    if (n_segs) *n_segs = (uint32_t)ix->segs.size();
+    if (n_postings) *n_postings = P;
+    if (device_bytes) *device_bytes = ix->device_bytes;
+  });
+}
+
+int slg_index_set_stream(slg_index *ix, void *hip_stream) {
+  return guarded([&] {
+    SLG_REQUIRE(ix != nullptr, "index is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    SLG_HIP(hipStreamSynchronize(ix->stream));
+    ix->stream = hip_stream ? (hipStream_t)hip_stream : ix->own_stream;
+  });
+}
+
+slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offsets,
+                             const uint32_t *q_term_ids, const float *q_weights, uint32_t k,
+                             int strategy) {
+  slg_batch *b = nullptr;
+  int rc = guarded([&] {
+    SLG_REQUIRE(ix != nullptr, "index is NULL");
+    SLG_REQUIRE(nq == 0 || q_offsets != nullptr, "q_offsets is NULL");
+    SLG_REQUIRE(strategy == SLG_STRATEGY_BM25 || strategy == SLG_STRATEGY_WAND ||
+                    strategy == SLG_STRATEGY_BMW,
+                "unknown strategy");
+    if (k > SLG_MAX_K)
+      throw SlgError(SLG_ERR_UNSUPPORTED, "k > SLG_MAX_K (" + std::to_string(SLG_MAX_K) + ")");
+    const uint32_t n_segs = (uint32_t)ix->segs.size();
+    const uint32_t total_terms = nq ? q_offsets[nq] : 0;
+    SLG_REQUIRE(total_terms == 0 || (q_term_ids && q_weights), "q_term_ids/q_weights is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+
+    b = new slg_batch();
+    b->idx = ix;
+    b->nq = nq;
+    b->k = k;
+    b->strategy = strategy;
+    b->q_postings.assign(nq, 0);
+
+    // ---- pass 1: sub-queries and their terms (api/reader.rs:2986-3005) ----
+    std::vector<slg::SubQuery> sqs;
+    std::vector<slg::TermRef> terms;
+    std::vector<uint64_t> sq_postings;
+    std::vector<uint32_t> q_sq_begin(nq + 1, 0);
+    for (uint32_t q = 0; q < nq; q++) {
+      q_sq_begin[q] = (uint32_t)sqs.size();
+      SLG_REQUIRE(q_offsets[q + 1] >= q_offsets[q], "q_offsets not monotone");
+      const uint32_t t0 = q_offsets[q], nt = q_offsets[q + 1] - t0;
+      if (nt > SLG_MAX_QUERY_TERMS)
+        throw SlgError(SLG_ERR_UNSUPPORTED, "query " + std::to_string(q) + " has more than " +
+                                                std::to_string(SLG_MAX_QUERY_TERMS) + " terms");
+      if (k == 0) continue;  // wand.rs:413-416: k == 0 and no collector => no work
+      for (uint32_t s = 0; s < n_segs; s++) {
+        const SegHost &sh = *ix->segs[s];
+        slg::SubQuery sq{};
+        sq.q = q;
+        sq.seg = s;
+        sq.term_begin = (uint32_t)terms.size();
+        uint64_t P = 0;
+        uint32_t longest = 0, longest_df = 0;
+        for (uint32_t i = 0; i < nt; i++) {
+          const uint32_t tid = q_term_ids[(size_t)(t0 + i) * n_segs + s];
+          if (tid == SLG_NO_TERM) continue;
+          SLG_REQUIRE(tid < sh.n_terms, "term id out of range in query " + std::to_string(q));
+          const uint64_t off = sh.term_offsets[tid];
+          const uint32_t df = (uint32_t)(sh.term_offsets[tid + 1] - off);
+          if (df == 0) continue;  // wand.rs:441 filter(postings.len() > 0)
+          const float w = q_weights[t0 + i];
+          SLG_REQUIRE(std::isfinite(w), "non-finite weight in query " + std::to_string(q));
+          const uint32_t local = (uint32_t)terms.size() - sq.term_begin;
+          if (df > longest_df) {
+            longest_df = df;
+            longest = local;
+          }
+          terms.push_back(slg::TermRef{off, df, w});
+          P += df;
+        }
+        sq.n_terms = (uint32_t)terms.size() - sq.term_begin;
+        if (sq.n_terms == 0) continue;
+        sq.longest = longest;
+        sqs.push_back(sq);
+        sq_postings.push_back(P);
+        b->q_postings[q] += P;
+        b->n_postings += P;
+      }
+    }
+    q_sq_begin[nq] = (uint32_t)sqs.size();
+
+    // ---- pass 2: cut sub-queries into doc-range slices of ~G postings ----
+    const uint32_t target_slices = env_u32("SLG_TARGET_SLICES", 16384);
+    uint64_t G = env_u32("SLG_SLICE_POSTINGS", 0);
+    if (G == 0) {
+      G = b->n_postings / std::max<uint32_t>(target_slices, 1);
+      G = std::max<uint64_t>(G, env_u32("SLG_MIN_SLICE_POSTINGS", 4096));
+      G = std::min<uint64_t>(G, 1u << 20);
+    }
+    std::vector<uint32_t> slice_sq;
+    uint64_t n_bounds = 0;
+    for (size_t i = 0; i < sqs.size(); i++) {
+      slg::SubQuery &sq = sqs[i];
+      uint64_t S = (sq_postings[i] + G - 1) / G;
+      const uint32_t dfL = terms[sq.term_begin + sq.longest].df;
+      S = std::max<uint64_t>(1, std::min<uint64_t>(S, dfL));
+      S = std::min<uint64_t>(S, 1u << 16);
+      sq.slice_begin = (uint32_t)slice_sq.size();
+      sq.n_slices = (uint32_t)S;
+      SLG_REQUIRE(n_bounds + S * sq.n_terms < 0xFFFFFFFFull, "batch too large (bounds)");
+      sq.bounds_begin = (uint32_t)n_bounds;
+      n_bounds += S * sq.n_terms;
+      SLG_REQUIRE(slice_sq.size() + S < 0x7FFFFFFFull, "batch too large (slices)");
+      for (uint32_t j = 0; j < S; j++) slice_sq.push_back((uint32_t)i);
+    }
+    std::vector<slg::QueryRef> qrefs(nq);
+    for (uint32_t q = 0; q < nq; q++) {
+      const uint32_t a = q_sq_begin[q], e = q_sq_begin[q + 1];
+      if (a == e) {
+        qrefs[q] = slg::QueryRef{0, 0};
+      } else {
+        qrefs[q].slice_begin = sqs[a].slice_begin;
+        qrefs[q].slice_end = sqs[e - 1].slice_begin + sqs[e - 1].n_slices;
+      }
+    }
+    b->n_sq = (uint32_t)sqs.size();
+    b->n_terms = (uint32_t)terms.size();
+    b->n_slices = (uint32_t)slice_sq.size();
+    b->n_bounds = (uint32_t)n_bounds;
+
+    // ---- pack descriptors, one H2D copy ----
+    size_t cur = 0;
+    const size_t o_sq = place<slg::SubQuery>(cur, sqs.size());
+    const size_t o_terms = place<slg::TermRef>(cur, terms.size());
+    const size_t o_slice = place<uint32_t>(cur, slice_sq.size());
+    const size_t o_q = place<slg::QueryRef>(cur, qrefs.size());
+    const size_t total = (cur + 15) & ~(size_t)15;
+    void *hbuf = nullptr;
+    SLG_HIP(hipHostMalloc(&hbuf, total ? total : 16, hipHostMallocDefault));
+    struct HostFree {
+      void *p;
+      ~HostFree() { (void)hipHostFree(p); }
+    } hf{hbuf};
+    unsigned char *hb = static_cast<unsigned char *>(hbuf);
+    if (!sqs.empty()) std::memcpy(hb + o_sq, sqs.data(), sqs.size() * sizeof(slg::SubQuery));
+    if (!terms.empty()) std::memcpy(hb + o_terms, terms.data(), terms.size() * sizeof(slg::TermRef));
+    if (!slice_sq.empty()) std::memcpy(hb + o_slice, slice_sq.data(), slice_sq.size() * 4);
+    if (!qrefs.empty()) std::memcpy(hb + o_q, qrefs.data(), qrefs.size() * sizeof(slg::QueryRef));
+    b->d_desc.alloc(total);
+    SLG_HIP(hipMemcpyAsync(b->d_desc.p, hbuf, total, hipMemcpyHostToDevice, ix->stream));
+    unsigned char *db = b->d_desc.as<unsigned char>();
+    b->d_sq = reinterpret_cast<const slg::SubQuery *>(db + o_sq);
+    b->d_terms = reinterpret_cast<const slg::TermRef *>(db + o_terms);
+    b->d_slice_sq = reinterpret_cast<const uint32_t *>(db + o_slice);
+    b->d_queries = reinterpret_cast<const slg::QueryRef *>(db + o_q);
+
+    b->d_bounds.alloc((size_t)n_bounds * 4);
+    b->d_slice_tk.alloc((size_t)b->n_slices * k * 4);
+    b->d_slice_doc.alloc((size_t)b->n_slices * k * 4);
+    b->d_q_scored.alloc((size_t)nq * 4);
+    b->d_out_doc.alloc((size_t)nq * k * 4);
+    b->d_out_seg.alloc((size_t)nq * k * 4);
+    b->d_out_score.alloc((size_t)nq * k * 4);
+    b->d_out_count.alloc((size_t)nq * 4);
+    SLG_HIP(hipStreamSynchronize(ix->stream));  // pinned staging buffer is freed on return
+  });
+  if (rc != SLG_OK) {
+    std::string keep = g_last_error;
+    delete b;
+    g_last_error = keep;
+    return nullptr;
+  }
+  return b;
+}
+
+int slg_batch_run(slg_batch *b) {
+  return guarded([&] {
+    SLG_REQUIRE(b != nullptr, "batch is NULL");
+    slg_index *ix = b->idx;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    hipStream_t st = ix->stream;
+    if (b->nq == 0) return;
+    SLG_HIP(hipMemsetAsync(b->d_q_scored.p, 0, (size_t)b->nq * 4, st));
+    if (b->n_slices > 0) {
+      slg::PartParams pp{};
+      pp.sq = b->d_sq;
+      pp.terms = b->d_terms;
+      pp.slice_sq = b->d_slice_sq;
+      pp.segs = ix->d_segs.as<slg::SegDev>();
+      pp.bounds = b->d_bounds.as<uint32_t>();
+      pp.n_slices = b->n_slices;
+      const uint32_t blocks = (b->n_slices + slg::kWavesPerBlock - 1) / slg::kWavesPerBlock;
+      hipLaunchKernelGGL(slg::partition_kernel, dim3(blocks), dim3(256), 0, st, pp);
+      SLG_HIP(hipGetLastError());
+
+      slg::ScoreParams sp{};
+      sp.sq = b->d_sq;
+      sp.terms = b->d_terms;
+      sp.slice_sq = b->d_slice_sq;
+      sp.segs = ix->d_segs.as<slg::SegDev>();
+      sp.bounds = b->d_bounds.as<uint32_t>();
+      sp.slice_tk = b->d_slice_tk.as<int32_t>();
+      sp.slice_doc = b->d_slice_doc.as<uint32_t>();
+      sp.q_scored = b->d_q_scored.as<uint32_t>();
+      sp.n_slices = b->n_slices;
+      sp.k = b->k;
+      std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+      if (ix->profile) {
+        if (ix->prof_used == ix->prof_events.size()) {
+          hipEvent_t a, c;
+          SLG_HIP(hipEventCreate(&a));
+          SLG_HIP(hipEventCreate(&c));
+          ix->prof_events.emplace_back(a, c);
+        }
+        ev = &ix->prof_events[ix->prof_used++];
+        SLG_HIP(hipEventRecord(ev->first, st));
+      }
+      launch_score(sp, st);
+      if (ev) SLG_HIP(hipEventRecord(ev->second, st));
+    }
+    if (b->k > 0) {
+      slg::MergeParams mp{};
+      mp.queries = b->d_queries;
+      mp.sq = b->d_sq;
+      mp.slice_sq = b->d_slice_sq;
+      mp.slice_tk = b->d_slice_tk.as<int32_t>();
+      mp.slice_doc = b->d_slice_doc.as<uint32_t>();
+      mp.out_doc = b->d_out_doc.as<uint32_t>();
+      mp.out_seg = b->d_out_seg.as<uint32_t>();
+      mp.out_score = b->d_out_score.as<float>();
+      mp.out_count = b->d_out_count.as<uint32_t>();
+      mp.nq = b->nq;
+      mp.k = b->k;
+      launch_merge(mp, st);
+    } else {
+      SLG_HIP(hipMemsetAsync(b->d_out_count.p, 0, (size_t)b->nq * 4, st));
+    }
+  });
+}
+
+int slg_batch_sync(slg_batch *b) {
+  return guarded([&] {
+    SLG_REQUIRE(b != nullptr, "batch is NULL");
+    DeviceGuard g(b->idx->device);
+    SLG_HIP(hipStreamSynchronize(b->idx->stream));
+  });
+}
+
+int slg_batch_fetch(slg_batch *b, uint32_t *out_doc, uint32_t *out_seg, float *out_score,
+                    uint32_t *out_count, slg_stats *stats) {
+  return guarded([&] {
+    SLG_REQUIRE(b != nullptr, "batch is NULL");
+    SLG_REQUIRE(b->nq == 0 || (out_count != nullptr), "out_count is NULL");
+    SLG_REQUIRE(b->nq == 0 || b->k == 0 || (out_doc && out_seg && out_score), "output array is NULL");
+    slg_index *ix = b->idx;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    hipStream_t st = ix->stream;
+    const size_t n = (size_t)b->nq * b->k;
+    if (n) {
+      SLG_HIP(hipMemcpyAsync(out_doc, b->d_out_doc.p, n * 4, hipMemcpyDeviceToHost, st));
+      SLG_HIP(hipMemcpyAsync(out_seg, b->d_out_seg.p, n * 4, hipMemcpyDeviceToHost, st));
+      SLG_HIP(hipMemcpyAsync(out_score, b->d_out_score.p, n * 4, hipMemcpyDeviceToHost, st));
+    }
+    std::vector<uint32_t> scored;
+    if (b->nq) {
+      SLG_HIP(hipMemcpyAsync(out_count, b->d_out_count.p, (size_t)b->nq * 4, hipMemcpyDeviceToHost, st));
+      if (stats) {
+        scored.resize(b->nq);
+        SLG_HIP(hipMemcpyAsync(scored.data(), b->d_q_scored.p, (size_t)b->nq * 4,
+                               hipMemcpyDeviceToHost, st));
+      }
+    }
+    SLG_HIP(hipStreamSynchronize(st));
+    if (stats)
+      for (uint32_t q = 0; q < b->nq; q++) {
+        // brute-force accounting: wand.rs:472 (postings_advanced += len), :500-503
+        stats[q].postings_advanced = b->q_postings[q];
+        stats[q].scored_docs = scored[q];
+        stats[q].candidates_examined = scored[q];
+      }
+  });
+}
+
+int slg_batch_device_results(slg_batch *b, void **d_doc, void **d_seg, void **d_score,
+                             void **d_count) {
+  return guarded([&] {
+    SLG_REQUIRE(b != nullptr, "batch is NULL");
+    if (d_doc) *d_doc = b->d_out_doc.p;
+    if (d_seg) *d_seg = b->d_out_seg.p;
+    if (d_score) *d_score = b->d_out_score.p;
+    if (d_count) *d_count = b->d_out_count.p;
+  });
+}
+
+int slg_batch_info(const slg_batch *b, uint64_t *n_postings, uint32_t *n_slices,
+                   uint64_t *algorithmic_bytes) {
+  return guarded([&] {
+    SLG_REQUIRE(b != nullptr, "batch is NULL");
+    if (n_postings) *n_postings = b->n_postings;
+    if (n_slices) *n_slices = b->n_slices;
+    if (algorithmic_bytes) *algorithmic_bytes = 12ull * b->n_postings + 8ull * b->k * b->nq;
+  });
+}
+
+void slg_batch_destroy(slg_batch *b) {
+  if (!b) return;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  (void)hipSetDevice(b->idx->device);
+  (void)hipStreamSynchronize(b->idx->stream);
+  delete b;
+  if (prev >= 0) (void)hipSetDevice(prev);
+}
+
+int slg_search_batch(slg_index *ix, const slg_query *queries, uint32_t nq, uint32_t k,
+                     int strategy, uint32_t *out_doc, uint32_t *out_seg, float *out_score,
+                     uint32_t *out_count, slg_stats *stats) {
+  slg_batch *b = nullptr;
+  int rc = guarded([&] {
+    SLG_REQUIRE(ix != nullptr, "index is NULL");
+    SLG_REQUIRE(nq == 0 || queries != nullptr, "queries is NULL");
+  });
+  if (rc != SLG_OK) return rc;
+  std::vector<uint32_t> offs(nq + 1, 0), tids;
+  std::vector<float> ws;
+  rc = guarded([&] {
+    const size_t n_segs = ix->segs.size();
+    for (uint32_t q = 0; q < nq; q++) {
+      const slg_query &qq = queries[q];
+      SLG_REQUIRE(qq.n_terms == 0 || (qq.term_ids && qq.weights), "query arrays are NULL");
+      offs[q + 1] = offs[q] + qq.n_terms;
+      tids.insert(tids.end(), qq.term_ids, qq.term_ids + (size_t)qq.n_terms * n_segs);
+      ws.insert(ws.end(), qq.weights, qq.weights + qq.n_terms);
+    }
+  });
+  if (rc != SLG_OK) return rc;
+  b = slg_batch_prepare(ix, nq, offs.data(), tids.data(), ws.data(), k, strategy);
+  if (!b) {
+    // slg_batch_prepare already set the thread-local error; map it back to a code
+    return g_last_error.find("SLG_MAX") != std::string::npos ||
+                   g_last_error.find("more than") != std::string::npos
+               ? SLG_ERR_UNSUPPORTED
+               : SLG_ERR_INVALID;
+  }
+  rc = slg_batch_run(b);
+  if (rc == SLG_OK) rc = slg_batch_fetch(b, out_doc, out_seg, out_score, out_count, stats);
+  std::string keep = g_last_error;
+  slg_batch_destroy(b);
+  g_last_error = keep;
+  return rc;
+}
+
+int slg_merge_shards_device(slg_index *ix, uint32_t n_shards, uint32_t nq, uint32_t k,
+                            const uint32_t *d_doc, const uint32_t *d_seg, const float *d_score,
+                            const uint32_t *d_count, uint32_t seg_stride, uint32_t *d_out_doc,
+                            uint32_t *d_out_seg, float *d_out_score, uint32_t *d_out_count) {
+  return guarded([&] {
+    SLG_REQUIRE(ix != nullptr, "index is NULL");
+    if (k > SLG_MAX_K) throw SlgError(SLG_ERR_UNSUPPORTED, "k > SLG_MAX_K");
+    if (nq == 0) return;
+    SLG_REQUIRE(d_count && d_out_count, "count arrays are NULL");
+    SLG_REQUIRE(k == 0 || (d_doc && d_seg && d_score && d_out_doc && d_out_seg && d_out_score),
+                "device arrays are NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    if (k == 0) {
+      SLG_HIP(hipMemsetAsync(d_out_count, 0, (size_t)nq * 4, ix->stream));
+      return;
+    }
+    slg::ShardMergeParams mp{};
+    mp.doc = d_doc;
+    mp.seg = d_seg;
+    mp.score = d_score;
+    mp.count = d_count;
+    mp.out_doc = d_out_doc;
+    mp.out_seg = d_out_seg;
+    mp.out_score = d_out_score;
+    mp.out_count = d_out_count;
+    mp.n_shards = n_shards;
+    mp.nq = nq;
+    mp.k = k;
+    mp.seg_stride = seg_stride;
+    launch_shard_merge(mp, ix->stream);
+  });
+}
+
+int slg_profile_enable(slg_index *ix, int on) {
+  return guarded([&] {
+    SLG_REQUIRE(ix != nullptr, "index is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    ix->profile = on != 0;
+  });
+}
+
+int slg_profile_read(slg_index *ix, uint32_t *n_launches, float *total_ms) {
+  return guarded([&] {
+    SLG_REQUIRE(ix != nullptr, "index is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    float sum = 0.0f;
+    for (size_t i = 0; i < ix->prof_used; i++) {
+      SLG_HIP(hipEventSynchronize(ix->prof_events[i].second));
+      float ms = 0.0f;
+      SLG_HIP(hipEventElapsedTime(&ms, ix->prof_events[i].first, ix->prof_events[i].second));
+      sum += ms;
+    }
+    if (n_launches) *n_launches = (uint32_t)ix->prof_used;
+    if (total_ms) *total_ms = sum;
+    ix->prof_used = 0;
+  });
+}
+
+int slg_rerank_batch_device(slg_index *ix, uint32_t nq, const float *d_qvecs, const float *d_alpha,
+                            const uint32_t *d_cand_doc, const uint32_t *d_cand_seg,
+                            const float *d_cand_bm25, const uint32_t *d_cand_count,
+                            uint32_t max_cand, uint32_t k_out, uint32_t *d_out_doc,
+                            uint32_t *d_out_seg, float *d_out_score, float *d_out_vec_score,
+                            uint32_t *d_out_count) {
+  return guarded([&] {
+    SLG_REQUIRE(ix != nullptr, "index is NULL");
+    if (k_out > SLG_MAX_K) throw SlgError(SLG_ERR_UNSUPPORTED, "k_out > SLG_MAX_K");
+    if (nq == 0) return;
+    SLG_REQUIRE(d_qvecs && d_alpha && d_cand_count && d_out_count, "device arrays are NULL");
+    SLG_REQUIRE(max_cand == 0 || (d_cand_doc && d_cand_seg && d_cand_bm25), "candidate arrays are NULL");
+    SLG_REQUIRE(k_out == 0 || (d_out_doc && d_out_seg && d_out_score), "output arrays are NULL");
+    uint32_t dim = 0;
+    for (auto &s : ix->segs)
+      if (s->vec_dim) {
+        SLG_REQUIRE(dim == 0 || dim == s->vec_dim, "segments disagree on vec_dim");
+        dim = s->vec_dim;
+      }
+    if (dim == 0) throw SlgError(SLG_ERR_UNSUPPORTED, "index has no vector field");
+    if (max_cand > slg::kRerankMaxCand)
+      throw SlgError(SLG_ERR_UNSUPPORTED, "max_cand > " + std::to_string(slg::kRerankMaxCand));
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    slg::RerankParams rp{};
+    rp.vsegs = ix->d_vsegs.as<slg::VecSegDev>();
+    rp.n_segs = (uint32_t)ix->segs.size();
+    rp.dim = dim;
+    rp.qvecs = d_qvecs;
+    rp.alpha = d_alpha;
+    rp.cand_doc = d_cand_doc;
+    rp.cand_seg = d_cand_seg;
+    rp.cand_bm25 = d_cand_bm25;
+    rp.cand_count = d_cand_count;
+    rp.max_cand = max_cand;
+    rp.k_out = k_out;
+    rp.out_doc = d_out_doc;
+    rp.out_seg = d_out_seg;
+    rp.out_score = d_out_score;
+    rp.out_vec = d_out_vec_score;
+    rp.out_count = d_out_count;
+    rp.nq = nq;
+    slg::launch_rerank(rp, kregs_for(k_out ? k_out : 1), ix->stream);
+    SLG_HIP(hipGetLastError());
+  });
+}
+
+int slg_rerank_batch(slg_index *ix, uint32_t nq, const float *qvecs, const float *alpha,
+                     const uint32_t *cand_doc, const uint32_t *cand_seg, const float *cand_bm25,
+                     const uint32_t *cand_count, uint32_t max_cand, uint32_t k_out,
+                     uint32_t *out_doc, uint32_t *out_seg, float *out_score, float *out_vec_score,
+                     uint32_t *out_count) {
+  int rc = guarded([&] {
+    SLG_REQUIRE(ix != nullptr, "index is NULL");
+    if (nq == 0) return;
+    SLG_REQUIRE(qvecs && alpha && cand_count && out_count, "host arrays are NULL");
+    SLG_REQUIRE(max_cand == 0 || (cand_doc && cand_seg && cand_bm25), "candidate arrays are NULL");
+    SLG_REQUIRE(k_out == 0 || (out_doc && out_seg && out_score), "output arrays are NULL");
+  });
+  if (rc != SLG_OK || nq == 0) return rc;
+  uint32_t dim = 0;
+  for (auto &s : ix->segs)
+    if (s->vec_dim) dim = s->vec_dim;
+  if (dim == 0) {
+    g_last_error = "index has no vector field";
+    return SLG_ERR_UNSUPPORTED;
+  }
+  DevBuf dq, da, dcd, dcs, dcb, dcc, dod, dos, dosc, dov, doc_;
+  const size_t nc = (size_t)nq * max_cand, no = (size_t)nq * k_out;
+  rc = guarded([&] {
+    DeviceGuard g(ix->device);
+    hipStream_t st = ix->stream;
+    dq.alloc((size_t)nq * dim * 4);
+    da.alloc((size_t)nq * 4);
+    dcd.alloc(nc * 4);
+    dcs.alloc(nc * 4);
+    dcb.alloc(nc * 4);
+    dcc.alloc((size_t)nq * 4);
+    dod.alloc(no * 4);
+    dos.alloc(no * 4);
+    dosc.alloc(no * 4);
+    dov.alloc(no * 4);
+    doc_.alloc((size_t)nq * 4);
+    SLG_HIP(hipMemcpyAsync(dq.p, qvecs, (size_t)nq * dim * 4, hipMemcpyHostToDevice, st));
+    SLG_HIP(hipMemcpyAsync(da.p, alpha, (size_t)nq * 4, hipMemcpyHostToDevice, st));
+    if (nc) {
+      SLG_HIP(hipMemcpyAsync(dcd.p, cand_doc, nc * 4, hipMemcpyHostToDevice, st));
+      SLG_HIP(hipMemcpyAsync(dcs.p, cand_seg, nc * 4, hipMemcpyHostToDevice, st));
+      SLG_HIP(hipMemcpyAsync(dcb.p, cand_bm25, nc * 4, hipMemcpyHostToDevice, st));
+    }
+    SLG_HIP(hipMemcpyAsync(dcc.p, cand_count, (size_t)nq * 4, hipMemcpyHostToDevice, st));
+  });
+  if (rc != SLG_OK) return rc;
+  rc = slg_rerank_batch_device(ix, nq, dq.as<float>(), da.as<float>(), dcd.as<uint32_t>(),
+                               dcs.as<uint32_t>(), dcb.as<float>(), dcc.as<uint32_t>(), max_cand,
+                               k_out, dod.as<uint32_t>(), dos.as<uint32_t>(), dosc.as<float>(),
+                               dov.as<float>(), doc_.as<uint32_t>());
+  if (rc != SLG_OK) return rc;
+  return guarded([&] {
+    DeviceGuard g(ix->device);
+    hipStream_t st = ix->stream;
+    if (no) {
+      SLG_HIP(hipMemcpyAsync(out_doc, dod.p, no * 4, hipMemcpyDeviceToHost, st));
+      SLG_HIP(hipMemcpyAsync(out_seg, dos.p, no * 4, hipMemcpyDeviceToHost, st));
+      SLG_HIP(hipMemcpyAsync(out_score, dosc.p, no * 4, hipMemcpyDeviceToHost, st));
+      if (out_vec_score)
+        SLG_HIP(hipMemcpyAsync(out_vec_score, dov.p, no * 4, hipMemcpyDeviceToHost, st));
+    }
+    SLG_HIP(hipMemcpyAsync(out_count, doc_.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    SLG_HIP(hipStreamSynchronize(st));
+  });
+}
+
+}  // extern "C"

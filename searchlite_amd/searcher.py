@@ -1,0 +1,247 @@
+"""Host mirror of the scorer interface, on top of the C ABI.
+
+Names follow searchlite-core (query/wand.rs): `ScoredTerm`-style term lists, `execute_top_k`,
+`RankedDoc`-style (doc_id, score) results, `QueryStats`.  GpuIndex owns an `slg_index`
+(device-resident segments); PreparedBatch owns an `slg_batch`.
+
+No CPU fallback lives here: every search goes through libsearchlite_gpu.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native as N
+from .segment import Segment, fold_terms, parse_query_terms, resolve_query
+
+Bm25, Wand, Bmw = N.STRATEGY_BM25, N.STRATEGY_WAND, N.STRATEGY_BMW  # api/types.rs:6-13
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data
+
+
+def device_count() -> int:
+    n = N.load().slg_device_count()
+    if n < 0:
+        raise N.SlgError(n, N.last_error())
+    return n
+
+
+class GpuIndex:
+    """All segments of one shard, staged in HBM (slg_index_create)."""
+
+    def __init__(self, segments: Sequence[Segment], device: int = 0):
+        self._lib = N.load()
+        self.segments = list(segments)
+        self.device = device
+        descs = (N.SegmentDesc * len(self.segments))()
+        keep = []
+        for i, s in enumerate(self.segments):
+            nf = len(s.field_doc_len)
+            ptrs = (C.c_void_p * nf)(*[_ptr(a) for a in s.field_doc_len])
+            keep.append(ptrs)
+            vec_rows = 0 if s.vec_values is None else int(s.vec_values.shape[0])
+            descs[i] = N.SegmentDesc(
+                s.n_docs, s.n_terms, _ptr(s.term_offsets), _ptr(s.doc_ids), _ptr(s.tfs),
+                _ptr(s.term_field), nf, C.addressof(ptrs), _ptr(s.field_avgdl),
+                s.docs, s.k1, s.b, _ptr(s.deleted),
+                s.vec_dim, s.vec_metric, _ptr(s.vec_offsets), _ptr(s.vec_values), vec_rows)
+        self._h = self._lib.slg_index_create(descs, len(self.segments), device)
+        if not self._h:
+            raise N.SlgError(N.ERR_INVALID, N.last_error())
+
+    # -- lifecycle -------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.slg_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def n_segs(self) -> int:
+        return len(self.segments)
+
+    def info(self):
+        ns, npost, nbytes = C.c_uint32(), C.c_uint64(), C.c_uint64()
+        N.check(self._lib.slg_index_info(self._h, C.addressof(ns), C.addressof(npost),
+                                         C.addressof(nbytes)))
+        return {"n_segs": ns.value, "n_postings": npost.value, "device_bytes": nbytes.value}
+
+    def set_stream(self, hip_stream: int) -> None:
+        """Run on an external hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+        N.check(self._lib.slg_index_set_stream(self._h, C.c_void_p(hip_stream or None)))
+
+    def profile(self, on: bool) -> None:
+        N.check(self._lib.slg_profile_enable(self._h, int(on)))
+
+    def profile_read(self) -> Tuple[int, float]:
+        n, ms = C.c_uint32(), C.c_float()
+        N.check(self._lib.slg_profile_read(self._h, C.addressof(n), C.addressof(ms)))
+        return n.value, ms.value
+
+    # -- search ----------------------------------------------------------------------
+    def prepare(self, q_offsets, q_terms, q_weights, k: int, strategy: int = Wand
+                ) -> "PreparedBatch":
+        return PreparedBatch(self, q_offsets, q_terms, q_weights, k, strategy)
+
+    def search_batch(self, q_offsets, q_terms, q_weights, k: int, strategy: int = Wand,
+                     want_stats: bool = False):
+        """One-shot slg_search_batch over CSR queries -> (doc, seg, score, count[, stats])."""
+        q_offsets = np.ascontiguousarray(q_offsets, dtype=np.uint32)
+        nq = len(q_offsets) - 1
+        q_terms = np.ascontiguousarray(q_terms, dtype=np.uint32).reshape(-1, self.n_segs)
+        q_weights = np.ascontiguousarray(q_weights, dtype=np.float32)
+        qs = (N.Query * max(nq, 1))()
+        for q in range(nq):
+            a, b = int(q_offsets[q]), int(q_offsets[q + 1])
+            qs[q] = N.Query(b - a, q_terms.ctypes.data + a * self.n_segs * 4,
+                            q_weights.ctypes.data + a * 4)
+        out_doc = np.zeros((nq, k), dtype=np.uint32)
+        out_seg = np.zeros((nq, k), dtype=np.uint32)
+        out_score = np.zeros((nq, k), dtype=np.float32)
+        out_count = np.zeros(nq, dtype=np.uint32)
+        stats = (N.Stats * max(nq, 1))() if want_stats else None
+        N.check(self._lib.slg_search_batch(self._h, qs, nq, k, strategy, _ptr(out_doc),
+                                           _ptr(out_seg), _ptr(out_score), _ptr(out_count),
+                                           None if stats is None else C.addressof(stats)))
+        if want_stats:
+            return out_doc, out_seg, out_score, out_count, stats
+        return out_doc, out_seg, out_score, out_count
+
+    def execute_top_k(self, terms: Sequence[Tuple[int, float]], k: int, strategy: int = Wand,
+                      segment: int = 0) -> List[Tuple[int, float]]:
+        """query/wand.rs:338-356 for one query against one segment: terms = [(term_id, weight)],
+        term i is leaf i.  Returns [(doc_id, score)] sorted score desc, doc asc."""
+        ids = np.full((len(terms), self.n_segs), N.NO_TERM, dtype=np.uint32)
+        for i, (tid, _) in enumerate(terms):
+            ids[i, segment] = tid
+        w = np.array([t[1] for t in terms], dtype=np.float32)
+        offs = np.array([0, len(terms)], dtype=np.uint32)
+        d, s, sc, c = self.search_batch(offs, ids, w, k, strategy)
+        return [(int(d[0, i]), float(sc[0, i])) for i in range(int(c[0]))]
+
+    def search(self, query: str, default_field: str, limit: int = 10, strategy: int = Wand):
+        """IndexReader::search for an eligible query string: k = limit + 1 is handed to the
+        scorer (api/reader.rs:2615-2619), hits truncated to limit (:2836-2852).
+        Returns [(segment_ord, doc_id, score)]."""
+        folded = fold_terms(parse_query_terms(query, default_field))
+        if not folded:
+            return []
+        ids, w = resolve_query(self.segments, folded)
+        offs = np.array([0, len(folded)], dtype=np.uint32)
+        d, s, sc, c = self.search_batch(offs, ids, w, limit + 1, strategy)
+        n = min(int(c[0]), limit)
+        return [(int(s[0, i]), int(d[0, i]), float(sc[0, i])) for i in range(n)]
+
+    # -- rerank ----------------------------------------------------------------------
+    def rerank_batch(self, qvecs, alpha, cand_doc, cand_seg, cand_bm25, cand_count, k_out: int):
+        """gpu::rerank slot (gpu/rerank.rs:3): vector similarity + alpha blend + top-k_out."""
+        qvecs = np.ascontiguousarray(qvecs, dtype=np.float32)
+        nq = qvecs.shape[0]
+        alpha = np.ascontiguousarray(np.broadcast_to(np.asarray(alpha, dtype=np.float32), (nq,)))
+        cand_doc = np.ascontiguousarray(cand_doc, dtype=np.uint32).reshape(nq, -1)
+        max_cand = cand_doc.shape[1]
+        cand_seg = np.ascontiguousarray(cand_seg, dtype=np.uint32).reshape(nq, max_cand)
+        cand_bm25 = np.ascontiguousarray(cand_bm25, dtype=np.float32).reshape(nq, max_cand)
+        cand_count = np.ascontiguousarray(cand_count, dtype=np.uint32)
+        out_doc = np.zeros((nq, k_out), dtype=np.uint32)
+        out_seg = np.zeros((nq, k_out), dtype=np.uint32)
+        out_score = np.zeros((nq, k_out), dtype=np.float32)
+        out_vec = np.zeros((nq, k_out), dtype=np.float32)
+        out_count = np.zeros(nq, dtype=np.uint32)
+        N.check(self._lib.slg_rerank_batch(self._h, nq, _ptr(qvecs), _ptr(alpha), _ptr(cand_doc),
+                                           _ptr(cand_seg), _ptr(cand_bm25), _ptr(cand_count),
+                                           max_cand, k_out, _ptr(out_doc), _ptr(out_seg),
+                                           _ptr(out_score), _ptr(out_vec), _ptr(out_count)))
+        return out_doc, out_seg, out_score, out_vec, out_count
+
+    def rerank_batch_device(self, nq, d_qvecs, d_alpha, d_cand_doc, d_cand_seg, d_cand_bm25,
+                            d_cand_count, max_cand, k_out, d_out_doc, d_out_seg, d_out_score,
+                            d_out_vec, d_out_count) -> None:
+        """Device-pointer form (ints), asynchronous on the index stream."""
+        N.check(self._lib.slg_rerank_batch_device(
+            self._h, nq, d_qvecs, d_alpha, d_cand_doc, d_cand_seg, d_cand_bm25, d_cand_count,
+            max_cand, k_out, d_out_doc, d_out_seg, d_out_score, d_out_vec, d_out_count))
+
+    def merge_shards_device(self, n_shards, nq, k, d_doc, d_seg, d_score, d_count, seg_stride,
+                            d_out_doc, d_out_seg, d_out_score, d_out_count) -> None:
+        N.check(self._lib.slg_merge_shards_device(self._h, n_shards, nq, k, d_doc, d_seg, d_score,
+                                                  d_count, seg_stride, d_out_doc, d_out_seg,
+                                                  d_out_score, d_out_count))
+
+
+class PreparedBatch:
+    """A planned query batch with device-resident descriptors and work buffers."""
+
+    def __init__(self, index: GpuIndex, q_offsets, q_terms, q_weights, k: int, strategy: int):
+        self.index = index
+        self._lib = index._lib
+        q_offsets = np.ascontiguousarray(q_offsets, dtype=np.uint32)
+        q_terms = np.ascontiguousarray(q_terms, dtype=np.uint32)
+        q_weights = np.ascontiguousarray(q_weights, dtype=np.float32)
+        self.nq = len(q_offsets) - 1
+        self.k = k
+        self._h = self._lib.slg_batch_prepare(index._h, self.nq, _ptr(q_offsets), _ptr(q_terms),
+                                              _ptr(q_weights), k, strategy)
+        if not self._h:
+            msg = N.last_error()
+            code = N.ERR_UNSUPPORTED if ("SLG_MAX" in msg or "more than" in msg) else N.ERR_INVALID
+            raise N.SlgError(code, msg)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.slg_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self) -> None:
+        N.check(self._lib.slg_batch_run(self._h))
+
+    def sync(self) -> None:
+        N.check(self._lib.slg_batch_sync(self._h))
+
+    def info(self):
+        npost, nsl, nbytes = C.c_uint64(), C.c_uint32(), C.c_uint64()
+        N.check(self._lib.slg_batch_info(self._h, C.addressof(npost), C.addressof(nsl),
+                                         C.addressof(nbytes)))
+        return {"n_postings": npost.value, "n_slices": nsl.value,
+                "algorithmic_bytes": nbytes.value}
+
+    def device_results(self):
+        """-> (d_doc, d_seg, d_score, d_count) raw device addresses."""
+        ptrs = [C.c_void_p() for _ in range(4)]
+        N.check(self._lib.slg_batch_device_results(self._h, *[C.addressof(p) for p in ptrs]))
+        return tuple(p.value for p in ptrs)
+
+    def fetch(self, want_stats: bool = False):
+        nq, k = self.nq, self.k
+        out_doc = np.zeros((nq, k), dtype=np.uint32)
+        out_seg = np.zeros((nq, k), dtype=np.uint32)
+        out_score = np.zeros((nq, k), dtype=np.float32)
+        out_count = np.zeros(nq, dtype=np.uint32)
+        stats = (N.Stats * max(nq, 1))() if want_stats else None
+        N.check(self._lib.slg_batch_fetch(self._h, _ptr(out_doc), _ptr(out_seg), _ptr(out_score),
+                                          _ptr(out_count),
+                                          None if stats is None else C.addressof(stats)))
+        if want_stats:
+            return out_doc, out_seg, out_score, out_count, stats
+        return out_doc, out_seg, out_score, out_count
