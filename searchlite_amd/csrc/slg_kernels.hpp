@@ -92,6 +92,10 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane) {
   }
   return x - v;
 }
+// lane l receives lane l-1's value (lane 0 keeps its own): one DPP move, no LDS traffic
+__device__ __forceinline__ int32_t wave_shr1(int32_t v) {
+  return __builtin_amdgcn_update_dpp(v, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
 // compiler-only ordering point for wave-synchronous LDS traffic (hardware keeps a wave's
 // DS instructions in order; this stops the compiler from moving them across phases)
 __device__ __forceinline__ void wave_fence() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }
@@ -145,9 +149,9 @@ struct WaveTopK {
     uint32_t pos_lane = (uint32_t)__popcll(full);  // fully-better lanes form a prefix
     uint32_t pos_r = pos_lane < 64 ? rl(cnt, pos_lane) : 0u;
     // value arriving from the previous lane's last register
-    int32_t up_tk = __shfl_up(tk[KREGS - 1], 1, 64);
-    uint32_t up_doc = __shfl_up(doc[KREGS - 1], 1, 64);
-    uint32_t up_seg = HAS_SEG ? __shfl_up(seg[KREGS - 1], 1, 64) : 0u;
+    int32_t up_tk = wave_shr1(tk[KREGS - 1]);
+    uint32_t up_doc = (uint32_t)wave_shr1((int32_t)doc[KREGS - 1]);
+    uint32_t up_seg = HAS_SEG ? (uint32_t)wave_shr1((int32_t)seg[KREGS - 1]) : 0u;
 #pragma unroll
     for (int r = KREGS - 1; r >= 0; r--) {
       bool shift = lane > pos_lane || (lane == pos_lane && (uint32_t)r > pos_r);
@@ -300,11 +304,25 @@ struct ScoreParams {
 
 template <int NSLOT>
 struct ScoreCfg {
-  static constexpr int kCap = NSLOT * 64;          // postings per round
+  static constexpr int kCap = NSLOT * 64;  // postings per round
   static constexpr int kLogSlots = 31 - __builtin_clz((unsigned)(2 * kCap - 1)) + 1;
-  static constexpr int kSlots = 1 << kLogSlots;    // hash slots (load <= 0.5)
-  static constexpr int kTermBytes = kMaxTerms * 8; // per-term absolute posting cursor
-  static constexpr int kWaveLds = kSlots * 8 + kTermBytes;
+  static constexpr int kSlots = 1 << kLogSlots;   // hash slots (load <= 0.5)
+  static constexpr int kLogBuckets = kLogSlots - 2;  // buckets of 4 keys (one ds_read_b128)
+  static constexpr int kBuckets = 1 << kLogBuckets;
+  static constexpr int kWaveLds = kSlots * 8;  // keys u32[kSlots] then vals f32[kSlots]
+};
+
+// One round's worth of postings held in registers (v = jj*64 + lane over the concatenated
+// per-list chunks) plus the per-list plan that produced it.
+template <int NSLOT>
+struct Round {
+  uint32_t doc[NSLOT];
+  float imp[NSLOT];
+  uint32_t et[NSLOT];   // list index of each element
+  uint32_t chunk;       // lane t: postings of list t loaded this round
+  uint32_t lastdoc;     // lane t: doc id that bounds the round if list t does not finish
+  uint32_t total;       // uniform: sum of chunks
+  uint32_t tfirst[NSLOT], tlast[NSLOT];  // uniform per slot: first / last list present
 };
 
 template <int KREGS, int NSLOT>
@@ -316,8 +334,9 @@ __global__ void __launch_bounds__(256) score_slices_kernel(ScoreParams p) {
   const uint32_t slice = rfl(blockIdx.x * kWavesPerBlock + wib);
   if (slice >= p.n_slices) return;  // no workgroup barriers anywhere: waves are independent
 
-  uint2 *table = reinterpret_cast<uint2 *>(smem + (size_t)wib * Cfg::kWaveLds);
-  uint64_t *tcur = reinterpret_cast<uint64_t *>(smem + (size_t)wib * Cfg::kWaveLds + Cfg::kSlots * 8);
+  uint32_t *keys = reinterpret_cast<uint32_t *>(smem + (size_t)wib * Cfg::kWaveLds);
+  uint32_t *vals = keys + Cfg::kSlots;
+  uint4 *keys4 = reinterpret_cast<uint4 *>(keys);
 
   const uint32_t sqi = rfl(p.slice_sq[slice]);
   const SubQuery s = p.sq[sqi];
@@ -343,19 +362,23 @@ __global__ void __launch_bounds__(256) score_slices_kernel(ScoreParams p) {
     if (my_end < my_cur) my_end = my_cur;
   }
 
-  // clear the hash table (keys only matter)
-  for (uint32_t i = lane; i < (uint32_t)Cfg::kSlots; i += 64) table[i] = make_uint2(kEmptyKey, 0u);
+  // clear the hash keys once; every round's owners restore kEmptyKey behind themselves
+  for (uint32_t i = lane; i < (uint32_t)(Cfg::kSlots / 4); i += 64)
+    keys4[i] = make_uint4(kEmptyKey, kEmptyKey, kEmptyKey, kEmptyKey);
   wave_fence();
 
   WaveTopK<KREGS, false> top;
   top.init();
   uint32_t n_scored = 0;
 
-  for (;;) {
+  // ---- plan a round at the current cursors and issue its loads.  Returns false if the
+  //      slice is exhausted.  All per-list bookkeeping is a scalar loop over t < T. ----
+  auto plan = [&](Round<NSLOT> &r) -> bool {
     const uint32_t rem = my_end - my_cur;
-    const uint32_t R = wave_sum(rem);  // (lists are < 2^32 each; slices are far smaller)
-    if (R == 0) break;
-    // ---- choose chunk sizes (sum <= kCap) and the round's doc-id bound ----
+    uint32_t R = 0;
+    for (uint32_t t = 0; t < T; t++) R += rl(rem, t);
+    r.total = 0;
+    if (R == 0) return false;
     uint32_t chunk;
     if (R <= (uint32_t)Cfg::kCap) {
       chunk = rem;
@@ -365,102 +388,146 @@ __global__ void __launch_bounds__(256) score_slices_kernel(ScoreParams p) {
       c = c < 1u ? 1u : c;
       chunk = rem == 0 ? 0u : (c < rem ? c : rem);
     }
-    const uint32_t start = wave_excl_scan(chunk, lane);
-    const uint32_t total = rfl(__shfl(start + chunk, 63, 64));
+    uint32_t start = 0, run = 0;
+    for (uint32_t t = 0; t < T; t++) {
+      start = lane == t ? run : start;
+      run += rl(chunk, t);
+    }
+    const uint32_t total = run;
+    r.total = total;
+    r.chunk = chunk;
     // a list that does not finish in this round bounds the round by its last loaded doc
-    uint32_t lastdoc = kDocEnd;
-    if (chunk < rem) lastdoc = gdocs[my_off + my_cur + chunk - 1];
-    if (lane < T) tcur[lane] = my_off + my_cur - start;  // absolute posting index of v = 0
-    wave_fence();
-    const uint32_t bound = wave_min(lastdoc);
-
-    // ---- load this round's postings: v = jj*64 + lane over the concatenated chunks ----
-    uint32_t e_doc[NSLOT], e_t[NSLOT];
-    float e_imp[NSLOT];
+    const uint64_t abs0 = my_off + my_cur;  // absolute index of the list's first loaded posting
+    r.lastdoc = kDocEnd;
+    if (chunk < rem) r.lastdoc = gdocs[abs0 + chunk - 1];
+    const uint64_t rel = abs0 - start;  // absolute index of v = 0 for this list (mod 2^64)
+    const uint32_t rel_lo = (uint32_t)rel, rel_hi = (uint32_t)(rel >> 32);
 #pragma unroll
     for (int jj = 0; jj < NSLOT; jj++) {
-      const uint32_t v = jj * 64 + lane;
-      uint32_t t = 0;
-      for (uint32_t tt = 1; tt < T; tt++) t += (v >= rl(start, tt)) ? 1u : 0u;
-      e_t[jj] = t;
-      e_doc[jj] = kDocEnd;
-      e_imp[jj] = 0.0f;
-      if (v < total) {
-        const uint64_t a = tcur[t] + v;
-        e_doc[jj] = gdocs[a];
-        e_imp[jj] = gimps[a];
+      r.doc[jj] = kDocEnd;
+      r.imp[jj] = 0.0f;
+      r.et[jj] = 0;
+      r.tfirst[jj] = 0;
+      r.tlast[jj] = 0;
+      const uint32_t v0 = jj * 64;
+      if (v0 < total) {  // uniform
+        const uint32_t vl = (total - v0) >= 64 ? v0 + 63 : total - 1;
+        uint32_t tf = 0, tl = 0;
+        for (uint32_t t = 1; t < T; t++) {
+          const uint32_t st = rl(start, t);
+          tf += v0 >= st ? 1u : 0u;
+          tl += vl >= st ? 1u : 0u;
+        }
+        r.tfirst[jj] = tf;
+        r.tlast[jj] = tl;
+        const uint32_t v = v0 + lane;
+        uint64_t a;
+        if (tf == tl) {  // the whole slot lies in one list: uniform base + lane
+          r.et[jj] = tf;
+          a = (((uint64_t)rl(rel_hi, tf) << 32) | rl(rel_lo, tf)) + v;
+        } else {
+          uint32_t t = tf;
+          for (uint32_t tt = tf + 1; tt <= tl; tt++) t += (v >= rl(start, tt)) ? 1u : 0u;
+          r.et[jj] = t;
+          a = (((uint64_t)__shfl(rel_hi, t, 64) << 32) | __shfl(rel_lo, t, 64)) + v;
+        }
+        if (v < total) {
+          r.doc[jj] = gdocs[a];
+          r.imp[jj] = gimps[a];
+        }
       }
     }
+    return true;
+  };
 
-    // ---- accumulate, one list at a time within each slot (term order == leaf order) ----
-    uint32_t consumed = 0;        // lane t: postings of list t accepted this round
-    uint32_t own_slot[NSLOT];     // hash slot this lane inserted (it owns the doc), or ~0
+  // ---- after the loads of `r` landed: fix the round's doc bound, mark the postings that
+  //      belong to it (returned as a per-lane bit mask) and advance the cursors. ----
+  auto finalize = [&](const Round<NSLOT> &r) -> uint32_t {
+    uint32_t bound = kDocEnd;
+    for (uint32_t t = 0; t < T; t++) {
+      const uint32_t ld = rl(r.lastdoc, t);
+      bound = ld < bound ? ld : bound;
+    }
+    uint32_t inmask = 0, consumed = 0;
+#pragma unroll
+    for (int jj = 0; jj < NSLOT; jj++) {
+      if ((uint32_t)(jj * 64) < r.total) {
+        const bool in_round = r.doc[jj] <= bound;  // out-of-range lanes hold kDocEnd... see below
+        const bool valid = (uint32_t)(jj * 64) + lane < r.total && in_round;
+        inmask |= valid ? (1u << jj) : 0u;
+        for (uint32_t tc = r.tfirst[jj]; tc <= r.tlast[jj]; tc++) {
+          const uint64_t am = __ballot(valid && r.et[jj] == tc);
+          consumed += lane == tc ? (uint32_t)__popcll(am) : 0u;
+        }
+      }
+    }
+    my_cur += consumed;
+    return inmask;
+  };
+
+  // ---- accumulate the round into the hash table (one list at a time: term order ==
+  //      ScorePlan leaf order), read the finished sums back, feed the top-k. ----
+  auto process = [&](const Round<NSLOT> &r, const uint32_t inmask) {
+    uint32_t own_slot[NSLOT];
 #pragma unroll
     for (int jj = 0; jj < NSLOT; jj++) {
       own_slot[jj] = 0xFFFFFFFFu;
-      if ((uint32_t)(jj * 64) < total) {  // uniform
-        const uint32_t v = jj * 64 + lane;
-        const bool in_round = v < total && e_doc[jj] <= bound;
-        const uint32_t t_first = rfl(e_t[jj]);
-        const uint32_t last_lane = (total - jj * 64) >= 64 ? 63u : (total - jj * 64 - 1);
-        const uint32_t t_last = rl(e_t[jj], last_lane);
-        for (uint32_t tc = t_first; tc <= t_last; tc++) {
-          const bool act = in_round && e_t[jj] == tc;
-          const uint64_t am = __ballot(act);
-          if (am == 0) continue;
-          if (lane == tc) consumed += (uint32_t)__popcll(am);
+      if ((uint32_t)(jj * 64) < r.total) {  // uniform
+        const bool in_round = (inmask >> jj) & 1u;
+        const uint32_t doc = r.doc[jj];
+        const uint32_t b0 = (doc * 0x9E3779B1u) >> (32 - Cfg::kLogBuckets);
+        uint32_t own_h = 0xFFFFFFFFu;
+        for (uint32_t tc = r.tfirst[jj]; tc <= r.tlast[jj]; tc++) {
+          bool pend = in_round && r.et[jj] == tc;
+          if (__ballot(pend) == 0) continue;
           const float w = __int_as_float((int)rl((uint32_t)__float_as_int(my_w), tc));
           // score_tf: base * weight (query/wand.rs:285); 0.0 + x is or_insert(0.0) += x
-          const float x = 0.0f + e_imp[jj] * w;
-          const uint32_t doc = e_doc[jj];
-          uint32_t h = (doc * 0x9E3779B1u) >> (32 - Cfg::kLogSlots);
-          bool pend = act;
-          while (__ballot(pend) != 0) {
-            if (pend) {
-              const uint2 kv = table[h];
-              if (kv.x == doc) {
-                // same doc seen in an earlier list: add in term order
-                table[h].y = __float_as_uint(__uint_as_float(kv.y) + x);
-                pend = false;
-              } else if (kv.x == kEmptyKey) {
-                const uint32_t old = atomicCAS(&table[h].x, kEmptyKey, doc);
-                if (old == kEmptyKey) {
-                  table[h].y = __float_as_uint(x);
-                  own_slot[jj] = h;
-                  pend = false;
-                } else if (old != doc) {
-                  h = (h + 1) & (Cfg::kSlots - 1);
-                }
-                // old == doc cannot happen (docs are unique within a list)
-              } else {
-                h = (h + 1) & (Cfg::kSlots - 1);
-              }
-            }
+          const float x = 0.0f + r.imp[jj] * w;
+          uint32_t b = b0;
+          do {
+            uint4 kk = make_uint4(0u, 0u, 0u, 0u);
+            if (pend) kk = keys4[b];
+            const uint32_t sub_hit = kk.x == doc ? 0u : kk.y == doc ? 1u : kk.z == doc ? 2u
+                                                                  : kk.w == doc ? 3u : 4u;
+            const uint32_t sub_emp = kk.x == kEmptyKey ? 0u : kk.y == kEmptyKey ? 1u
+                                   : kk.z == kEmptyKey ? 2u : kk.w == kEmptyKey ? 3u : 4u;
+            const bool hit = pend && sub_hit < 4u;
+            const bool can = pend && !hit && sub_emp < 4u;
+            const uint32_t slot = b * 4 + (hit ? sub_hit : sub_emp);
+            if (hit)  // doc already present from an earlier list: add in term order
+              vals[slot] = __float_as_uint(__uint_as_float(vals[slot]) + x);
+            uint32_t old = 0u;
+            if (can) old = atomicCAS(&keys[slot], kEmptyKey, doc);
+            const bool won = can && old == kEmptyKey;
+            if (won) vals[slot] = __float_as_uint(x);
+            own_h = won ? slot : own_h;
+            // bucket full of other docs: next bucket.  A lost CAS re-reads the same bucket.
+            b = (pend && !hit && !can) ? ((b + 1) & (Cfg::kBuckets - 1)) : b;
+            pend = pend && !(hit || won);
             wave_fence();
-          }
+          } while (__ballot(pend) != 0);
         }
+        own_slot[jj] = own_h;
       }
     }
     wave_fence();
-
-    // ---- owners read back the finished sums, feed the top-k, and clear their slots ----
 #pragma unroll
     for (int jj = 0; jj < NSLOT; jj++) {
-      if ((uint32_t)(jj * 64) < total) {
+      if ((uint32_t)(jj * 64) < r.total) {
         const bool own = own_slot[jj] != 0xFFFFFFFFu;
         int32_t ctk = kSentinelTk;
         if (own) {
-          const uint32_t hs = own_slot[jj];
-          ctk = total_key(__uint_as_float(table[hs].y));
-          table[hs].x = kEmptyKey;
+          ctk = total_key(__uint_as_float(vals[own_slot[jj]]));
+          keys[own_slot[jj]] = kEmptyKey;
         }
-        n_scored += (uint32_t)__popcll(__ballot(own));
-        uint64_t m = __ballot(own && top.passes(ctk, 0u, e_doc[jj]));
+        const uint64_t om = __ballot(own);
+        n_scored += (uint32_t)__popcll(om);
+        uint64_t m = __ballot(own && top.passes(ctk, 0u, r.doc[jj]));
         while (m) {
           const uint32_t l = (uint32_t)__builtin_ctzll(m);
           m &= m - 1;
           const int32_t c_tk = (int32_t)rl((uint32_t)ctk, l);
-          const uint32_t c_doc = rl(e_doc[jj], l);
+          const uint32_t c_doc = rl(r.doc[jj], l);
           if (!top.passes(c_tk, 0u, c_doc)) continue;
           if (gdel && ((gdel[c_doc >> 5] >> (c_doc & 31)) & 1u)) continue;  // accept()
           top.insert(c_tk, 0u, c_doc, k, lane);
@@ -468,7 +535,19 @@ __global__ void __launch_bounds__(256) score_slices_kernel(ScoreParams p) {
       }
     }
     wave_fence();
-    my_cur += consumed;
+  };
+
+  // ---- software pipeline: the loads of round r+1 are in flight while round r is hashed ----
+  Round<NSLOT> ra, rb;
+  bool more = plan(ra);
+  while (more) {
+    const uint32_t ma = finalize(ra);
+    more = plan(rb);
+    process(ra, ma);
+    if (!more) break;
+    const uint32_t mb = finalize(rb);
+    more = plan(ra);
+    process(rb, mb);
   }
 
   // ---- write this slice's candidates (sorted best-first; sentinel-padded) ----
