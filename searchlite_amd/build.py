@@ -18,7 +18,7 @@ LIBDIR = os.path.join(_HERE, "lib")
 GPU_LIB = os.path.join(LIBDIR, "libsearchlite_gpu.so")
 CORPUS_LIB = os.path.join(LIBDIR, "libslg_corpus.so")
 
-GPU_SOURCES = ["slg_api.hip", "slg_kernels.hpp", "slg_rerank.hpp"]
+GPU_SOURCES = ["slg_api.hip", "slg_kernels.hpp", "slg_rerank.hpp", "slg_score.hpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off",  # f32 ops rounded one by one, as the Rust reference does
                "-Wall", "-Wno-unused-function"]

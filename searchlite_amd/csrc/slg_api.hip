@@ -23,6 +23,7 @@
 
 #include "slg_kernels.hpp"
 #include "slg_rerank.hpp"
+#include "slg_score.hpp"
 
 namespace {
 
@@ -130,16 +131,18 @@ struct slg_batch {
   slg_index *idx = nullptr;
   uint32_t nq = 0, k = 0;
   int strategy = 0;
-  uint32_t n_sq = 0, n_slices = 0, n_terms = 0, n_bounds = 0;
-  uint64_t n_postings = 0;
+  uint32_t n_sq = 0, n_slices = 0, n_terms = 0, n_boundaries = 0, max_terms = 0;
+  uint64_t n_postings = 0, n_rounds = 0;
   std::vector<uint64_t> q_postings;  // per query (stats.postings_advanced)
   DevBuf d_desc;                     // packed descriptors
-  const slg::SubQuery *d_sq = nullptr;
+  const slg::RoundQuery *d_sq = nullptr;
   const slg::TermRef *d_terms = nullptr;
   const uint32_t *d_slice_sq = nullptr;
+  const uint32_t *d_bnd_sq = nullptr;
   const slg::QueryRef *d_queries = nullptr;
-  DevBuf d_bounds, d_slice_tk, d_slice_doc, d_q_scored;
+  DevBuf d_bounds, d_rdoc, d_slice_tk, d_slice_doc, d_q_scored;
   DevBuf d_out_doc, d_out_seg, d_out_score, d_out_count;
+  DevBuf d_stamps;  // SLG_STAMPS diagnostic builds
 };
 
 namespace {
@@ -163,25 +166,38 @@ int kregs_for(uint32_t k) {
   return 16;
 }
 
-constexpr int kNSlot = 8;
-
-template <int KREGS>
-void launch_score_t(const slg::ScoreParams &sp, hipStream_t st) {
-  using Cfg = slg::ScoreCfg<kNSlot>;
+template <int KREGS, int TT>
+void launch_score_tt(const slg::RoundScoreParams &sp, hipStream_t st) {
   const uint32_t blocks = (sp.n_slices + slg::kWavesPerBlock - 1) / slg::kWavesPerBlock;
-  const size_t lds = (size_t)slg::kWavesPerBlock * Cfg::kWaveLds;
-  hipLaunchKernelGGL((slg::score_slices_kernel<KREGS, kNSlot>), dim3(blocks), dim3(256), lds, st,
-                     sp);
+  const size_t lds = (size_t)slg::kWavesPerBlock * slg::kScoreWaveLds;
+  hipLaunchKernelGGL((slg::score_rounds_kernel<KREGS, TT>), dim3(blocks), dim3(256), lds, st, sp);
 }
-void launch_score(const slg::ScoreParams &sp, hipStream_t st) {
+template <int KREGS>
+void launch_score_t(const slg::RoundScoreParams &sp, uint32_t max_terms, hipStream_t st) {
+  if (max_terms <= 4)
+    launch_score_tt<KREGS, 4>(sp, st);
+  else if (max_terms <= 8)
+    launch_score_tt<KREGS, 8>(sp, st);
+  else
+    launch_score_tt<KREGS, 32>(sp, st);
+}
+void launch_score(const slg::RoundScoreParams &sp, uint32_t max_terms, hipStream_t st) {
+#ifdef SLG_DEV_BUILD  // development only: one instantiation, fast compile
+  if (kregs_for(sp.k) != 1 || max_terms > 4)
+    throw SlgError(SLG_ERR_UNSUPPORTED, "SLG_DEV_BUILD supports k <= 64 and <= 4 terms only");
+  launch_score_tt<1, 4>(sp, st);
+  SLG_HIP(hipGetLastError());
+  return;
+#else
   switch (kregs_for(sp.k)) {
-    case 1: launch_score_t<1>(sp, st); break;
-    case 2: launch_score_t<2>(sp, st); break;
-    case 4: launch_score_t<4>(sp, st); break;
-    case 8: launch_score_t<8>(sp, st); break;
-    default: launch_score_t<16>(sp, st); break;
+    case 1: launch_score_t<1>(sp, max_terms, st); break;
+    case 2: launch_score_t<2>(sp, max_terms, st); break;
+    case 4: launch_score_t<4>(sp, max_terms, st); break;
+    case 8: launch_score_t<8>(sp, max_terms, st); break;
+    default: launch_score_t<16>(sp, max_terms, st); break;
   }
   SLG_HIP(hipGetLastError());
+#endif
 }
 
 template <int KREGS>
@@ -485,7 +501,7 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
     b->q_postings.assign(nq, 0);
 
     // ---- pass 1: sub-queries and their terms (api/reader.rs:2986-3005) ----
-    std::vector<slg::SubQuery> sqs;
+    std::vector<slg::RoundQuery> sqs;
     std::vector<slg::TermRef> terms;
     std::vector<uint64_t> sq_postings;
     std::vector<uint32_t> q_sq_begin(nq + 1, 0);
@@ -499,7 +515,7 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
       if (k == 0) continue;  // wand.rs:413-416: k == 0 and no collector => no work
       for (uint32_t s = 0; s < n_segs; s++) {
         const SegHost &sh = *ix->segs[s];
-        slg::SubQuery sq{};
+        slg::RoundQuery sq{};
         sq.q = q;
         sq.seg = s;
         sq.term_begin = (uint32_t)terms.size();
@@ -525,6 +541,7 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
         sq.n_terms = (uint32_t)terms.size() - sq.term_begin;
         if (sq.n_terms == 0) continue;
         sq.longest = longest;
+        b->max_terms = std::max(b->max_terms, sq.n_terms);
         sqs.push_back(sq);
         sq_postings.push_back(P);
         b->q_postings[q] += P;
@@ -533,29 +550,35 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
     }
     q_sq_begin[nq] = (uint32_t)sqs.size();
 
-    // ---- pass 2: cut sub-queries into doc-range slices of ~G postings ----
-    const uint32_t target_slices = env_u32("SLG_TARGET_SLICES", 16384);
-    uint64_t G = env_u32("SLG_SLICE_POSTINGS", 0);
-    if (G == 0) {
-      G = b->n_postings / std::max<uint32_t>(target_slices, 1);
-      G = std::max<uint64_t>(G, env_u32("SLG_MIN_SLICE_POSTINGS", 4096));
-      G = std::min<uint64_t>(G, 1u << 20);
-    }
-    std::vector<uint32_t> slice_sq;
-    uint64_t n_bounds = 0;
+    // ---- pass 2: rounds of ~kRoundTarget postings, slices of consecutive rounds ----
+    const uint32_t round_target = std::max<uint32_t>(64, std::min<uint32_t>(
+        env_u32("SLG_ROUND_TARGET", slg::kRoundTarget), slg::kCap));
+    const uint32_t max_rps = std::max<uint32_t>(1, std::min<uint32_t>(
+        env_u32("SLG_ROUNDS_PER_SLICE", slg::kMaxRoundsPerSlice), slg::kMaxRoundsPerSlice));
+    std::vector<uint32_t> slice_sq, bnd_sq;
+    uint64_t n_bounds = 0, n_bnd = 0;
     for (size_t i = 0; i < sqs.size(); i++) {
-      slg::SubQuery &sq = sqs[i];
-      uint64_t S = (sq_postings[i] + G - 1) / G;
+      slg::RoundQuery &sq = sqs[i];
       const uint32_t dfL = terms[sq.term_begin + sq.longest].df;
-      S = std::max<uint64_t>(1, std::min<uint64_t>(S, dfL));
-      S = std::min<uint64_t>(S, 1u << 16);
+      uint64_t nr = (sq_postings[i] + round_target - 1) / round_target;
+      nr = std::max<uint64_t>(1, std::min<uint64_t>(nr, dfL));
+      const uint32_t rps = std::max<uint32_t>(1, std::min<uint32_t>(max_rps, 64 / sq.n_terms - 1));
+      const uint64_t S = (nr + rps - 1) / rps;
+      SLG_REQUIRE(nr < 0x7FFFFFFFull && slice_sq.size() + S < 0x7FFFFFFFull,
+                  "batch too large (rounds)");
+      sq.n_rounds = (uint32_t)nr;
+      sq.rounds_per_slice = rps;
       sq.slice_begin = (uint32_t)slice_sq.size();
       sq.n_slices = (uint32_t)S;
-      SLG_REQUIRE(n_bounds + S * sq.n_terms < 0xFFFFFFFFull, "batch too large (bounds)");
+      SLG_REQUIRE(n_bounds + (nr + 1) * sq.n_terms < 0xFFFFFFFFull, "batch too large (bounds)");
       sq.bounds_begin = (uint32_t)n_bounds;
-      n_bounds += S * sq.n_terms;
-      SLG_REQUIRE(slice_sq.size() + S < 0x7FFFFFFFull, "batch too large (slices)");
-      for (uint32_t j = 0; j < S; j++) slice_sq.push_back((uint32_t)i);
+      sq.rdoc_begin = (uint32_t)n_bnd;
+      sq.bnd_begin = (uint32_t)n_bnd;
+      n_bounds += (nr + 1) * sq.n_terms;
+      n_bnd += nr + 1;
+      b->n_rounds += nr;
+      slice_sq.insert(slice_sq.end(), (size_t)S, (uint32_t)i);
+      bnd_sq.insert(bnd_sq.end(), (size_t)(nr + 1), (uint32_t)i);
     }
     std::vector<slg::QueryRef> qrefs(nq);
     for (uint32_t q = 0; q < nq; q++) {
@@ -570,13 +593,14 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
     b->n_sq = (uint32_t)sqs.size();
     b->n_terms = (uint32_t)terms.size();
     b->n_slices = (uint32_t)slice_sq.size();
-    b->n_bounds = (uint32_t)n_bounds;
+    b->n_boundaries = (uint32_t)n_bnd;
 
     // ---- pack descriptors, one H2D copy ----
     size_t cur = 0;
-    const size_t o_sq = place<slg::SubQuery>(cur, sqs.size());
+    const size_t o_sq = place<slg::RoundQuery>(cur, sqs.size());
     const size_t o_terms = place<slg::TermRef>(cur, terms.size());
     const size_t o_slice = place<uint32_t>(cur, slice_sq.size());
+    const size_t o_bnd = place<uint32_t>(cur, bnd_sq.size());
     const size_t o_q = place<slg::QueryRef>(cur, qrefs.size());
     const size_t total = (cur + 15) & ~(size_t)15;
     void *hbuf = nullptr;
@@ -586,19 +610,22 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
       ~HostFree() { (void)hipHostFree(p); }
     } hf{hbuf};
     unsigned char *hb = static_cast<unsigned char *>(hbuf);
-    if (!sqs.empty()) std::memcpy(hb + o_sq, sqs.data(), sqs.size() * sizeof(slg::SubQuery));
+    if (!sqs.empty()) std::memcpy(hb + o_sq, sqs.data(), sqs.size() * sizeof(slg::RoundQuery));
     if (!terms.empty()) std::memcpy(hb + o_terms, terms.data(), terms.size() * sizeof(slg::TermRef));
     if (!slice_sq.empty()) std::memcpy(hb + o_slice, slice_sq.data(), slice_sq.size() * 4);
+    if (!bnd_sq.empty()) std::memcpy(hb + o_bnd, bnd_sq.data(), bnd_sq.size() * 4);
     if (!qrefs.empty()) std::memcpy(hb + o_q, qrefs.data(), qrefs.size() * sizeof(slg::QueryRef));
     b->d_desc.alloc(total);
     SLG_HIP(hipMemcpyAsync(b->d_desc.p, hbuf, total, hipMemcpyHostToDevice, ix->stream));
     unsigned char *db = b->d_desc.as<unsigned char>();
-    b->d_sq = reinterpret_cast<const slg::SubQuery *>(db + o_sq);
+    b->d_sq = reinterpret_cast<const slg::RoundQuery *>(db + o_sq);
     b->d_terms = reinterpret_cast<const slg::TermRef *>(db + o_terms);
     b->d_slice_sq = reinterpret_cast<const uint32_t *>(db + o_slice);
+    b->d_bnd_sq = reinterpret_cast<const uint32_t *>(db + o_bnd);
     b->d_queries = reinterpret_cast<const slg::QueryRef *>(db + o_q);
 
     b->d_bounds.alloc((size_t)n_bounds * 4);
+    b->d_rdoc.alloc((size_t)n_bnd * 4);
     b->d_slice_tk.alloc((size_t)b->n_slices * k * 4);
     b->d_slice_doc.alloc((size_t)b->n_slices * k * 4);
     b->d_q_scored.alloc((size_t)nq * 4);
@@ -627,28 +654,37 @@ int slg_batch_run(slg_batch *b) {
     if (b->nq == 0) return;
     SLG_HIP(hipMemsetAsync(b->d_q_scored.p, 0, (size_t)b->nq * 4, st));
     if (b->n_slices > 0) {
-      slg::PartParams pp{};
+      slg::RoundPartParams pp{};
       pp.sq = b->d_sq;
       pp.terms = b->d_terms;
-      pp.slice_sq = b->d_slice_sq;
+      pp.bnd_sq = b->d_bnd_sq;
       pp.segs = ix->d_segs.as<slg::SegDev>();
       pp.bounds = b->d_bounds.as<uint32_t>();
-      pp.n_slices = b->n_slices;
-      const uint32_t blocks = (b->n_slices + slg::kWavesPerBlock - 1) / slg::kWavesPerBlock;
-      hipLaunchKernelGGL(slg::partition_kernel, dim3(blocks), dim3(256), 0, st, pp);
+      pp.rdoc = b->d_rdoc.as<uint32_t>();
+      pp.n_boundaries = b->n_boundaries;
+      const uint64_t pthreads = (uint64_t)b->n_boundaries * 8;
+      hipLaunchKernelGGL(slg::partition_rounds_kernel, dim3((uint32_t)((pthreads + 255) / 256)),
+                         dim3(256), 0, st, pp);
       SLG_HIP(hipGetLastError());
 
-      slg::ScoreParams sp{};
+      slg::RoundScoreParams sp{};
       sp.sq = b->d_sq;
       sp.terms = b->d_terms;
       sp.slice_sq = b->d_slice_sq;
       sp.segs = ix->d_segs.as<slg::SegDev>();
       sp.bounds = b->d_bounds.as<uint32_t>();
+      sp.rdoc = b->d_rdoc.as<uint32_t>();
       sp.slice_tk = b->d_slice_tk.as<int32_t>();
       sp.slice_doc = b->d_slice_doc.as<uint32_t>();
       sp.q_scored = b->d_q_scored.as<uint32_t>();
       sp.n_slices = b->n_slices;
       sp.k = b->k;
+      sp.dbg = env_u32("SLG_DEBUG_FLAGS", 0);
+      sp.stamps = nullptr;
+#ifdef SLG_STAMPS
+      b->d_stamps.alloc((size_t)b->n_slices * 64);
+      sp.stamps = b->d_stamps.as<unsigned long long>();
+#endif
       std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
       if (ix->profile) {
         if (ix->prof_used == ix->prof_events.size()) {
@@ -660,7 +696,7 @@ int slg_batch_run(slg_batch *b) {
         ev = &ix->prof_events[ix->prof_used++];
         SLG_HIP(hipEventRecord(ev->first, st));
       }
-      launch_score(sp, st);
+      launch_score(sp, b->max_terms, st);
       if (ev) SLG_HIP(hipEventRecord(ev->second, st));
     }
     if (b->k > 0) {
@@ -747,6 +783,15 @@ int slg_batch_info(const slg_batch *b, uint64_t *n_postings, uint32_t *n_slices,
     if (algorithmic_bytes) *algorithmic_bytes = 12ull * b->n_postings + 8ull * b->k * b->nq;
   });
 }
+
+#ifdef SLG_STAMPS
+int slg_debug_read_stamps(slg_batch *b, unsigned long long *out, uint32_t n_slices) {
+  return guarded([&] {
+    SLG_HIP(hipStreamSynchronize(b->idx->stream));
+    SLG_HIP(hipMemcpy(out, b->d_stamps.p, (size_t)n_slices * 64, hipMemcpyDeviceToHost));
+  });
+}
+#endif
 
 void slg_batch_destroy(slg_batch *b) {
   if (!b) return;

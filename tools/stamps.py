@@ -1,0 +1,30 @@
+"""Diagnostic: run one C2 batch with the SLG_STAMPS build and print per-phase cycle shares.
+usage (GPU box): python tools/stamps.py [rounds_per_slice]"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from searchlite_amd import build, corpus
+build.GPU_LIB = os.path.join(build.LIBDIR, "libsearchlite_gpu_stamps.so")
+from searchlite_amd import searcher, _native as N
+if len(sys.argv) > 1:
+    os.environ["SLG_ROUNDS_PER_SLICE"] = sys.argv[1]
+seg = corpus.zipf_segment(1_000_000, 1 << 18, seed=42)
+offs, terms, w = corpus.zipf_queries(1024, 3, seed=7, vocab=1 << 18)
+ix = searcher.GpuIndex([seg])
+b = ix.prepare(offs, terms, w, 11)
+for _ in range(3):
+    b.run()
+b.sync()
+info = b.info()
+n = info["n_slices"]
+out = np.zeros((n, 8), dtype=np.uint64)
+L = N.load()
+L.slg_debug_read_stamps.restype = C.c_int
+L.slg_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+assert L.slg_debug_read_stamps(b._h, out.ctypes.data, n) == 0
+names = ["0 plan/issue next", "1 window setup", "2 P0+P1 clear+or", "3 P2 scan", "4 P3 rmw",
+         "5 P4 read+topk", "6 wait loads+copy", "7 tail"]
+tot = out.sum()
+print("slices", n, "postings", info["n_postings"], "mean cycles/slice", tot / n)
+for i, nm in enumerate(names):
+    print(f"{nm:22s} {out[:, i].sum() / tot * 100:6.2f}%   mean/slice {out[:, i].mean():10.0f}")
