@@ -103,7 +103,7 @@ struct SegHost {
   uint32_t n_docs = 0, n_terms = 0;
   uint64_t n_postings = 0;
   std::vector<uint64_t> term_offsets;
-  DevBuf d_docs, d_imps, d_deleted;
+  DevBuf d_docs, d_imps, d_deleted, d_champ;
   // vectors
   uint32_t vec_dim = 0, vec_rows = 0;
   int32_t vec_metric = 0;
@@ -138,6 +138,7 @@ struct slg_batch {
   const slg::RoundQuery *d_sq = nullptr;
   const slg::TermRef *d_terms = nullptr;
   const uint32_t *d_slice_sq = nullptr;
+  const uint32_t *d_slice_seg = nullptr;
   const uint32_t *d_bnd_sq = nullptr;
   const slg::QueryRef *d_queries = nullptr;
   DevBuf d_bounds, d_rdoc, d_slice_tk, d_slice_doc, d_q_scored;
@@ -339,6 +340,18 @@ void stage_segment(slg_index *ix, SegHost &sh, const slg_segment_desc &d) {
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(want, 256ull * 32);
     hipLaunchKernelGGL(slg::stage_impacts_kernel, dim3(blocks), dim3(256), 0, st, sp);
     SLG_HIP(hipGetLastError());
+    if (env_u32("SLG_NO_CHAMPIONS", 0) == 0) {
+      sh.d_champ.alloc((size_t)d.n_terms * slg::kChampions * 4);
+      ix->device_bytes += sh.d_champ.bytes;
+      slg::ChampParams cp{};
+      cp.term_offsets = d_offs.as<uint64_t>();
+      cp.imps = sh.d_imps.as<float>();
+      cp.champ = sh.d_champ.as<float>();
+      cp.n_terms = d.n_terms;
+      const uint32_t cblocks = std::min<uint32_t>((d.n_terms + 3) / 4, 256u * 16);
+      hipLaunchKernelGGL(slg::stage_champions_kernel, dim3(cblocks ? cblocks : 1), dim3(256), 0, st, cp);
+      SLG_HIP(hipGetLastError());
+    }
     SLG_HIP(hipStreamSynchronize(st));  // temporaries die here
   }
   if (d.vec_dim) {
@@ -411,6 +424,7 @@ slg_index *slg_index_create(const slg_segment_desc *segs, uint32_t n_segs, int d
       sd[s].docs = ix->segs[s]->d_docs.as<uint32_t>();
       sd[s].imps = ix->segs[s]->d_imps.as<float>();
       sd[s].deleted = ix->segs[s]->d_deleted.as<uint32_t>();
+      sd[s].champ = ix->segs[s]->d_champ.as<float>();
       sd[s].n_docs = ix->segs[s]->n_docs;
       sd[s].pad = 0;
       vd[s].offsets = ix->segs[s]->d_vec_offsets.as<uint32_t>();
@@ -535,7 +549,7 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
             longest_df = df;
             longest = local;
           }
-          terms.push_back(slg::TermRef{off, df, w});
+          terms.push_back(slg::TermRef{off, df, w, tid, 0u});
           P += df;
         }
         sq.n_terms = (uint32_t)terms.size() - sq.term_begin;
@@ -554,8 +568,8 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
     const uint32_t round_target = std::max<uint32_t>(64, std::min<uint32_t>(
         env_u32("SLG_ROUND_TARGET", slg::kRoundTarget), slg::kCap));
     const uint32_t max_rps = std::max<uint32_t>(1, std::min<uint32_t>(
-        env_u32("SLG_ROUNDS_PER_SLICE", slg::kMaxRoundsPerSlice), slg::kMaxRoundsPerSlice));
-    std::vector<uint32_t> slice_sq, bnd_sq;
+        env_u32("SLG_ROUNDS_PER_SLICE", slg::kDefaultRoundsPerSlice), slg::kMaxRoundsPerSlice));
+    std::vector<uint32_t> slice_sq, slice_seg, bnd_sq;
     uint64_t n_bounds = 0, n_bnd = 0;
     for (size_t i = 0; i < sqs.size(); i++) {
       slg::RoundQuery &sq = sqs[i];
@@ -578,6 +592,7 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
       n_bnd += nr + 1;
       b->n_rounds += nr;
       slice_sq.insert(slice_sq.end(), (size_t)S, (uint32_t)i);
+      slice_seg.insert(slice_seg.end(), (size_t)S, sq.seg);
       bnd_sq.insert(bnd_sq.end(), (size_t)(nr + 1), (uint32_t)i);
     }
     std::vector<slg::QueryRef> qrefs(nq);
@@ -601,6 +616,7 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
     const size_t o_terms = place<slg::TermRef>(cur, terms.size());
     const size_t o_slice = place<uint32_t>(cur, slice_sq.size());
     const size_t o_bnd = place<uint32_t>(cur, bnd_sq.size());
+    const size_t o_sseg = place<uint32_t>(cur, slice_seg.size());
     const size_t o_q = place<slg::QueryRef>(cur, qrefs.size());
     const size_t total = (cur + 15) & ~(size_t)15;
     void *hbuf = nullptr;
@@ -614,6 +630,7 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
     if (!terms.empty()) std::memcpy(hb + o_terms, terms.data(), terms.size() * sizeof(slg::TermRef));
     if (!slice_sq.empty()) std::memcpy(hb + o_slice, slice_sq.data(), slice_sq.size() * 4);
     if (!bnd_sq.empty()) std::memcpy(hb + o_bnd, bnd_sq.data(), bnd_sq.size() * 4);
+    if (!slice_seg.empty()) std::memcpy(hb + o_sseg, slice_seg.data(), slice_seg.size() * 4);
     if (!qrefs.empty()) std::memcpy(hb + o_q, qrefs.data(), qrefs.size() * sizeof(slg::QueryRef));
     b->d_desc.alloc(total);
     SLG_HIP(hipMemcpyAsync(b->d_desc.p, hbuf, total, hipMemcpyHostToDevice, ix->stream));
@@ -622,6 +639,7 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
     b->d_terms = reinterpret_cast<const slg::TermRef *>(db + o_terms);
     b->d_slice_sq = reinterpret_cast<const uint32_t *>(db + o_slice);
     b->d_bnd_sq = reinterpret_cast<const uint32_t *>(db + o_bnd);
+    b->d_slice_seg = reinterpret_cast<const uint32_t *>(db + o_sseg);
     b->d_queries = reinterpret_cast<const slg::QueryRef *>(db + o_q);
 
     b->d_bounds.alloc((size_t)n_bounds * 4);
@@ -652,7 +670,7 @@ int slg_batch_run(slg_batch *b) {
     DeviceGuard g(ix->device);
     hipStream_t st = ix->stream;
     if (b->nq == 0) return;
-    SLG_HIP(hipMemsetAsync(b->d_q_scored.p, 0, (size_t)b->nq * 4, st));
+    if (b->n_slices == 0) SLG_HIP(hipMemsetAsync(b->d_q_scored.p, 0, (size_t)b->nq * 4, st));
     if (b->n_slices > 0) {
       slg::RoundPartParams pp{};
       pp.sq = b->d_sq;
@@ -661,8 +679,10 @@ int slg_batch_run(slg_batch *b) {
       pp.segs = ix->d_segs.as<slg::SegDev>();
       pp.bounds = b->d_bounds.as<uint32_t>();
       pp.rdoc = b->d_rdoc.as<uint32_t>();
+      pp.q_scored = b->d_q_scored.as<uint32_t>();
+      pp.nq = b->nq;
       pp.n_boundaries = b->n_boundaries;
-      const uint64_t pthreads = (uint64_t)b->n_boundaries * 8;
+      const uint64_t pthreads = std::max<uint64_t>((uint64_t)b->n_boundaries * 8, b->nq);
       hipLaunchKernelGGL(slg::partition_rounds_kernel, dim3((uint32_t)((pthreads + 255) / 256)),
                          dim3(256), 0, st, pp);
       SLG_HIP(hipGetLastError());
@@ -702,8 +722,7 @@ int slg_batch_run(slg_batch *b) {
     if (b->k > 0) {
       slg::MergeParams mp{};
       mp.queries = b->d_queries;
-      mp.sq = b->d_sq;
-      mp.slice_sq = b->d_slice_sq;
+      mp.slice_seg = b->d_slice_seg;
       mp.slice_tk = b->d_slice_tk.as<int32_t>();
       mp.slice_doc = b->d_slice_doc.as<uint32_t>();
       mp.out_doc = b->d_out_doc.as<uint32_t>();

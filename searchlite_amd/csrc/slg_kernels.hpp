@@ -21,12 +21,14 @@ constexpr int32_t kSentinelTk = INT32_MIN;
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 constexpr uint32_t kMaxTerms = 32;
+constexpr int kChampions = 64;  // per-term impact lower bounds kept at staging time
 
 // ---- device-side descriptors (built on the host per batch) ---------------------------
 struct SegDev {
   const uint32_t *docs;     // [P] doc ids
   const float *imps;        // [P] precomputed bm25 (weight == 1) per posting
   const uint32_t *deleted;  // bitmap words or nullptr
+  const float *champ;       // [V * kChampions] per-term descending impact lower bounds
   uint32_t n_docs;
   uint32_t pad;
 };
@@ -35,6 +37,8 @@ struct TermRef {  // one scored term of one sub-query
   uint64_t off;   // posting offset inside the segment arrays
   uint32_t df;    // list length
   float weight;
+  uint32_t term;  // term id inside the segment (champion table row)
+  uint32_t pad;
 };
 
 struct RoundQuery {  // sub-query = (query, segment) pair with >= 1 non-empty term
@@ -116,9 +120,10 @@ struct WaveTopK {
   int32_t tk[KREGS];
   uint32_t doc[KREGS];
   uint32_t seg[HAS_SEG ? KREGS : 1];
-  int32_t th_tk;  // threshold = entry at position k-1 (uniform)
+  int32_t th_tk;  // threshold = entry at position k-1 (uniform), never below the floor
   uint32_t th_seg, th_doc;
   uint32_t count;  // real entries held, capped at k (uniform)
+  int32_t floor_tk;  // exact lower bound of the final k-th score known up front (or sentinel)
 
   __device__ __forceinline__ void init() {
 #pragma unroll
@@ -132,6 +137,15 @@ struct WaveTopK {
     th_seg = 0xFFFFFFFFu;
     th_doc = 0xFFFFFFFFu;
     count = 0;
+    floor_tk = kSentinelTk;
+  }
+  // At least k docs are known to score >= f: nothing below f can reach the final top-k.
+  // Candidates equal to f still pass (ties are broken by doc id later).
+  __device__ __forceinline__ void set_floor(float f) {
+    floor_tk = total_key(f);
+    th_tk = floor_tk;
+    th_seg = 0xFFFFFFFFu;
+    th_doc = 0xFFFFFFFFu;
   }
   __device__ __forceinline__ bool passes(int32_t ctk, uint32_t cseg, uint32_t cdoc) const {
     return better<HAS_SEG>(ctk, cseg, cdoc, th_tk, th_seg, th_doc);
@@ -176,6 +190,11 @@ struct WaveTopK {
     th_tk = (int32_t)rl((uint32_t)v_tk, tl);
     th_doc = rl(v_doc, tl);
     th_seg = HAS_SEG ? rl(v_seg, tl) : 0u;
+    if (th_tk < floor_tk) {  // fewer than k entries so far: the up-front bound still rules
+      th_tk = floor_tk;
+      th_doc = 0xFFFFFFFFu;
+      th_seg = 0xFFFFFFFFu;
+    }
   }
 };
 
@@ -235,11 +254,45 @@ __global__ void __launch_bounds__(256) stage_impacts_kernel(StageParams p) {
   }
 }
 
+// ---- staging: per-term champion impacts ------------------------------------------------------
+// champ[t][r] (r = 0..63, descending) is a value v such that at least r+1 postings of term t
+// have impact >= v (0 where the list is shorter).  Lane l keeps the maximum of postings
+// l, l+64, ...; the 64 lane maxima are sorted descending.  Not the exact order statistics of
+// the list, but a valid lower bound for every rank, which is all the threshold seed needs:
+// a doc's total score is >= any one of its (non-negative) per-term contributions.
+struct ChampParams {
+  const uint64_t *term_offsets;  // [V+1]
+  const float *imps;             // [P]
+  float *champ;                  // [V * kChampions]
+  uint32_t n_terms;
+};
+
+__global__ void __launch_bounds__(256) stage_champions_kernel(ChampParams p) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const uint32_t n_waves = gridDim.x * kWavesPerBlock;
+  for (uint32_t t = wave; t < p.n_terms; t += n_waves) {
+    const uint64_t a = p.term_offsets[t], b = p.term_offsets[t + 1];
+    float m = 0.0f;
+    for (uint64_t i = a + lane; i < b; i += 64) m = fmaxf(m, p.imps[i]);
+    // bitonic sort of the 64 lane maxima, descending (lane 0 = largest)
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+      for (int d = size >> 1; d > 0; d >>= 1) {
+        const float o = __shfl_xor(m, d, 64);
+        const bool up = ((lane & size) == 0) == ((lane & d) == 0);  // keep the larger one
+        m = up ? fmaxf(m, o) : fminf(m, o);
+      }
+    }
+    p.champ[(size_t)t * kChampions + lane] = m;
+  }
+}
+
 // ---- merge: per query, all slice candidate lists -> final top-k ---------------------------
 struct MergeParams {
   const QueryRef *queries;
-  const RoundQuery *sq;
-  const uint32_t *slice_sq;
+  const uint32_t *slice_seg;  // [n_slices] segment ordinal of each slice
   const int32_t *slice_tk;
   const uint32_t *slice_doc;
   uint32_t *out_doc;
@@ -250,6 +303,9 @@ struct MergeParams {
   uint32_t k;
 };
 
+// One wave per query.  The query's slices occupy a contiguous range of the candidate arrays
+// ([slice_begin*k, slice_end*k)); it is streamed 64 entries at a time (independent coalesced
+// loads), filtered against the running threshold and inserted into the register top-k.
 template <int KREGS>
 __global__ void __launch_bounds__(256) merge_topk_kernel(MergeParams p) {
   const uint32_t lane = threadIdx.x & 63;
@@ -259,29 +315,23 @@ __global__ void __launch_bounds__(256) merge_topk_kernel(MergeParams p) {
   const QueryRef qr = p.queries[q];
   WaveTopK<KREGS, true> top;
   top.init();
-  for (uint32_t sl = qr.slice_begin; sl < qr.slice_end; sl++) {
-    const uint32_t seg = rfl(p.sq[p.slice_sq[sl]].seg);
-    const int32_t *itk = p.slice_tk + (size_t)sl * k;
-    const uint32_t *idoc = p.slice_doc + (size_t)sl * k;
-    for (uint32_t base = 0; base < k; base += 64) {
-      const uint32_t i = base + lane;
-      int32_t ctk = kSentinelTk;
-      uint32_t cdoc = 0xFFFFFFFFu;
-      if (i < k) {
-        ctk = itk[i];
-        cdoc = idoc[i];
-      }
-      const bool valid = !(ctk == kSentinelTk && cdoc == 0xFFFFFFFFu);
-      uint64_t m = __ballot(valid && top.passes(ctk, seg, cdoc));
-      if (m == 0) break;  // lists are sorted: nothing further in this slice can pass
-      while (m) {
-        const uint32_t l = (uint32_t)__builtin_ctzll(m);
-        m &= m - 1;
-        const int32_t c_tk = (int32_t)rl((uint32_t)ctk, l);
-        const uint32_t c_doc = rl(cdoc, l);
-        if (!top.passes(c_tk, seg, c_doc)) continue;
-        top.insert(c_tk, seg, c_doc, k, lane);
-      }
+  const uint64_t f0 = (uint64_t)qr.slice_begin * k, f1 = (uint64_t)qr.slice_end * k;
+  for (uint64_t base = f0; base < f1; base += 64) {
+    const uint64_t f = base + lane;
+    int32_t ctk = kSentinelTk;
+    uint32_t cdoc = 0xFFFFFFFFu, cseg = 0xFFFFFFFFu;
+    if (f < f1) {
+      ctk = p.slice_tk[f];
+      cdoc = p.slice_doc[f];
+      cseg = p.slice_seg[(uint32_t)(f / k)];
+    }
+    const bool valid = !(ctk == kSentinelTk && cdoc == 0xFFFFFFFFu);
+    uint64_t m = __ballot(valid && top.passes(ctk, cseg, cdoc));
+    while (m) {
+      const uint32_t l = (uint32_t)__builtin_ctzll(m);
+      top.insert((int32_t)rl((uint32_t)ctk, l), rl(cseg, l), rl(cdoc, l), k, lane);
+      m &= m - 1;
+      m &= __ballot(top.passes(ctk, cseg, cdoc));
     }
   }
 #pragma unroll

@@ -32,6 +32,7 @@ constexpr int kNSlot = 8;                 // 64-posting register slots per round
 constexpr int kCap = kNSlot * 64;         // postings per round
 constexpr int kRoundTarget = 416;         // planned postings per round (host + partition)
 constexpr int kMaxRoundsPerSlice = 16;  // and (rounds+1)*T <= 64: cut points live in one VGPR
+constexpr int kDefaultRoundsPerSlice = 8;
 constexpr int kSpanWords = 512;           // bitmap words per window
 constexpr uint32_t kSpan = kSpanWords * 32;  // docs per window
 // per-wave LDS: bitmap words, exclusive prefix popcounts, accumulators
@@ -45,12 +46,15 @@ struct RoundPartParams {
   const SegDev *segs;
   uint32_t *bounds;
   uint32_t *rdoc;
+  uint32_t *q_scored;  // [nq] zeroed here (saves a memset node per batch)
+  uint32_t nq;
   uint32_t n_boundaries;
 };
 
 // 8 threads per boundary: thread u handles lists u, u+8, ...
 __global__ void __launch_bounds__(256) partition_rounds_kernel(RoundPartParams p) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < p.nq) p.q_scored[gid] = 0;
   const uint32_t b = gid >> 3, u = gid & 7;
   if (b >= p.n_boundaries) return;
   const uint32_t sqi = p.bnd_sq[b];
@@ -207,10 +211,12 @@ __global__ void __launch_bounds__(256) score_rounds_kernel(RoundScoreParams p) {
   // lane t < T: list t's posting offset; weights go to scalars
   uint64_t my_off = 0;
   float my_w = 0.0f;
+  uint32_t my_term = 0;
   if (lane < T) {
     const TermRef tr = p.terms[s.term_begin + lane];
     my_off = tr.off;
     my_w = tr.weight;
+    my_term = tr.term;
   }
   // all cut points of the slice in ONE register: lane i holds bounds[r0*T + i] for
   // i < (rounds+1)*T (the host picks rounds_per_slice so that this fits 64 lanes); likewise
@@ -220,6 +226,17 @@ __global__ void __launch_bounds__(256) score_rounds_kernel(RoundScoreParams p) {
 
   WaveTopK<KREGS, false> top;
   top.init();
+  if (sd.champ != nullptr && k <= (uint32_t)kChampions) {
+    // threshold seed: >= k postings of term t have impact >= champ[t][k-1], and a doc's total
+    // is >= any single (non-negative) contribution, so >= k docs score >= w_t * champ[t][k-1]
+    float f = 0.0f;
+    if (lane < T && my_w > 0.0f) f = my_w * ((const gf32_t)sd.champ)[(size_t)my_term * kChampions + (k - 1)];
+    float best = 0.0f;
+    for (uint32_t t = 0; t < T; t++) best = fmaxf(best, __int_as_float((int)rl((uint32_t)__float_as_int(f), t)));
+    // a negative weight would break "total >= single contribution": no seed then
+    const bool anyneg = __ballot(lane < T && !(my_w >= 0.0f)) != 0ull;
+    if (best > 0.0f && !anyneg) top.set_floor(best);
+  }
   uint32_t n_scored = 0;
 #ifdef SLG_STAMPS
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
@@ -282,40 +299,47 @@ __global__ void __launch_bounds__(256) score_rounds_kernel(RoundScoreParams p) {
     bm4[lane] = make_uint4(0u, 0u, 0u, 0u);
     bm4[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
     wave_fence();
-    // P1: one bit per posting; the returned old word tells who came first
-    uint32_t wi[kNSlot], bit[kNSlot], ownmask = 0, tfl[kNSlot];
+    // P1: one bit per posting; the returned old word tells who came first.  Slots are
+    // laid out list by list, so across slots "first" is term order.  Inside one slot that
+    // straddles two lists the hardware may pick either of two same-doc lanes as first; the
+    // sum of two terms commutes, so that is still bit-exact.  Only a slot holding three or
+    // more lists (tiny lists) needs the ordered path.
+    uint32_t wi[kNSlot], bit[kNSlot], ownmask = 0;
     {
       uint32_t oldw[kNSlot];
+      bool tiny = false;
 #pragma unroll
       for (int jj = 0; jj < kNSlot; jj++) {
         const uint32_t rel = e.doc[jj] - wbase;
         const bool valid = (validmask >> jj) & 1u;
-        const uint32_t tj = e.t(jj);
-        // transposed bitmap: doc d -> word d mod 512, bit d / 512.  Neighbouring docs of a dense
-        // list land in neighbouring words (distinct banks, no same-address atomic
-        // serialization: ~4 cycles per colliding lane on gfx950); the prefix popcount over
-        // (word, bit) order is still a perfect hash doc -> accumulator slot.
+        // transposed bitmap: doc d -> word d mod 512, bit d / 512 (neighbouring docs of a
+        // dense list hit neighbouring words); the prefix popcount over (word, bit) order is
+        // still a perfect hash doc -> accumulator slot.
         wi[jj] = rel & (kSpanWords - 1);  // in range even for idle lanes
         bit[jj] = valid ? 1u << ((rel >> 9) & 31) : 0u;
-        tfl[jj] = rfl(tj);  // list of the slot's first lane
-        const uint64_t rest = __ballot(valid && tj != tfl[jj]);
-        if (rest == 0) {
-          oldw[jj] = atomicOr(&bm[wi[jj]], bit[jj]);
-        } else {  // slot straddles lists (at most T-1 per round): claim in term order
-          oldw[jj] = 0xFFFFFFFFu;
-          uint64_t left = __ballot(valid);
-          for (uint32_t tc = tfl[jj]; left; tc++) {
-            const bool mine = valid && tj == tc;
-            const uint32_t o = atomicOr(&bm[wi[jj]], mine ? bit[jj] : 0u);
-            oldw[jj] = mine ? o : oldw[jj];
-            left &= ~__ballot(mine);
-            wave_fence();
-          }
-        }
+        oldw[jj] = atomicOr(&bm[wi[jj]], bit[jj]);
+        const uint32_t tj = e.t(jj);
+        tiny = tiny || (bit[jj] != 0u && tj > rfl(tj) + 1u);
       }
 #pragma unroll
       for (int jj = 0; jj < kNSlot; jj++)
         ownmask |= (bit[jj] != 0u && (oldw[jj] & bit[jj]) == 0u) ? (1u << jj) : 0u;
+      if (__ballot(tiny) != 0ull) {  // rare: redo the claims strictly in term order
+        wave_fence();
+        bm4[lane] = make_uint4(0u, 0u, 0u, 0u);
+        bm4[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
+        wave_fence();
+        ownmask = 0;
+        for (uint32_t tc = 0; tc < T; tc++) {
+#pragma unroll
+          for (int jj = 0; jj < kNSlot; jj++) {
+            const bool mine = bit[jj] != 0u && e.t(jj) == tc;
+            const uint32_t o = atomicOr(&bm[wi[jj]], mine ? bit[jj] : 0u);
+            ownmask |= (mine && (o & bit[jj]) == 0u) ? (1u << jj) : 0u;
+          }
+          wave_fence();
+        }
+      }
     }
     wave_fence();
     SLG_STAMP(2);
@@ -358,7 +382,11 @@ __global__ void __launch_bounds__(256) score_rounds_kernel(RoundScoreParams p) {
     wave_fence();
     // P3b: later postings of a doc add to the owner's value, one list at a time in term order
     if (__ballot(lmask != 0u) != 0ull) {
-      for (uint32_t tc = 1; tc < T; tc++) {
+      for (uint32_t tc = 0; tc < T; tc++) {
+        uint32_t am = 0;
+#pragma unroll
+        for (int jj = 0; jj < kNSlot; jj++) am |= (((lmask >> jj) & 1u) && e.t(jj) == tc) ? 1u : 0u;
+        if (__ballot(am != 0u) == 0ull) continue;
         uint32_t old[kNSlot];
 #pragma unroll
         for (int jj = 0; jj < kNSlot; jj++) old[jj] = vals[slot[jj]];
@@ -389,15 +417,17 @@ __global__ void __launch_bounds__(256) score_rounds_kernel(RoundScoreParams p) {
     if (__ballot(passmask != 0u) != 0ull) {
 #pragma unroll
       for (int jj = 0; jj < kNSlot; jj++) {
-        uint64_t m = __ballot((passmask >> jj) & 1u);
+        // re-evaluate against the current threshold after every insertion: a cold slot
+        // costs ~k(1 + ln(64/k)) insertions instead of 64 iterations
+        uint64_t m = __ballot(((passmask >> jj) & 1u) && top.passes(ctk[jj], 0u, e.doc[jj]));
         while (m) {
           const uint32_t l = (uint32_t)__builtin_ctzll(m);
-          m &= m - 1;
           const int32_t c_tk = (int32_t)rl((uint32_t)ctk[jj], l);
           const uint32_t c_doc = rl(e.doc[jj], l);
-          if (!top.passes(c_tk, 0u, c_doc)) continue;
-          if (gdel && ((gdel[c_doc >> 5] >> (c_doc & 31)) & 1u)) continue;  // accept()
-          top.insert(c_tk, 0u, c_doc, k, lane);
+          if (!(gdel && ((gdel[c_doc >> 5] >> (c_doc & 31)) & 1u)))  // accept()
+            top.insert(c_tk, 0u, c_doc, k, lane);
+          m &= m - 1;
+          m &= __ballot(top.passes(ctk[jj], 0u, e.doc[jj]));
         }
       }
     }
