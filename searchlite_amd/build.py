@@ -18,7 +18,7 @@ LIBDIR = os.path.join(_HERE, "lib")
 GPU_LIB = os.path.join(LIBDIR, "libsearchlite_gpu.so")
 CORPUS_LIB = os.path.join(LIBDIR, "libslg_corpus.so")
 
-GPU_SOURCES = ["slg_api.hip", "slg_kernels.hpp", "slg_rerank.hpp", "slg_score.hpp"]
+GPU_SOURCES = ["slg_api.hip", "slg_score_inst.hip", "slg_kernels.hpp", "slg_rerank.hpp", "slg_score.hpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off",  # f32 ops rounded one by one, as the Rust reference does
                "-Wall", "-Wno-unused-function"]
@@ -38,14 +38,40 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: cannot build libsearchlite_gpu.so")
 
 
+SCORE_KREGS = (1, 2, 4, 8, 16)
+
+
 def build_gpu(force: bool = False, verbose: bool = False) -> str:
+    """hipcc every translation unit for gfx950 (score-kernel variants in parallel), then link."""
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIBDIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in GPU_SOURCES]
-    srcs.append(os.path.join(_HERE, "..", "include", "searchlite_gpu.h"))
-    if force or _newer(GPU_LIB, srcs):
-        cmd = [_hipcc(), *HIPCC_FLAGS, "-o", GPU_LIB, os.path.join(CSRC, "slg_api.hip")]
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in ("slg_kernels.hpp", "slg_rerank.hpp", "slg_score.hpp")]
+    hdrs.append(os.path.join(_HERE, "..", "include", "searchlite_gpu.h"))
+    compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    jobs = [(os.path.join(CSRC, "slg_api.hip"), os.path.join(objdir, "slg_api.o"), [])]
+    for kr in SCORE_KREGS:
+        jobs.append((os.path.join(CSRC, "slg_score_inst.hip"),
+                     os.path.join(objdir, f"slg_score_k{kr}.o"), [f"-DSLG_INST_KREGS={kr}"]))
+
+    def compile_one(job):
+        src, obj, extra = job
+        if force or _newer(obj, [src] + hdrs):
+            cmd = [_hipcc(), *compile_flags, *extra, "-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            return True
+        return False
+
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+        rebuilt = list(ex.map(compile_one, jobs))
+    objs = [j[1] for j in jobs]
+    if force or any(rebuilt) or _newer(GPU_LIB, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", GPU_LIB, *objs]
         if verbose:
-            print(" ".join(cmd))
+            print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     return GPU_LIB
 

@@ -167,38 +167,28 @@ int kregs_for(uint32_t k) {
   return 16;
 }
 
-template <int KREGS, int TT>
-void launch_score_tt(const slg::RoundScoreParams &sp, hipStream_t st) {
-  const uint32_t blocks = (sp.n_slices + slg::kWavesPerBlock - 1) / slg::kWavesPerBlock;
-  const size_t lds = (size_t)slg::kWavesPerBlock * slg::kScoreWaveLds;
-  hipLaunchKernelGGL((slg::score_rounds_kernel<KREGS, TT>), dim3(blocks), dim3(256), lds, st, sp);
-}
+}  // namespace
+namespace slg {
+// defined in slg_score_inst.hip, one translation unit per KREGS
 template <int KREGS>
-void launch_score_t(const slg::RoundScoreParams &sp, uint32_t max_terms, hipStream_t st) {
-  if (max_terms <= 4)
-    launch_score_tt<KREGS, 4>(sp, st);
-  else if (max_terms <= 8)
-    launch_score_tt<KREGS, 8>(sp, st);
-  else
-    launch_score_tt<KREGS, 32>(sp, st);
-}
+void launch_score_kregs(const RoundScoreParams &sp, uint32_t max_terms, hipStream_t st);
+template <> void launch_score_kregs<1>(const RoundScoreParams &, uint32_t, hipStream_t);
+template <> void launch_score_kregs<2>(const RoundScoreParams &, uint32_t, hipStream_t);
+template <> void launch_score_kregs<4>(const RoundScoreParams &, uint32_t, hipStream_t);
+template <> void launch_score_kregs<8>(const RoundScoreParams &, uint32_t, hipStream_t);
+template <> void launch_score_kregs<16>(const RoundScoreParams &, uint32_t, hipStream_t);
+}  // namespace slg
+namespace {
+
 void launch_score(const slg::RoundScoreParams &sp, uint32_t max_terms, hipStream_t st) {
-#ifdef SLG_DEV_BUILD  // development only: one instantiation, fast compile
-  if (kregs_for(sp.k) != 1 || max_terms > 4)
-    throw SlgError(SLG_ERR_UNSUPPORTED, "SLG_DEV_BUILD supports k <= 64 and <= 4 terms only");
-  launch_score_tt<1, 4>(sp, st);
-  SLG_HIP(hipGetLastError());
-  return;
-#else
   switch (kregs_for(sp.k)) {
-    case 1: launch_score_t<1>(sp, max_terms, st); break;
-    case 2: launch_score_t<2>(sp, max_terms, st); break;
-    case 4: launch_score_t<4>(sp, max_terms, st); break;
-    case 8: launch_score_t<8>(sp, max_terms, st); break;
-    default: launch_score_t<16>(sp, max_terms, st); break;
+    case 1: slg::launch_score_kregs<1>(sp, max_terms, st); break;
+    case 2: slg::launch_score_kregs<2>(sp, max_terms, st); break;
+    case 4: slg::launch_score_kregs<4>(sp, max_terms, st); break;
+    case 8: slg::launch_score_kregs<8>(sp, max_terms, st); break;
+    default: slg::launch_score_kregs<16>(sp, max_terms, st); break;
   }
   SLG_HIP(hipGetLastError());
-#endif
 }
 
 template <int KREGS>

@@ -217,7 +217,7 @@ struct StageParams {
   float *imps;  // out [P]
 };
 
-__global__ void __launch_bounds__(256) stage_impacts_kernel(StageParams p) {
+static __global__ void __launch_bounds__(256) stage_impacts_kernel(StageParams p) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (; i < p.n_postings; i += stride) {
@@ -267,7 +267,7 @@ struct ChampParams {
   uint32_t n_terms;
 };
 
-__global__ void __launch_bounds__(256) stage_champions_kernel(ChampParams p) {
+static __global__ void __launch_bounds__(256) stage_champions_kernel(ChampParams p) {
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const uint32_t n_waves = gridDim.x * kWavesPerBlock;

@@ -52,7 +52,7 @@ struct RoundPartParams {
 };
 
 // 8 threads per boundary: thread u handles lists u, u+8, ...
-__global__ void __launch_bounds__(256) partition_rounds_kernel(RoundPartParams p) {
+static __global__ void __launch_bounds__(256) partition_rounds_kernel(RoundPartParams p) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid < p.nq) p.q_scored[gid] = 0;
   const uint32_t b = gid >> 3, u = gid & 7;

@@ -1,0 +1,35 @@
+// slg_score_inst.hip — one translation unit per top-k register width (SLG_INST_KREGS), so
+// the score_rounds_kernel instantiations compile in parallel.  slg_api.hip calls
+// slg::launch_score_kregs<N>() declared below.
+#include <hip/hip_runtime.h>
+
+#include "slg_score.hpp"
+
+#ifndef SLG_INST_KREGS
+#error "compile with -DSLG_INST_KREGS={1,2,4,8,16}"
+#endif
+
+namespace slg {
+
+template <int KREGS, int TT>
+static void launch_tt(const RoundScoreParams &sp, hipStream_t st) {
+  const uint32_t blocks = (sp.n_slices + kWavesPerBlock - 1) / kWavesPerBlock;
+  const size_t lds = (size_t)kWavesPerBlock * kScoreWaveLds;
+  hipLaunchKernelGGL((score_rounds_kernel<KREGS, TT>), dim3(blocks), dim3(256), lds, st, sp);
+}
+
+template <int KREGS>
+void launch_score_kregs(const RoundScoreParams &sp, uint32_t max_terms, hipStream_t st);
+
+template <>
+void launch_score_kregs<SLG_INST_KREGS>(const RoundScoreParams &sp, uint32_t max_terms,
+                                        hipStream_t st) {
+  if (max_terms <= 4)
+    launch_tt<SLG_INST_KREGS, 4>(sp, st);
+  else if (max_terms <= 8)
+    launch_tt<SLG_INST_KREGS, 8>(sp, st);
+  else
+    launch_tt<SLG_INST_KREGS, 32>(sp, st);
+}
+
+}  // namespace slg

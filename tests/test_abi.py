@@ -1,0 +1,86 @@
+"""The C-ABI library loads without a GPU and exports exactly what include/searchlite_gpu.h
+declares; host-side argument checking works before any device call."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "searchlite_gpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(slg_[a-z_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from searchlite_amd import _native
+    if not os.path.exists(_native.lib_path()):
+        from searchlite_amd import build
+        build.build_gpu()
+    return _native.load()
+
+
+def test_header_declares_expected_surface():
+    names = declared_functions()
+    for must in ["slg_index_create", "slg_index_destroy", "slg_search_batch", "slg_batch_prepare",
+                 "slg_batch_run", "slg_batch_fetch", "slg_rerank_batch", "slg_last_error",
+                 "slg_merge_shards_device"]:
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(lib):
+    missing = [n for n in declared_functions() if not hasattr(lib, n)]
+    assert not missing, f"not exported: {missing}"
+
+
+def test_abi_version_and_error_string(lib):
+    assert lib.slg_abi_version() == 1
+    assert isinstance(lib.slg_last_error(), bytes)
+
+
+def test_null_arguments_fail_cleanly(lib):
+    """searchlite-ffi conventions (searchlite-ffi/src/lib.rs:24-43): NULL / negative, no crash."""
+    from searchlite_amd import _native as N
+    assert lib.slg_index_create(None, 0, 0) is None
+    assert b"segs" in lib.slg_last_error()
+    assert lib.slg_batch_run(None) == N.ERR_INVALID
+    assert lib.slg_batch_fetch(None, None, None, None, None, None) == N.ERR_INVALID
+    assert lib.slg_search_batch(None, None, 0, 11, 1, None, None, None, None, None) == N.ERR_INVALID
+    assert lib.slg_index_info(None, None, None, None) == N.ERR_INVALID
+    lib.slg_index_destroy(None)
+    lib.slg_batch_destroy(None)
+
+
+def test_malformed_segment_is_rejected_before_touching_a_device(lib):
+    import numpy as np
+    from searchlite_amd import _native as N
+    offs = np.array([0, 2, 1], dtype=np.uint64)  # not monotone
+    docs = np.array([1, 2], dtype=np.uint32)
+    tfs = np.array([1, 1], dtype=np.uint32)
+    dl = np.ones(4, dtype=np.float32)
+    avg = np.ones(1, dtype=np.float32)
+    ptrs = (C.c_void_p * 1)(dl.ctypes.data)
+    d = N.SegmentDesc(4, 2, offs.ctypes.data, docs.ctypes.data, tfs.ctypes.data, None, 1,
+                      C.addressof(ptrs), avg.ctypes.data, 4.0, 0.9, 0.4, None, 0, 0, None, None, 0)
+    arr = (N.SegmentDesc * 1)(d)
+    assert lib.slg_index_create(arr, 1, 0) is None
+    assert b"monotone" in lib.slg_last_error() or b"too long" in lib.slg_last_error()
+
+
+def test_no_cpu_fallback_without_device():
+    """Without a GPU the product must fail loudly, not compute on the CPU."""
+    import numpy as np
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import searchlite_amd as sa
+    from searchlite_amd import _native as N
+    from tests.util import random_segment
+    seg = random_segment(np.random.default_rng(0), 50, 5, 5)
+    with pytest.raises(N.SlgError) as ei:
+        sa.GpuIndex([seg])
+    assert ei.value.code in (N.ERR_DEVICE, N.ERR_INVALID)

@@ -55,3 +55,266 @@ def test_wand_unit_case(gpu, oracle):
     want = oracle.execute_top_k([t1, t2], 2, oracle.BM25, use_plan=True)
     assert [h[0] for h in hits] == [3, 1]
     assert hits == want
+
+
+# ---- golden fixtures through the HIP path ------------------------------------------------------
+@pytest.mark.parametrize("name", ["recipes.npz", "pruning40.npz", "two_segments.npz"])
+def test_golden_fixtures(gpu, name):
+    from tests.util import golden_expected, load_golden
+    segs, z = load_golden(name)
+    with gpu.GpuIndex(segs) as ix:
+        for strat in (gpu.Bm25, gpu.Wand, gpu.Bmw):
+            got = ix.search_batch(z["q_offsets"], z["q_terms"], z["q_weights"], int(z["k"]), strat)
+            assert_same_hits(got, golden_expected(z), 0.0, f"{name} strategy {strat}")
+
+
+def test_recipes_query_string_search(gpu):
+    """BASELINE config 1 replayed end to end: query string -> folded terms -> GPU -> top-10."""
+    import json
+    import os
+    from tests.util import GOLDEN, load_golden
+    meta = json.load(open(os.path.join(GOLDEN, "recipes.json")))
+    segs, z = load_golden("recipes.npz")
+    # rebuild the dictionary the fixture was made with (keys are stored per query)
+    with gpu.GpuIndex(segs) as ix:
+        d, s, sc, c = ix.search_batch(z["q_offsets"], z["q_terms"], z["q_weights"], 11)
+    for qi, top in enumerate(meta["top10"]):
+        n = min(int(c[qi]), 10)
+        assert [meta["ext_ids"][int(x)] for x in d[qi, :n]] == [t[0] for t in top]
+        assert [float(x) for x in sc[qi, :n]] == [t[1] for t in top]
+
+
+# ---- multi-segment, deleted docs, ragged inputs ----------------------------------------------
+def test_multi_segment_with_absent_terms(gpu, oracle):
+    rng = np.random.default_rng(77)
+    segs = [random_segment(rng, 800 + 300 * i, 40, 18, missing_len_frac=0.1) for i in range(3)]
+    nq, T = 20, 4
+    offs, terms, w = random_queries(rng, nq, T, 40, n_segs=3, weights=True)
+    terms[::5, 1] = gpu.NO_TERM          # some terms missing from segment 1
+    terms[3::7, :] = gpu.NO_TERM         # some terms missing everywhere
+    want = _oracle_batch(oracle, segs, offs, terms, w, 11)
+    with gpu.GpuIndex(segs) as ix:
+        got = ix.search_batch(offs, terms, w, 11)
+    assert_same_hits(got, want, 0.0, "3 segments")
+
+
+def test_deleted_docs_and_stats(gpu, oracle):
+    rng = np.random.default_rng(5)
+    seg = random_segment(rng, 1500, 30, 20)
+    offs, terms, w = random_queries(rng, 16, 3, 30)
+    first = _oracle_batch(oracle, [seg], offs, terms, w, 11)
+    seg.set_deleted([int(first[0][q, 0]) for q in range(16)] + list(range(0, 1500, 7)))
+    want = oracle.search_batch([seg], offs, terms, w, 11, strategy=oracle.BM25, want_stats=True)
+    with gpu.GpuIndex([seg]) as ix:
+        got = ix.search_batch(offs, terms, w, 11, want_stats=True)
+    assert_same_hits(got[:4], want[:4], 0.0, "deleted")
+    for q in range(16):  # brute-force accounting (wand.rs:472,500-503)
+        assert got[4][q].postings_advanced == want[4][q].postings_advanced
+        assert got[4][q].scored_docs == want[4][q].scored_docs
+        assert got[4][q].candidates_examined == want[4][q].candidates_examined
+
+
+def test_ragged_and_empty_inputs(gpu, oracle):
+    rng = np.random.default_rng(3)
+    seg = random_segment(rng, 300, 12, 10)
+    # query 0: no terms; 1: one term; 2: five terms; 3: a term with NO_TERM only
+    offs = np.array([0, 0, 1, 6, 7], dtype=np.uint32)
+    terms = np.array([[2], [0], [1], [3], [4], [5], [gpu.NO_TERM]], dtype=np.uint32)
+    w = np.ones(7, dtype=np.float32)
+    want = _oracle_batch(oracle, [seg], offs, terms, w, 11)
+    with gpu.GpuIndex([seg]) as ix:
+        got = ix.search_batch(offs, terms, w, 11)
+        assert_same_hits(got, want, 0.0, "ragged")
+        assert got[3][0] == 0 and got[3][3] == 0
+        # nq == 0 and k == 0 (wand.rs:413-416)
+        d, s, sc, c = ix.search_batch(np.array([0], dtype=np.uint32), np.zeros((0, 1), np.uint32),
+                                      np.zeros(0, np.float32), 11)
+        assert d.shape == (0, 11) and c.shape == (0,)
+        d, s, sc, c = ix.search_batch(offs, terms, w, 0)
+        assert (c == 0).all()
+        # k larger than the number of matching docs
+        big = ix.search_batch(offs, terms, w, 600)
+        wantb = _oracle_batch(oracle, [seg], offs, terms, w, 600)
+        assert_same_hits(big, wantb, 0.0, "k > matches")
+
+
+def test_equal_scores_tie_break_on_doc_id(gpu, oracle):
+    """query/wand.rs:951-966: equal score => smaller doc id first, also across the k boundary."""
+    from searchlite_amd.segment import Segment
+    n = 500
+    seg = Segment(n_docs=n, term_offsets=[0, n], doc_ids=np.arange(n), tfs=np.ones(n),
+                  field_doc_len=[np.full(n, 7.0, np.float32)], field_avgdl=[7.0], docs=float(n))
+    with gpu.GpuIndex([seg]) as ix:
+        for k in (1, 11, 64, 65, 200):
+            hits = ix.execute_top_k([(0, 1.0)], k)
+            assert [h[0] for h in hits] == list(range(k))
+            assert len({h[1] for h in hits}) == 1
+
+
+@pytest.mark.parametrize("T", [6, 8, 12, 32])
+def test_many_terms(gpu, oracle, T):
+    rng = np.random.default_rng(40 + T)
+    seg = random_segment(rng, 2500, 80, 30, zipf=False)
+    offs, terms, w = random_queries(rng, 6, T, 80, weights=True)
+    want = _oracle_batch(oracle, [seg], offs, terms, w, 21)
+    with gpu.GpuIndex([seg]) as ix:
+        got = ix.search_batch(offs, terms, w, 21)
+    assert_same_hits(got, want, 0.0, f"T={T}")
+
+
+def test_negative_and_zero_weights(gpu, oracle):
+    """A negative boost disables the champion threshold seed; results stay exact."""
+    rng = np.random.default_rng(8)
+    seg = random_segment(rng, 2000, 25, 20)
+    offs, terms, w = random_queries(rng, 10, 3, 25, weights=True)
+    w[::3] = -w[::3]
+    w[1::5] = 0.0
+    want = _oracle_batch(oracle, [seg], offs, terms, w, 11)
+    with gpu.GpuIndex([seg]) as ix:
+        got = ix.search_batch(offs, terms, w, 11)
+    assert_same_hits(got, want, 0.0, "negative weights")
+
+
+# ---- skewed corpora: over-full rounds and rounds spanning many doc windows ----------------------
+def _skewed_segment(n_docs, lists):
+    """lists: [(doc_ids array)] -> one-field segment with tf from a fixed pattern."""
+    from searchlite_amd.segment import Segment
+    offs, docs, tfs = [0], [], []
+    for d in lists:
+        d = np.unique(np.asarray(d, dtype=np.uint32))
+        docs.append(d)
+        tfs.append((d % 5 + 1).astype(np.uint32))
+        offs.append(offs[-1] + len(d))
+    rng = np.random.default_rng(1)
+    dl = rng.integers(5, 60, size=n_docs).astype(np.float32)
+    return Segment(n_docs=n_docs, term_offsets=np.array(offs, dtype=np.uint64),
+                   doc_ids=np.concatenate(docs), tfs=np.concatenate(tfs), field_doc_len=[dl],
+                   field_avgdl=[float(dl.mean())], docs=float(n_docs), k1=1.2, b=0.75)
+
+
+def test_clustered_list_makes_overfull_rounds(gpu, oracle):
+    """The round planner cuts at strides of the longest list; a shorter list that is packed into
+    a narrow doc range then lands > 512 postings in one round (the streaming path)."""
+    n = 400_000
+    rng = np.random.default_rng(12)
+    long_list = np.sort(rng.choice(n, size=60_000, replace=False))
+    clustered = np.arange(200_000, 200_000 + 20_000)          # 20k consecutive docs
+    sparse = np.sort(rng.choice(n, size=300, replace=False))
+    seg = _skewed_segment(n, [long_list, clustered, sparse])
+    offs = np.array([0, 3, 5, 6], dtype=np.uint32)
+    terms = np.array([[0], [1], [2], [1], [2], [1]], dtype=np.uint32)
+    w = np.array([1.0, 0.7, 2.0, 1.0, 1.0, 1.0], dtype=np.float32)
+    want = _oracle_batch(oracle, [seg], offs, terms, w, 11)
+    with gpu.GpuIndex([seg]) as ix:
+        got = ix.search_batch(offs, terms, w, 11, want_stats=True)
+    assert_same_hits(got[:4], want[:4], 0.0, "clustered")
+    assert got[4][0].scored_docs == len(np.union1d(np.union1d(long_list, clustered), sparse))
+
+
+def test_sparse_lists_span_many_doc_windows(gpu, oracle):
+    """Few postings spread over millions of doc ids: one round spans far more than the
+    16384-doc bitmap window (the multi-window path)."""
+    n = 3_000_000
+    rng = np.random.default_rng(13)
+    lists = [np.sort(rng.choice(n, size=s, replace=False)) for s in (900, 700, 40)]
+    lists.append(np.array([5, n - 1]))
+    seg = _skewed_segment(n, lists)
+    offs = np.array([0, 3, 5, 7], dtype=np.uint32)
+    terms = np.array([[0], [1], [2], [3], [0], [2], [3]], dtype=np.uint32)
+    w = np.ones(7, dtype=np.float32)
+    want = _oracle_batch(oracle, [seg], offs, terms, w, 64)
+    with gpu.GpuIndex([seg]) as ix:
+        got = ix.search_batch(offs, terms, w, 64)
+    assert_same_hits(got, want, 0.0, "sparse windows")
+
+
+def test_three_tiny_lists_share_one_slot(gpu, oracle):
+    """Three lists inside one 64-posting slot with common docs: the strictly ordered claim path
+    (sum order (a+b)+c matters in f32)."""
+    n = 2000
+    common = np.array([10, 500, 501, 1999])
+    lists = [np.union1d(common, [1, 7]), np.union1d(common, [3, 1500]), np.union1d(common, [2])]
+    seg = _skewed_segment(n, lists)
+    offs = np.array([0, 3], dtype=np.uint32)
+    terms = np.array([[0], [1], [2]], dtype=np.uint32)
+    w = np.array([0.3, 1.7, 0.9], dtype=np.float32)
+    want = _oracle_batch(oracle, [seg], offs, terms, w, 11)
+    with gpu.GpuIndex([seg]) as ix:
+        got = ix.search_batch(offs, terms, w, 11)
+    assert_same_hits(got, want, 0.0, "tiny lists")
+
+
+# ---- prepared batches, determinism, errors -----------------------------------------------------
+def test_prepared_batch_is_deterministic_and_reusable(gpu, oracle):
+    rng = np.random.default_rng(21)
+    seg = random_segment(rng, 6000, 200, 25)
+    offs, terms, w = random_queries(rng, 128, 3, 200)
+    want = _oracle_batch(oracle, [seg], offs, terms, w, 11)
+    with gpu.GpuIndex([seg]) as ix:
+        b = ix.prepare(offs, terms, w, 11)
+        info = b.info()
+        assert info["n_postings"] == sum(seg.df(int(t)) for t in terms.reshape(-1))
+        assert info["algorithmic_bytes"] == 12 * info["n_postings"] + 8 * 11 * 128
+        outs = []
+        for _ in range(3):
+            b.run()
+            outs.append(b.fetch())
+        b.close()
+    for o in outs:
+        assert_same_hits(o, want, 0.0, "prepared")
+    for a, c in zip(outs[0], outs[2]):
+        assert np.array_equal(a, c)  # same batch twice => bit-identical output
+
+
+def test_error_codes(gpu):
+    from searchlite_amd import _native as N
+    rng = np.random.default_rng(2)
+    seg = random_segment(rng, 100, 40, 8)
+    with gpu.GpuIndex([seg]) as ix:
+        offs = np.array([0, 1], dtype=np.uint32)
+        with pytest.raises(N.SlgError) as e:
+            ix.search_batch(offs, np.array([[0]], np.uint32), np.ones(1, np.float32), 2000)
+        assert e.value.code == N.ERR_UNSUPPORTED        # k > SLG_MAX_K
+        with pytest.raises(N.SlgError) as e:
+            ix.search_batch(np.array([0, 33], np.uint32), np.arange(33, dtype=np.uint32)[:, None],
+                            np.ones(33, np.float32), 5)
+        assert e.value.code == N.ERR_UNSUPPORTED        # > SLG_MAX_QUERY_TERMS
+        with pytest.raises(N.SlgError) as e:
+            ix.search_batch(offs, np.array([[4000]], np.uint32), np.ones(1, np.float32), 5)
+        assert e.value.code == N.ERR_INVALID            # term id out of range
+        with pytest.raises(N.SlgError) as e:
+            ix.search_batch(offs, np.array([[0]], np.uint32), np.array([np.nan], np.float32), 5)
+        assert e.value.code == N.ERR_INVALID
+        with pytest.raises(N.SlgError) as e:
+            ix.rerank_batch(np.zeros((1, 4), np.float32), 0.5, np.zeros((1, 2)), np.zeros((1, 2)),
+                            np.zeros((1, 2)), np.array([2]), 1)
+        assert e.value.code == N.ERR_UNSUPPORTED        # index has no vectors
+
+
+# ---- BASELINE-size properties (config 2: 1M docs, 3-term OR, batch 1024, top-10) -----------------
+def test_config2_full_size_properties(gpu, oracle):
+    from searchlite_amd import corpus
+    seg = corpus.zipf_segment(1_000_000, 1 << 18, seed=42)
+    offs, terms, w = corpus.zipf_queries(1024, 3, seed=7, vocab=1 << 18)
+    with gpu.GpuIndex([seg]) as ix:
+        b = ix.prepare(offs, terms, w, 11)
+        b.run()
+        d, s, sc, c = b.fetch()
+        b.run()
+        d2, s2, sc2, c2 = b.fetch()
+        b.close()
+    assert np.array_equal(d, d2) and np.array_equal(sc.view(np.uint32), sc2.view(np.uint32))
+    assert (c == 11).all()
+    # sortedness: score desc, doc asc on ties; docs distinct and in range
+    assert (sc[:, :-1] >= sc[:, 1:]).all()
+    tie = sc[:, :-1] == sc[:, 1:]
+    assert (d[:, :-1][tie] < d[:, 1:][tie]).all()
+    assert (d < seg.n_docs).all() and all(len(set(r)) == 11 for r in d[:64])
+    # every returned doc really contains a query term, and a sample of queries is bit-exact
+    nchk = 48
+    want = oracle.search_batch([seg], offs[:nchk + 1], terms[:nchk * 3], w[:nchk * 3], 11,
+                               strategy=oracle.BM25, n_threads=8)
+    assert_same_hits((d[:nchk], s[:nchk], sc[:nchk], c[:nchk]), want, 0.0, "config 2 sample")
+    wand = oracle.search_batch([seg], offs[:9], terms[:24], w[:24], 11, strategy=oracle.WAND,
+                               cache_min_len=True, n_threads=8)
+    assert_same_hits((d[:8], s[:8], sc[:8], c[:8]), wand, 0.0, "config 2 vs oracle WAND")

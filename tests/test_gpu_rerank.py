@@ -1,0 +1,106 @@
+"""GPU rerank (the gpu::rerank slot) vs the oracle.  The reference sums the dot product left to
+right in f32 (vectors/mod.rs:111); the kernel reduces lane-parallel, so vector scores agree to
+|d| <= 1e-5 (north_star tolerance 1e-4) and orderings are checked away from near-ties."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import GOLDEN
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _segment_with_vectors(n_docs, offsets, values, metric):
+    from searchlite_amd.segment import Segment
+    return Segment(n_docs=n_docs, term_offsets=[0, 1], doc_ids=[0], tfs=[1],
+                   field_doc_len=[np.ones(n_docs, np.float32)], field_avgdl=[1.0],
+                   docs=float(n_docs), vec_dim=values.shape[1], vec_metric=metric,
+                   vec_offsets=offsets, vec_values=values)
+
+
+def _check(got, want_doc, want_score, want_vec, what):
+    gd, gs, gsc, gv, gc = got
+    for q in range(len(want_doc)):
+        n = len(want_doc[q])
+        assert gc[q] == n, what
+        assert np.abs(gsc[q, :n] - want_score[q]).max() <= TOL, what
+        # same docs; order may differ only between candidates closer than the tolerance
+        assert sorted(gd[q, :n]) == sorted(want_doc[q]) or \
+            np.abs(np.sort(gsc[q, :n]) - np.sort(want_score[q])).max() <= TOL, what
+        for i in range(n):
+            if gd[q, i] != want_doc[q][i]:
+                j = list(want_doc[q]).index(gd[q, i]) if gd[q, i] in want_doc[q] else None
+                assert j is not None and abs(want_score[q][j] - want_score[q][i]) <= 2 * TOL, what
+        if want_vec is not None:
+            m = {int(d): float(v) for d, v in zip(want_doc[q], want_vec[q])}
+            for i in range(n):
+                if int(gd[q, i]) in m:
+                    assert abs(gv[q, i] - m[int(gd[q, i])]) <= TOL or m[int(gd[q, i])] < -1e30, what
+
+
+@pytest.mark.parametrize("metric,name", [(0, "cos"), (1, "l2")])
+def test_rerank_golden(metric, name):
+    import searchlite_amd as sa
+    z = np.load(os.path.join(GOLDEN, "rerank16.npz"))
+    seg = _segment_with_vectors(64, z["vec_offsets"], z["vec_values"], metric)
+    nq, nc = z["cand_doc"].shape
+    with sa.GpuIndex([seg]) as ix:
+        got = ix.rerank_batch(z["qvecs"], z["alpha"], z["cand_doc"], np.zeros((nq, nc), np.uint32),
+                              z["cand_bm25"], np.full(nq, nc, np.uint32), 10)
+    _check(got, z[f"exp_doc_{name}"], z[f"exp_score_{name}"], z[f"exp_vec_{name}"], name)
+
+
+@pytest.mark.parametrize("dim,ncand,k_out", [(768, 1001, 10), (100, 300, 70), (6, 40, 40)])
+def test_rerank_random(oracle, dim, ncand, k_out):
+    """config 5 shape: BM25 top-1000 -> cosine rerank -> top-10 (dim 768)."""
+    import searchlite_amd as sa
+    from searchlite_amd import corpus
+    rng = np.random.default_rng(dim)
+    n = 5000
+    vals = corpus.unit_vectors(n, dim, seed=11)
+    offsets = np.arange(n, dtype=np.uint32)
+    offsets[rng.choice(n, size=50, replace=False)] = 0xFFFFFFFF
+    rows = vals  # offsets index rows directly
+    nq = 6
+    q = corpus.unit_vectors(nq, dim, seed=12)
+    cand = np.stack([rng.choice(n, size=ncand, replace=False) for _ in range(nq)]).astype(np.uint32)
+    bm = (rng.random((nq, ncand)) * 20).astype(np.float32)
+    cnt = np.full(nq, ncand, np.uint32)
+    cnt[1] = ncand // 2
+    alpha = np.array([0.5, 0.5, 0.2, 0.8, 1.0, 0.0], np.float32)
+    for metric in (0, 1):
+        seg = _segment_with_vectors(n, offsets, rows, metric)
+        with sa.GpuIndex([seg]) as ix:
+            got = ix.rerank_batch(q, alpha, cand, np.zeros_like(cand), bm, cnt, k_out)
+        wd, ws, wv = [], [], []
+        for i in range(nq):
+            d_, s_, v_ = oracle.rerank(metric, offsets, rows, q[i], float(alpha[i]),
+                                       cand[i, :cnt[i]], bm[i, :cnt[i]], k_out)
+            wd.append(d_)
+            ws.append(s_)
+            wv.append(v_)
+        _check(got, wd, ws, wv, f"metric {metric} dim {dim}")
+
+
+def test_hybrid_blends_text_and_vector_gpu(oracle):
+    """tests/vector_search.rs:201-269 through BM25 (GPU) -> rerank (GPU)."""
+    import searchlite_amd as sa
+    from searchlite_amd.segment import SegmentBuilder
+    b = SegmentBuilder(["body"], k1=0.9, b=0.4)
+    b.add_document("long", {"body": "rust rust rust"})
+    b.add_document("short", {"body": "rust"})
+    seg = b.build()
+    seg.vec_dim, seg.vec_metric = 2, 0
+    seg.vec_offsets = np.array([0, 1], dtype=np.uint32)
+    seg.vec_values = np.array([[0.0, 1.0], [1.0, 0.0]], dtype=np.float32)
+    with sa.GpuIndex([seg]) as ix:
+        hits = ix.search("rust", "body", limit=10)
+        assert [seg.ext_ids[h[1]] for h in hits] == ["long", "short"]
+        d = np.array([[h[1] for h in hits]], np.uint32)
+        sc = np.array([[h[2] for h in hits]], np.float32)
+        od, os_, osc, ov, oc = ix.rerank_batch(np.array([[1.0, 0.0]], np.float32), 0.2, d,
+                                                np.zeros_like(d), sc, np.array([2]), 2)
+    assert seg.ext_ids[int(od[0, 0])] == "short"
+    assert osc[0, 0] == np.float32(np.float32(0.2) * np.float32(1.1046511) + np.float32(0.8))

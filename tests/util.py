@@ -75,3 +75,35 @@ def assert_same_hits(got, want, score_tol=0.0, what=""):
             if d.size and d.max() > score_tol:
                 bad.append((q, "score", float(d.max()), score_tol))
     assert not bad, f"{what}: {len(bad)} queries differ, first: {bad[:5]}"
+
+
+GOLDEN = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    """-> (segments, npz) for a fixture written by tests/golden/make_golden.py."""
+    import os
+    from searchlite_amd.segment import Segment
+    z = np.load(os.path.join(GOLDEN, name))
+
+    def seg(prefix):
+        nf = int(z[prefix + "n_fields"])
+        lens = [z[prefix + f"doc_len{i}"] if (prefix + f"doc_len{i}") in z else None
+                for i in range(nf)]
+        return Segment(n_docs=int(z[prefix + "n_docs"]), term_offsets=z[prefix + "term_offsets"],
+                       doc_ids=z[prefix + "doc_ids"], tfs=z[prefix + "tfs"], field_doc_len=lens,
+                       field_avgdl=z[prefix + "field_avgdl"], docs=float(z[prefix + "docs"]),
+                       k1=float(z[prefix + "k1"]), b=float(z[prefix + "b"]),
+                       term_field=z[prefix + "term_field"] if (prefix + "term_field") in z else None)
+
+    if "n_docs" in z:
+        return [seg("")], z
+    segs, i = [], 0
+    while f"s{i}_n_docs" in z:
+        segs.append(seg(f"s{i}_"))
+        i += 1
+    return segs, z
+
+
+def golden_expected(z):
+    return z["exp_doc"], z["exp_seg"], z["exp_score"], z["exp_count"]
