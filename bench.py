@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=0, help="queries in the CPU sample")
     ap.add_argument("--check", type=int, default=64, help="queries parity-checked vs the oracle")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) even for one rank, to exercise the all-gather path")
     return ap.parse_args()
 
 
@@ -78,7 +80,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
@@ -91,7 +96,8 @@ def main():
     limit = args.limit or limit
     k = limit + 1  # api/reader.rs:2615-2619
     strategy = {"bm25": searcher.Bm25, "wand": searcher.Wand, "bmw": searcher.Bmw}[args.strategy]
-    threads = max(1, (os.cpu_count() or 1) // max(1, world if world <= 8 else 8))
+    host_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(32, host_cores // max(1, world)))
 
     t0 = time.time()
     shard_mode = args.mode == "shard" and world > 1
@@ -111,7 +117,7 @@ def main():
     t_seg = torch.as_tensor(_DevArray(d_seg, (nq, k), "<i4"), device="cuda")
     t_score = torch.as_tensor(_DevArray(d_score, (nq, k), "<f4"), device="cuda")
     t_count = torch.as_tensor(_DevArray(d_count, (nq,), "<i4"), device="cuda")
-    if world > 1:
+    if use_dist:
         g_doc = torch.empty((world, nq, k), dtype=torch.int32, device="cuda")
         g_seg = torch.empty_like(g_doc)
         g_score = torch.empty((world, nq, k), dtype=torch.float32, device="cuda")
@@ -123,7 +129,7 @@ def main():
 
     def step():
         batch.run()
-        if world > 1:
+        if use_dist:
             # per-rank top-k exchanged over xGMI: Q*k*(4+4+4)+Q*4 bytes per rank
             dist.all_gather_into_tensor(g_doc, t_doc)
             dist.all_gather_into_tensor(g_seg, t_seg)
@@ -136,7 +142,7 @@ def main():
                                           m_count.data_ptr())
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -152,7 +158,7 @@ def main():
     elapsed = time.perf_counter() - t1
     n_launch, kern_ms = index.profile_read()
     index.profile(False)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -194,7 +200,7 @@ def main():
                        "corpus_build_s": round(t_corpus, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "kernel": "score_slices_kernel",
+                         "traffic": traffic, "kernel": "score_rounds_kernel",
                          "kernel_ms": round(kern_avg_ms, 4), "launches": n_launch,
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
@@ -217,7 +223,7 @@ def main():
                 print(json.dumps(out))
                 raise SystemExit("bench.py: GPU results differ from the oracle")
         if world == 1 and not args.no_cpu_baseline:
-            cores = os.cpu_count() or 1
+            cores = host_cores
             ncpu = min(args.cpu_queries or nq, nq)
             co, ct, cw = offs[:ncpu + 1], terms[:ncpu * T], w[:ncpu * T]
             ostrat = {"bm25": O.BM25, "wand": O.WAND, "bmw": O.BMW}[args.strategy]
@@ -250,7 +256,7 @@ def main():
 
     batch.close()
     index.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
