@@ -41,17 +41,20 @@ def _hipcc() -> str:
 SCORE_KREGS = (1, 2, 4, 8, 16)
 
 
-def build_gpu(force: bool = False, verbose: bool = False) -> str:
-    """hipcc every translation unit for gfx950 (score-kernel variants in parallel), then link."""
+def build_gpu(force: bool = False, verbose: bool = False, stamps: bool = False) -> str:
+    """hipcc every translation unit for gfx950 (score-kernel variants in parallel), then link.
+    stamps=True builds the diagnostic library with in-kernel s_memtime stamps (tools/stamps.py)."""
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
+    objdir = os.path.join(LIBDIR, "obj_stamps" if stamps else "obj")
+    out_lib = os.path.join(LIBDIR, "libsearchlite_gpu_stamps.so") if stamps else GPU_LIB
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in ("slg_kernels.hpp", "slg_rerank.hpp", "slg_score.hpp")]
     hdrs.append(os.path.join(_HERE, "..", "include", "searchlite_gpu.h"))
-    compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"] + (["-DSLG_STAMPS"] if stamps else [])
+    kregs = (1,) if stamps else SCORE_KREGS
     jobs = [(os.path.join(CSRC, "slg_api.hip"), os.path.join(objdir, "slg_api.o"), [])]
-    for kr in SCORE_KREGS:
+    for kr in kregs:
         jobs.append((os.path.join(CSRC, "slg_score_inst.hip"),
                      os.path.join(objdir, f"slg_score_k{kr}.o"), [f"-DSLG_INST_KREGS={kr}"]))
 
@@ -68,12 +71,12 @@ def build_gpu(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
         rebuilt = list(ex.map(compile_one, jobs))
     objs = [j[1] for j in jobs]
-    if force or any(rebuilt) or _newer(GPU_LIB, objs):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", GPU_LIB, *objs]
+    if force or any(rebuilt) or _newer(out_lib, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out_lib, *objs]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return GPU_LIB
+    return out_lib
 
 
 def build_corpus_tool(force: bool = False) -> str:

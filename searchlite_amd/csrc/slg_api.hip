@@ -103,6 +103,7 @@ struct SegHost {
   uint32_t n_docs = 0, n_terms = 0;
   uint64_t n_postings = 0;
   std::vector<uint64_t> term_offsets;
+  std::vector<float> champ;  // host mirror of d_champ [V * kChampions] (query planning)
   DevBuf d_docs, d_imps, d_deleted, d_champ;
   // vectors
   uint32_t vec_dim = 0, vec_rows = 0;
@@ -132,7 +133,7 @@ struct slg_batch {
   uint32_t nq = 0, k = 0;
   int strategy = 0;
   uint32_t n_sq = 0, n_slices = 0, n_terms = 0, n_boundaries = 0, max_terms = 0;
-  uint64_t n_postings = 0, n_rounds = 0;
+  uint64_t n_postings = 0, n_postings_essential = 0, n_rounds = 0;
   std::vector<uint64_t> q_postings;  // per query (stats.postings_advanced)
   DevBuf d_desc;                     // packed descriptors
   const slg::RoundQuery *d_sq = nullptr;
@@ -181,6 +182,12 @@ template <> void launch_score_kregs<16>(const RoundScoreParams &, uint32_t, hipS
 namespace {
 
 void launch_score(const slg::RoundScoreParams &sp, uint32_t max_terms, hipStream_t st) {
+#ifdef SLG_STAMPS  // diagnostic build: only the k <= 64 variant is compiled
+  if (kregs_for(sp.k) != 1) throw SlgError(SLG_ERR_UNSUPPORTED, "stamps build supports k <= 64 only");
+  slg::launch_score_kregs<1>(sp, max_terms, st);
+  SLG_HIP(hipGetLastError());
+  return;
+#else
   switch (kregs_for(sp.k)) {
     case 1: slg::launch_score_kregs<1>(sp, max_terms, st); break;
     case 2: slg::launch_score_kregs<2>(sp, max_terms, st); break;
@@ -189,6 +196,7 @@ void launch_score(const slg::RoundScoreParams &sp, uint32_t max_terms, hipStream
     default: slg::launch_score_kregs<16>(sp, max_terms, st); break;
   }
   SLG_HIP(hipGetLastError());
+#endif
 }
 
 template <int KREGS>
@@ -343,6 +351,10 @@ void stage_segment(slg_index *ix, SegHost &sh, const slg_segment_desc &d) {
       SLG_HIP(hipGetLastError());
     }
     SLG_HIP(hipStreamSynchronize(st));  // temporaries die here
+    if (sh.d_champ.p) {
+      sh.champ.resize((size_t)d.n_terms * slg::kChampions);
+      SLG_HIP(hipMemcpy(sh.champ.data(), sh.d_champ.p, sh.champ.size() * 4, hipMemcpyDeviceToHost));
+    }
   }
   if (d.vec_dim) {
     sh.vec_dim = d.vec_dim;
@@ -507,7 +519,7 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
     // ---- pass 1: sub-queries and their terms (api/reader.rs:2986-3005) ----
     std::vector<slg::RoundQuery> sqs;
     std::vector<slg::TermRef> terms;
-    std::vector<uint64_t> sq_postings;
+    std::vector<uint64_t> sq_postings, sq_postings_all;
     std::vector<uint32_t> q_sq_begin(nq + 1, 0);
     for (uint32_t q = 0; q < nq; q++) {
       q_sq_begin[q] = (uint32_t)sqs.size();
@@ -544,12 +556,62 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
         }
         sq.n_terms = (uint32_t)terms.size() - sq.term_begin;
         if (sq.n_terms == 0) continue;
+        // ---- MaxScore classification (opt-in with SLG_MAXSCORE=1 for strategies Wand / Bmw:
+        // exact, but in round 1 not yet faster than exhaustive scoring — DESIGN.md section 4) ----
+        // theta0 = max_t w_t * champ[t][k-1] is a lower bound of the final k-th score
+        // (slg_score.hpp sets the same floor on the device).  Lists taken in ascending order of
+        // their maximum contribution ub_t = w_t * champ[t][0] are non-essential while the running
+        // sum of ub stays below theta0: a doc found only in them totals < theta0.
+        uint32_t ess_mask = sq.n_terms >= 32 ? 0xFFFFFFFFu : ((1u << sq.n_terms) - 1u);
+        if (strategy != SLG_STRATEGY_BM25 && !sh.champ.empty() && k <= (uint32_t)slg::kChampions &&
+            sq.n_terms > 1 && env_u32("SLG_MAXSCORE", 0) != 0) {
+          bool ok = true;
+          float theta0 = 0.0f;
+          std::vector<std::pair<float, uint32_t>> ub(sq.n_terms);
+          for (uint32_t i = 0; i < sq.n_terms; i++) {
+            const slg::TermRef &tr = terms[sq.term_begin + i];
+            if (!(tr.weight >= 0.0f)) ok = false;
+            const float *c = &sh.champ[(size_t)tr.term * slg::kChampions];
+            theta0 = std::max(theta0, tr.weight * c[k - 1]);
+            ub[i] = {tr.weight * c[0], i};
+          }
+          if (ok && theta0 > 0.0f) {
+            std::sort(ub.begin(), ub.end());
+            double acc = 0.0;
+            for (uint32_t i = 0; i + 1 < sq.n_terms; i++) {  // at least one list stays essential
+              acc += (double)ub[i].first;
+              // margin: f32 sums of the real contributions may round up by a few ulps
+              if (acc * (1.0 + 1e-5) < (double)theta0)
+                ess_mask &= ~(1u << ub[i].second);
+              else
+                break;
+            }
+          }
+        }
+        sq.ess_mask = ess_mask;
+        // the round planner works on the essential lists only
+        P = 0;
+        longest = 0;
+        longest_df = 0;
+        uint64_t P_all = 0;
+        for (uint32_t i = 0; i < sq.n_terms; i++) {
+          const uint32_t df = terms[sq.term_begin + i].df;
+          P_all += df;
+          if (!((ess_mask >> i) & 1u)) continue;
+          P += df;
+          if (df > longest_df) {
+            longest_df = df;
+            longest = i;
+          }
+        }
+        b->q_postings[q] += P_all;
+        b->n_postings += P_all;
+        b->n_postings_essential += P;
         sq.longest = longest;
         b->max_terms = std::max(b->max_terms, sq.n_terms);
         sqs.push_back(sq);
         sq_postings.push_back(P);
-        b->q_postings[q] += P;
-        b->n_postings += P;
+        sq_postings_all.push_back(P_all);
       }
     }
     q_sq_begin[nq] = (uint32_t)sqs.size();
@@ -557,6 +619,7 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
     // ---- pass 2: rounds of ~kRoundTarget postings, slices of consecutive rounds ----
     const uint32_t round_target = std::max<uint32_t>(64, std::min<uint32_t>(
         env_u32("SLG_ROUND_TARGET", slg::kRoundTarget), slg::kCap));
+    const uint32_t probe_target = std::max<uint32_t>(round_target, env_u32("SLG_PROBE_TARGET", 2048));
     const uint32_t max_rps = std::max<uint32_t>(1, std::min<uint32_t>(
         env_u32("SLG_ROUNDS_PER_SLICE", slg::kDefaultRoundsPerSlice), slg::kMaxRoundsPerSlice));
     std::vector<uint32_t> slice_sq, slice_seg, bnd_sq;
@@ -564,7 +627,11 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
     for (size_t i = 0; i < sqs.size(); i++) {
       slg::RoundQuery &sq = sqs[i];
       const uint32_t dfL = terms[sq.term_begin + sq.longest].df;
+      // a round holds <= ~round_target postings of the essential lists (register slots) and
+      // <= ~probe_target postings overall (non-essential lists are streamed per round), so
+      // slices stay balanced whatever the mix
       uint64_t nr = (sq_postings[i] + round_target - 1) / round_target;
+      nr = std::max<uint64_t>(nr, (sq_postings_all[i] + probe_target - 1) / probe_target);
       nr = std::max<uint64_t>(1, std::min<uint64_t>(nr, dfL));
       const uint32_t rps = std::max<uint32_t>(1, std::min<uint32_t>(max_rps, 64 / sq.n_terms - 1));
       const uint64_t S = (nr + rps - 1) / rps;

@@ -50,7 +50,9 @@ struct RoundQuery {  // sub-query = (query, segment) pair with >= 1 non-empty te
   uint32_t bounds_begin;  // bounds[bounds_begin + j*n_terms + t], j = 0..n_rounds
   uint32_t rdoc_begin;    // rdoc[rdoc_begin + j]: first doc id of round j (j = n_rounds: end)
   uint32_t bnd_begin;     // first boundary task of this sub-query (partition kernel)
-  uint32_t longest;       // index of the longest list (splitter source)
+  uint32_t longest;       // index of the longest ESSENTIAL list (splitter source)
+  uint32_t ess_mask;      // bit t: list t is essential (MaxScore); the others are only probed
+  uint32_t pad[3];
 };
 
 struct QueryRef {

@@ -18,6 +18,12 @@
 //      term order, so the f32 sum is bit-identical to the reference's leaf-order sum);
 //   4. the first list that touched a doc "owns" it, reads the finished sum back and offers
 //      it to the wave-wide sorted top-k (registers, DPP shifts).
+// MaxScore pruning (strategies Wand/Bmw): the host marks as NON-ESSENTIAL the lists whose summed
+// maximum contributions stay below the seed threshold theta0 (slg_api.hip).  A doc that occurs
+// only in such lists can never reach the top-k, so those lists set no bitmap bits and own no
+// docs: their postings are merely streamed and probed against the bitmap built by the essential
+// lists, and the (few) hits are added in their term-order pass.  Results are identical to the
+// exhaustive scorer (the reference's own standard: tests/pruning.rs:44-104 Bm25 == Wand == Bmw).
 // Integer/f32 VALU + LDS work bounded by the HBM stream of postings; no MFMA on this path.
 #pragma once
 
@@ -191,6 +197,7 @@ __global__ void __launch_bounds__(256) score_rounds_kernel(RoundScoreParams p) {
   uint32_t *vals = pre + kSpanWords;
   uint4 *bm4 = reinterpret_cast<uint4 *>(bm);
   uint4 *pre4 = reinterpret_cast<uint4 *>(pre);
+  uint4 *vals4 = reinterpret_cast<uint4 *>(vals);
 
   const uint32_t sqi = rfl(p.slice_sq[slice]);
   const RoundQuery s = p.sq[sqi];
@@ -207,6 +214,7 @@ __global__ void __launch_bounds__(256) score_rounds_kernel(RoundScoreParams p) {
   const gf32_t gimps = (gf32_t)sd.imps;
   const gu32_t gdel = (gu32_t)sd.deleted;
   const uint32_t k = p.k;
+  const uint32_t ess_mask = rfl(s.ess_mask);
 
   // lane t < T: list t's posting offset; weights go to scalars
   uint64_t my_off = 0;
@@ -293,11 +301,17 @@ __global__ void __launch_bounds__(256) score_rounds_kernel(RoundScoreParams p) {
   //      * owners store 0.0 + x; the (few) later postings of the same doc add in term order:
   //        ((0.0 + x_a) + x_b) + ... is `or_insert(0.0) += score` (query/wand.rs:539) summed in
   //        ScorePlan leaf order (planner.rs:122-135). ----
-  auto accumulate = [&](Elems &e, const uint32_t validmask, const uint32_t wbase) {
+  // ne_cur (lane t): cursor of non-essential list t inside the current round; ne_end: its end
+  uint32_t ne_cur = 0, ne_end = 0;
+
+  auto accumulate = [&](Elems &e, const uint32_t validmask, const uint32_t wbase,
+                        const uint32_t dend) {
     SLG_STAMP(1);
-    // P0: clear the bitmap
+    // P0: clear the bitmap and the accumulators (+0.0f)
     bm4[lane] = make_uint4(0u, 0u, 0u, 0u);
     bm4[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
+    vals4[lane] = make_uint4(0u, 0u, 0u, 0u);
+    vals4[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
     wave_fence();
     // P1: one bit per posting; the returned old word tells who came first.  Slots are
     // laid out list by list, so across slots "first" is term order.  Inside one slot that
@@ -343,23 +357,25 @@ __global__ void __launch_bounds__(256) score_rounds_kernel(RoundScoreParams p) {
     }
     wave_fence();
     SLG_STAMP(2);
-    // P2: exclusive prefix popcount over words (lane l owns words 8l..8l+7)
+    // P2: exclusive prefix popcount.  Lane l owns words 4l..4l+3 and 256+4l..256+4l+3 (two
+    // conflict-free ds_read_b128 at a 16-byte lane stride); ranks are numbered lane-major
+    // (any bijection doc -> slot works), so one wave scan suffices.
     {
-      const uint4 a = bm4[lane * 2], b = bm4[lane * 2 + 1];
+      const uint4 a = bm4[lane], b = bm4[lane + 64];
       const uint32_t c0 = __popc(a.x), c1 = c0 + __popc(a.y), c2 = c1 + __popc(a.z),
                      c3 = c2 + __popc(a.w), c4 = c3 + __popc(b.x), c5 = c4 + __popc(b.y),
                      c6 = c5 + __popc(b.z), c7 = c6 + __popc(b.w);
       const uint32_t incl = wave_incl_scan(c7);
       const uint32_t ex = incl - c7;
-      pre4[lane * 2] = make_uint4(ex, ex + c0, ex + c1, ex + c2);
-      pre4[lane * 2 + 1] = make_uint4(ex + c3, ex + c4, ex + c5, ex + c6);
+      pre4[lane] = make_uint4(ex, ex + c0, ex + c1, ex + c2);
+      pre4[lane + 64] = make_uint4(ex + c3, ex + c4, ex + c5, ex + c6);
       n_scored += rl(incl, 63);
     }
     wave_fence();
     SLG_STAMP(3);
-    // P3a: rank of every posting and its weighted impact; owners store 0.0 + x
+    // P3a: rank of every (essential) posting and its weighted impact
     uint32_t slot[kNSlot];
-    uint32_t lmask = 0;  // bit jj: this lane holds a non-owner ("later") posting in slot jj
+    uint32_t tlo[kNSlot], thi[kNSlot];  // uniform: first / last list present in the slot
     {
       uint32_t wd[kNSlot], pf[kNSlot];
       float w[kNSlot];
@@ -372,30 +388,112 @@ __global__ void __launch_bounds__(256) score_rounds_kernel(RoundScoreParams p) {
       }
 #pragma unroll
       for (int jj = 0; jj < kNSlot; jj++) {
-        const bool own = (ownmask >> jj) & 1u;
         slot[jj] = (pf[jj] + __popc(wd[jj] & (bit[jj] - 1u))) & (kCap - 1);
         e.imp[jj] = bit[jj] != 0u ? e.imp[jj] * w[jj] : e.imp[jj];  // x, in place
-        vals[own ? slot[jj] : kCap + lane] = __float_as_uint(0.0f + e.imp[jj]);
-        lmask |= (bit[jj] != 0u && !own) ? (1u << jj) : 0u;
+        const uint32_t tj = e.t(jj);
+        tlo[jj] = rfl(tj);
+        thi[jj] = rl(tj, 63);  // idle lanes past the end report the last list: harmless
       }
     }
     wave_fence();
-    // P3b: later postings of a doc add to the owner's value, one list at a time in term order
-    if (__ballot(lmask != 0u) != 0ull) {
-      for (uint32_t tc = 0; tc < T; tc++) {
-        uint32_t am = 0;
+    // P3b: per-doc sums in term order.  vals started at +0.0, so each doc's sum is
+    // ((0.0 + x_a) + x_b) + ... exactly as the reference forms it.
+    const uint32_t full_mask = T >= 32 ? 0xFFFFFFFFu : ((1u << T) - 1u);
+    if (ess_mask == full_mask) {
+      // all lists essential: the owner is the first list (in term order) holding the doc, so it
+      // can store 0.0 + x directly; only later postings of the same doc read-add-write
+      uint32_t lmask = 0;
 #pragma unroll
-        for (int jj = 0; jj < kNSlot; jj++) am |= (((lmask >> jj) & 1u) && e.t(jj) == tc) ? 1u : 0u;
-        if (__ballot(am != 0u) == 0ull) continue;
-        uint32_t old[kNSlot];
+      for (int jj = 0; jj < kNSlot; jj++) {
+        const bool own = (ownmask >> jj) & 1u;
+        vals[own ? slot[jj] : kCap + lane] = __float_as_uint(0.0f + e.imp[jj]);
+        lmask |= (bit[jj] != 0u && !own) ? (1u << jj) : 0u;
+      }
+      wave_fence();
+      if (__ballot(lmask != 0u) != 0ull) {
+        for (uint32_t tc = 0; tc < T; tc++) {
+          uint32_t am = 0;
 #pragma unroll
-        for (int jj = 0; jj < kNSlot; jj++) old[jj] = vals[slot[jj]];
+          for (int jj = 0; jj < kNSlot; jj++) am |= (((lmask >> jj) & 1u) && e.t(jj) == tc) ? 1u : 0u;
+          if (__ballot(am != 0u) == 0ull) continue;
+          uint32_t old[kNSlot];
+#pragma unroll
+          for (int jj = 0; jj < kNSlot; jj++) old[jj] = vals[slot[jj]];
+#pragma unroll
+          for (int jj = 0; jj < kNSlot; jj++) {
+            const bool act = ((lmask >> jj) & 1u) && e.t(jj) == tc;
+            vals[act ? slot[jj] : kCap + lane] = __float_as_uint(__uint_as_float(old[jj]) + e.imp[jj]);
+          }
+          wave_fence();
+        }
+      }
+    } else
+    for (uint32_t tc = 0; tc < T; tc++) {
+      if ((ess_mask >> tc) & 1u) {
+        // essential list: its postings sit in the register slots
 #pragma unroll
         for (int jj = 0; jj < kNSlot; jj++) {
-          const bool act = ((lmask >> jj) & 1u) && e.t(jj) == tc;
-          vals[act ? slot[jj] : kCap + lane] = __float_as_uint(__uint_as_float(old[jj]) + e.imp[jj]);
+          if (tc >= tlo[jj] && tc <= thi[jj]) {  // uniform
+            const bool act = bit[jj] != 0u && e.t(jj) == tc;
+            const uint32_t old = vals[slot[jj]];
+            vals[act ? slot[jj] : kCap + lane] = __float_as_uint(__uint_as_float(old) + e.imp[jj]);
+          }
         }
         wave_fence();
+      } else {
+        // non-essential list: stream its postings of this doc window and probe the bitmap
+        SLG_STAMP(4);
+        uint32_t cur = rl(ne_cur, tc);
+        const uint32_t end = rl(ne_end, tc);
+        const uint64_t off = ((uint64_t)rl((uint32_t)(my_off >> 32), tc) << 32) | rl((uint32_t)my_off, tc);
+        const float w = __int_as_float((int)rl((uint32_t)__float_as_int(my_w), tc));
+        const gu32_t ld = gdocs + off;
+        const gf32_t li = gimps + off;
+        // two chunks of 64 postings in flight
+        uint32_t d0 = kDocEnd, d1 = kDocEnd;
+        float i0 = 0.0f, i1 = 0.0f;
+        if (cur + lane < end) {
+          d0 = ld[cur + lane];
+          i0 = li[cur + lane];
+        }
+        if (cur + 64 + lane < end) {
+          d1 = ld[cur + 64 + lane];
+          i1 = li[cur + 64 + lane];
+        }
+        while (cur < end) {
+          uint32_t d2 = kDocEnd;
+          float i2 = 0.0f;
+          if (cur + 128 + lane < end) {
+            d2 = ld[cur + 128 + lane];
+            i2 = li[cur + 128 + lane];
+          }
+          const uint32_t rel = d0 - wbase;
+          const bool have = cur + lane < end;
+          const bool inwin = have && d0 >= wbase && d0 < dend;
+          // postings below dend are finished with (docs before the window exist in no
+          // essential list: pruned); sorted, so they form a prefix of the chunk
+          const uint32_t adv = (uint32_t)__popcll(__ballot(have && d0 < dend));
+          const uint32_t nwi = rel & (kSpanWords - 1);
+          const uint32_t nbit = 1u << ((rel >> 9) & 31);
+          uint32_t nwd = 0;
+          if (inwin) nwd = bm[nwi];
+          const bool hit = inwin && (nwd & nbit) != 0u;
+          if (__ballot(hit) != 0ull) {
+            if (hit) {
+              const uint32_t r = (pre[nwi] + __popc(nwd & (nbit - 1u))) & (kCap - 1);
+              vals[r] = __float_as_uint(__uint_as_float(vals[r]) + i0 * w);
+            }
+            wave_fence();
+          }
+          cur += adv;
+          if (adv < 64u) break;  // the next posting is at or past the window end
+          d0 = d1;
+          i0 = i1;
+          d1 = d2;
+          i1 = i2;
+        }
+        ne_cur = lane == tc ? cur : ne_cur;
+        SLG_STAMP(7);
       }
     }
     wave_fence();
@@ -454,13 +552,17 @@ __global__ void __launch_bounds__(256) score_rounds_kernel(RoundScoreParams p) {
   // a common doc id.  Both paths share ONE accumulate site. ----
   Elems ew, en;
   uint32_t tot_n = 0, lo_n, hi_n;
+  const bool my_ess = lane < T && ((ess_mask >> lane) & 1u);
+  auto ess_cnt = [&](const uint32_t lo, const uint32_t hi) { return my_ess ? hi - lo : 0u; };
   cuts(0, lo_n, hi_n);
-  bool big_n = lane_sum_T(hi_n - lo_n) > (uint32_t)kCap;
-  if (!big_n) issue(en, lo_n, hi_n - lo_n, tot_n);
+  bool big_n = lane_sum_T(ess_cnt(lo_n, hi_n)) > (uint32_t)kCap;
+  if (!big_n) issue(en, lo_n, ess_cnt(lo_n, hi_n), tot_n);
   for (uint32_t rr = 0; rr < n_r; rr++) {
     const bool big = big_n;
     uint32_t ocur = lo_n;
-    const uint32_t oend = hi_n;
+    const uint32_t oend = my_ess ? hi_n : lo_n;  // the streaming path covers essential lists
+    ne_cur = lo_n;                               // non-essential lists: probed per doc window
+    ne_end = my_ess ? lo_n : hi_n;
     uint32_t total = tot_n;
     if (!big) ew = en;
 #ifdef SLG_STAMPS
@@ -469,17 +571,19 @@ __global__ void __launch_bounds__(256) score_rounds_kernel(RoundScoreParams p) {
     SLG_STAMP(6);
     if (rr + 1 < n_r) {  // prefetch the next round
       cuts(rr + 1, lo_n, hi_n);
-      big_n = lane_sum_T(hi_n - lo_n) > (uint32_t)kCap;
-      if (!big_n) issue(en, lo_n, hi_n - lo_n, tot_n);
+      big_n = lane_sum_T(ess_cnt(lo_n, hi_n)) > (uint32_t)kCap;
+      if (!big_n) issue(en, lo_n, ess_cnt(lo_n, hi_n), tot_n);
     }
     uint32_t dlo = rl(dflat, rr), dhi = rl(dflat, rr + 1);
     SLG_STAMP(0);
+    uint32_t guard = 0;
     do {
       uint32_t vmask = 0;
       if (big) {  // next chunk of an over-full round
         const uint32_t rem = oend - ocur;
         const uint32_t R = lane_sum_T(rem);
-        if (R == 0) break;
+        // every chunk consumes >= 1 posting; the bound only guards against a planner bug
+        if (R == 0 || ++guard > (1u << 22)) break;
         uint32_t chunk;
         if (R <= (uint32_t)kCap) {
           chunk = rem;
@@ -532,7 +636,7 @@ __global__ void __launch_bounds__(256) score_rounds_kernel(RoundScoreParams p) {
               vm |= in ? (1u << jj) : 0u;
             }
           }
-          accumulate(ew, vm, wbase);
+          accumulate(ew, vm, wbase, (dhi - wbase) < kSpan ? dhi : wbase + kSpan);
           if (single) break;
           remain &= ~vm;
           uint32_t mn = kDocEnd;

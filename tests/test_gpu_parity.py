@@ -106,12 +106,16 @@ def test_deleted_docs_and_stats(gpu, oracle):
     seg.set_deleted([int(first[0][q, 0]) for q in range(16)] + list(range(0, 1500, 7)))
     want = oracle.search_batch([seg], offs, terms, w, 11, strategy=oracle.BM25, want_stats=True)
     with gpu.GpuIndex([seg]) as ix:
-        got = ix.search_batch(offs, terms, w, 11, want_stats=True)
+        got = ix.search_batch(offs, terms, w, 11, gpu.Bm25, want_stats=True)
+        pruned = ix.search_batch(offs, terms, w, 11, gpu.Wand, want_stats=True)
     assert_same_hits(got[:4], want[:4], 0.0, "deleted")
+    assert_same_hits(pruned[:4], want[:4], 0.0, "deleted, MaxScore")
     for q in range(16):  # brute-force accounting (wand.rs:472,500-503)
         assert got[4][q].postings_advanced == want[4][q].postings_advanced
         assert got[4][q].scored_docs == want[4][q].scored_docs
         assert got[4][q].candidates_examined == want[4][q].candidates_examined
+        # with MaxScore pruning docs found only in non-essential lists are never scored
+        assert pruned[4][q].scored_docs <= want[4][q].scored_docs
 
 
 def test_ragged_and_empty_inputs(gpu, oracle):
@@ -206,8 +210,10 @@ def test_clustered_list_makes_overfull_rounds(gpu, oracle):
     w = np.array([1.0, 0.7, 2.0, 1.0, 1.0, 1.0], dtype=np.float32)
     want = _oracle_batch(oracle, [seg], offs, terms, w, 11)
     with gpu.GpuIndex([seg]) as ix:
-        got = ix.search_batch(offs, terms, w, 11, want_stats=True)
+        got = ix.search_batch(offs, terms, w, 11, gpu.Bm25, want_stats=True)
+        pruned = ix.search_batch(offs, terms, w, 11, gpu.Wand)
     assert_same_hits(got[:4], want[:4], 0.0, "clustered")
+    assert_same_hits(pruned, want[:4], 0.0, "clustered, MaxScore")
     assert got[4][0].scored_docs == len(np.union1d(np.union1d(long_list, clustered), sparse))
 
 
@@ -318,3 +324,29 @@ def test_config2_full_size_properties(gpu, oracle):
     wand = oracle.search_batch([seg], offs[:9], terms[:24], w[:24], 11, strategy=oracle.WAND,
                                cache_min_len=True, n_threads=8)
     assert_same_hits((d[:8], s[:8], sc[:8], c[:8]), wand, 0.0, "config 2 vs oracle WAND")
+
+
+# ---- MaxScore pruning (opt-in): same results as exhaustive scoring -------------------------------
+def test_maxscore_pruning_is_exact(gpu, oracle, monkeypatch):
+    """SLG_MAXSCORE=1: lists whose summed maximum contributions stay below the seed threshold are
+    only probed against the bitmap of the essential lists.  The reference's own standard
+    (tests/pruning.rs:44-104): pruned strategies return what Bm25 returns — here bit for bit."""
+    from searchlite_amd import corpus
+    monkeypatch.setenv("SLG_MAXSCORE", "1")
+    seg = corpus.zipf_segment(200_000, 1 << 16, seed=3)
+    offs, terms, w = corpus.zipf_queries(96, 3, rank_lo=8, rank_hi=4096, seed=5, vocab=1 << 16)
+    w = (np.random.default_rng(1).random(len(w)) * 2 + 0.1).astype(np.float32)
+    want = oracle.search_batch([seg], offs, terms, w, 11, strategy=oracle.BM25, n_threads=8)
+    with gpu.GpuIndex([seg]) as ix:
+        pruned = ix.search_batch(offs, terms, w, 11, gpu.Wand, want_stats=True)
+        full = ix.search_batch(offs, terms, w, 11, gpu.Bm25, want_stats=True)
+    assert_same_hits(pruned[:4], want, 0.0, "maxscore")
+    assert_same_hits(full[:4], want, 0.0, "exhaustive")
+    ps = sum(pruned[4][q].scored_docs for q in range(96))
+    fs = sum(full[4][q].scored_docs for q in range(96))
+    assert ps < fs  # some docs were never scored
+    # 5 terms, top-30
+    offs, terms, w = corpus.zipf_queries(32, 5, rank_lo=8, rank_hi=4096, seed=6, vocab=1 << 16)
+    want = oracle.search_batch([seg], offs, terms, w, 31, strategy=oracle.BM25, n_threads=8)
+    with gpu.GpuIndex([seg]) as ix:
+        assert_same_hits(ix.search_batch(offs, terms, w, 31, gpu.Bmw), want, 0.0, "maxscore T=5")

@@ -11,7 +11,7 @@ if len(sys.argv) > 1:
 seg = corpus.zipf_segment(1_000_000, 1 << 18, seed=42)
 offs, terms, w = corpus.zipf_queries(1024, 3, seed=7, vocab=1 << 18)
 ix = searcher.GpuIndex([seg])
-b = ix.prepare(offs, terms, w, 11)
+b = ix.prepare(offs, terms, w, 11, int(os.environ.get("STRATEGY", "1")))
 for _ in range(3):
     b.run()
 b.sync()
@@ -23,7 +23,7 @@ L.slg_debug_read_stamps.restype = C.c_int
 L.slg_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 assert L.slg_debug_read_stamps(b._h, out.ctypes.data, n) == 0
 names = ["0 plan/issue next", "1 window setup", "2 P0+P1 clear+or", "3 P2 scan", "4 P3 rmw",
-         "5 P4 read+topk", "6 wait loads+copy", "7 tail"]
+         "5 P4 read+topk", "6 wait loads+copy", "7 probe (non-essential)"]
 tot = out.sum()
 print("slices", n, "postings", info["n_postings"], "mean cycles/slice", tot / n)
 for i, nm in enumerate(names):
