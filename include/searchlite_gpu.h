@@ -125,9 +125,11 @@ void slg_index_destroy(slg_index *index);
 int slg_index_info(const slg_index *index, uint32_t *n_segs, uint64_t *n_postings,
                    uint64_t *device_bytes);
 
-/* Use an external HIP stream (hipStream_t) for all work of this index, e.g. the
- * current PyTorch stream so RCCL collectives order after the kernels.  NULL restores
- * the index's own stream. */
+/* Use an external HIP stream (hipStream_t) for all work of this index, e.g. the current
+ * PyTorch stream so RCCL collectives order after the kernels.  NULL is a valid handle (the
+ * HIP null stream, which is what PyTorch's default stream is); SLG_OWN_STREAM restores the
+ * index's own non-blocking stream. */
+#define SLG_OWN_STREAM ((void *)(intptr_t)-1)
 int slg_index_set_stream(slg_index *index, void *hip_stream);
 
 /* ---- one-shot search (what a searchlite `gpu` shim calls) -------------------------- */

@@ -487,7 +487,7 @@ int slg_index_set_stream(slg_index *ix, void *hip_stream) {
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
     SLG_HIP(hipStreamSynchronize(ix->stream));
-    ix->stream = hip_stream ? (hipStream_t)hip_stream : ix->own_stream;
+    ix->stream = hip_stream == SLG_OWN_STREAM ? ix->own_stream : (hipStream_t)hip_stream;
   });
 }
 

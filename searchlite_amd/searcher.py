@@ -81,9 +81,11 @@ class GpuIndex:
                                          C.addressof(nbytes)))
         return {"n_segs": ns.value, "n_postings": npost.value, "device_bytes": nbytes.value}
 
-    def set_stream(self, hip_stream: int) -> None:
-        """Run on an external hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
-        N.check(self._lib.slg_index_set_stream(self._h, C.c_void_p(hip_stream or None)))
+    def set_stream(self, hip_stream) -> None:
+        """Run on an external hipStream_t (e.g. torch.cuda.current_stream().cuda_stream; 0 is the
+        HIP null stream = PyTorch's default stream).  None restores the index's own stream."""
+        h = C.c_void_p(-1) if hip_stream is None else C.c_void_p(int(hip_stream) or None)
+        N.check(self._lib.slg_index_set_stream(self._h, h))
 
     def profile(self, on: bool) -> None:
         N.check(self._lib.slg_profile_enable(self._h, int(on)))
