@@ -563,7 +563,7 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
         // their maximum contribution ub_t = w_t * champ[t][0] are non-essential while the running
         // sum of ub stays below theta0: a doc found only in them totals < theta0.
         uint32_t ess_mask = sq.n_terms >= 32 ? 0xFFFFFFFFu : ((1u << sq.n_terms) - 1u);
-        if (strategy != SLG_STRATEGY_BM25 && !sh.champ.empty() && k <= (uint32_t)slg::kChampions &&
+        if (strategy != SLG_STRATEGY_BM25 && !sh.champ.empty() && k >= 1 && k <= 1024u &&
             sq.n_terms > 1 && env_u32("SLG_MAXSCORE", 0) != 0) {
           bool ok = true;
           float theta0 = 0.0f;
@@ -572,7 +572,7 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
             const slg::TermRef &tr = terms[sq.term_begin + i];
             if (!(tr.weight >= 0.0f)) ok = false;
             const float *c = &sh.champ[(size_t)tr.term * slg::kChampions];
-            theta0 = std::max(theta0, tr.weight * c[k - 1]);
+            theta0 = std::max(theta0, tr.weight * c[slg::champ_index(k)]);
             ub[i] = {tr.weight * c[0], i};
           }
           if (ok && theta0 > 0.0f) {

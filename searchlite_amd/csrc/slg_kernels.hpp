@@ -21,7 +21,12 @@ constexpr int32_t kSentinelTk = INT32_MIN;
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 constexpr uint32_t kMaxTerms = 32;
-constexpr int kChampions = 64;  // per-term impact lower bounds kept at staging time
+constexpr int kChampSorted = 64;  // exact-rank lower bounds (sorted lane maxima)
+constexpr int kChampions = 68;    // + bounds for ranks 128, 256, 512, 1024
+// index of the champion entry that bounds the k-th largest impact of a term from below
+__host__ __device__ inline int champ_index(uint32_t k) {
+  return k <= 64 ? (int)k - 1 : k <= 128 ? 64 : k <= 256 ? 65 : k <= 512 ? 66 : 67;
+}
 
 // ---- device-side descriptors (built on the host per batch) ---------------------------
 struct SegDev {
@@ -257,11 +262,13 @@ static __global__ void __launch_bounds__(256) stage_impacts_kernel(StageParams p
 }
 
 // ---- staging: per-term champion impacts ------------------------------------------------------
-// champ[t][r] (r = 0..63, descending) is a value v such that at least r+1 postings of term t
-// have impact >= v (0 where the list is shorter).  Lane l keeps the maximum of postings
-// l, l+64, ...; the 64 lane maxima are sorted descending.  Not the exact order statistics of
-// the list, but a valid lower bound for every rank, which is all the threshold seed needs:
-// a doc's total score is >= any one of its (non-negative) per-term contributions.
+// champ[t][r], r = 0..63 (descending): a value v such that at least r+1 postings of term t have
+// impact >= v (0 where the list is shorter).  Lane l scans postings l, l+64, ... and keeps its 16
+// largest; the 64 lane maxima, sorted, give ranks 1..64.  champ[t][64..67] bound ranks 128, 256,
+// 512, 1024: every lane holds j values >= its own j-th largest, so all lanes together hold 64*j
+// values >= the minimum over lanes of the j-th largest (j = 2, 4, 8, 16).  Not the exact order
+// statistics, but valid lower bounds, which is all the threshold seed needs: a doc's total
+// score is >= any one of its (non-negative) per-term contributions.
 struct ChampParams {
   const uint64_t *term_offsets;  // [V+1]
   const float *imps;             // [P]
@@ -275,19 +282,38 @@ static __global__ void __launch_bounds__(256) stage_champions_kernel(ChampParams
   const uint32_t n_waves = gridDim.x * kWavesPerBlock;
   for (uint32_t t = wave; t < p.n_terms; t += n_waves) {
     const uint64_t a = p.term_offsets[t], b = p.term_offsets[t + 1];
-    float m = 0.0f;
-    for (uint64_t i = a + lane; i < b; i += 64) m = fmaxf(m, p.imps[i]);
+    float m[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) m[r] = 0.0f;
+    for (uint64_t i0 = a; i0 < b; i0 += 64) {
+      const uint64_t i = i0 + lane;
+      const float x = i < b ? p.imps[i] : 0.0f;
+      if (__ballot(x > m[15]) == 0ull) continue;  // nobody improves: the common case
+#pragma unroll
+      for (int r = 15; r >= 1; r--) m[r] = x > m[r - 1] ? m[r - 1] : (x > m[r] ? x : m[r]);
+      m[0] = x > m[0] ? x : m[0];
+    }
+    // bounds for ranks 128 .. 1024
+    float lo[4] = {m[1], m[3], m[7], m[15]};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) lo[j] = fminf(lo[j], __shfl_xor(lo[j], o, 64));
+    }
     // bitonic sort of the 64 lane maxima, descending (lane 0 = largest)
+    float v = m[0];
 #pragma unroll
     for (int size = 2; size <= 64; size <<= 1) {
 #pragma unroll
       for (int d = size >> 1; d > 0; d >>= 1) {
-        const float o = __shfl_xor(m, d, 64);
+        const float o = __shfl_xor(v, d, 64);
         const bool up = ((lane & size) == 0) == ((lane & d) == 0);  // keep the larger one
-        m = up ? fmaxf(m, o) : fminf(m, o);
+        v = up ? fmaxf(v, o) : fminf(v, o);
       }
     }
-    p.champ[(size_t)t * kChampions + lane] = m;
+    float *row = p.champ + (size_t)t * kChampions;
+    row[lane] = v;
+    if (lane < 4) row[kChampSorted + lane] = lane == 0 ? lo[0] : lane == 1 ? lo[1] : lane == 2 ? lo[2] : lo[3];
   }
 }
 

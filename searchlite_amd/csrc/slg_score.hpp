@@ -234,11 +234,11 @@ __global__ void __launch_bounds__(256) score_rounds_kernel(RoundScoreParams p) {
 
   WaveTopK<KREGS, false> top;
   top.init();
-  if (sd.champ != nullptr && k <= (uint32_t)kChampions) {
+  if (sd.champ != nullptr && k <= 1024u) {
     // threshold seed: >= k postings of term t have impact >= champ[t][k-1], and a doc's total
     // is >= any single (non-negative) contribution, so >= k docs score >= w_t * champ[t][k-1]
     float f = 0.0f;
-    if (lane < T && my_w > 0.0f) f = my_w * ((const gf32_t)sd.champ)[(size_t)my_term * kChampions + (k - 1)];
+    if (lane < T && my_w > 0.0f) f = my_w * ((const gf32_t)sd.champ)[(size_t)my_term * kChampions + champ_index(k)];
     float best = 0.0f;
     for (uint32_t t = 0; t < T; t++) best = fmaxf(best, __int_as_float((int)rl((uint32_t)__float_as_int(f), t)));
     // a negative weight would break "total >= single contribution": no seed then
