@@ -18,7 +18,7 @@ LIBDIR = os.path.join(_HERE, "lib")
 GPU_LIB = os.path.join(LIBDIR, "libsearchlite_gpu.so")
 CORPUS_LIB = os.path.join(LIBDIR, "libslg_corpus.so")
 
-GPU_SOURCES = ["slg_api.hip", "slg_score_inst.hip", "slg_kernels.hpp", "slg_rerank.hpp", "slg_score.hpp"]
+GPU_SOURCES = ["slg_api.hip", "slg_score_inst.hip", "slg_kernels.hpp", "slg_rerank.hpp", "slg_score.hpp", "slg_score_uni.hpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off",  # f32 ops rounded one by one, as the Rust reference does
                "-Wall", "-Wno-unused-function"]
@@ -49,7 +49,7 @@ def build_gpu(force: bool = False, verbose: bool = False, stamps: bool = False) 
     objdir = os.path.join(LIBDIR, "obj_stamps" if stamps else "obj")
     out_lib = os.path.join(LIBDIR, "libsearchlite_gpu_stamps.so") if stamps else GPU_LIB
     os.makedirs(objdir, exist_ok=True)
-    hdrs = [os.path.join(CSRC, h) for h in ("slg_kernels.hpp", "slg_rerank.hpp", "slg_score.hpp")]
+    hdrs = [os.path.join(CSRC, h) for h in ("slg_kernels.hpp", "slg_rerank.hpp", "slg_score.hpp", "slg_score_uni.hpp")]
     hdrs.append(os.path.join(_HERE, "..", "include", "searchlite_gpu.h"))
     compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"] + (["-DSLG_STAMPS"] if stamps else [])
     kregs = (1,) if stamps else SCORE_KREGS

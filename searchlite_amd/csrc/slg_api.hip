@@ -24,6 +24,7 @@
 #include "slg_kernels.hpp"
 #include "slg_rerank.hpp"
 #include "slg_score.hpp"
+#include "slg_score_uni.hpp"
 
 namespace {
 
@@ -133,6 +134,7 @@ struct slg_batch {
   uint32_t nq = 0, k = 0;
   int strategy = 0;
   uint32_t n_sq = 0, n_slices = 0, n_terms = 0, n_boundaries = 0, max_terms = 0;
+  bool uniform = false;  // every sub-query fits the one-list-per-slot kernel
   uint64_t n_postings = 0, n_postings_essential = 0, n_rounds = 0;
   std::vector<uint64_t> q_postings;  // per query (stats.postings_advanced)
   DevBuf d_desc;                     // packed descriptors
@@ -172,28 +174,28 @@ int kregs_for(uint32_t k) {
 namespace slg {
 // defined in slg_score_inst.hip, one translation unit per KREGS
 template <int KREGS>
-void launch_score_kregs(const RoundScoreParams &sp, uint32_t max_terms, hipStream_t st);
-template <> void launch_score_kregs<1>(const RoundScoreParams &, uint32_t, hipStream_t);
-template <> void launch_score_kregs<2>(const RoundScoreParams &, uint32_t, hipStream_t);
-template <> void launch_score_kregs<4>(const RoundScoreParams &, uint32_t, hipStream_t);
-template <> void launch_score_kregs<8>(const RoundScoreParams &, uint32_t, hipStream_t);
-template <> void launch_score_kregs<16>(const RoundScoreParams &, uint32_t, hipStream_t);
+void launch_score_kregs(const RoundScoreParams &sp, uint32_t max_terms, bool uniform, hipStream_t st);
+template <> void launch_score_kregs<1>(const RoundScoreParams &, uint32_t, bool, hipStream_t);
+template <> void launch_score_kregs<2>(const RoundScoreParams &, uint32_t, bool, hipStream_t);
+template <> void launch_score_kregs<4>(const RoundScoreParams &, uint32_t, bool, hipStream_t);
+template <> void launch_score_kregs<8>(const RoundScoreParams &, uint32_t, bool, hipStream_t);
+template <> void launch_score_kregs<16>(const RoundScoreParams &, uint32_t, bool, hipStream_t);
 }  // namespace slg
 namespace {
 
-void launch_score(const slg::RoundScoreParams &sp, uint32_t max_terms, hipStream_t st) {
+void launch_score(const slg::RoundScoreParams &sp, uint32_t max_terms, bool uniform, hipStream_t st) {
 #ifdef SLG_STAMPS  // diagnostic build: only the k <= 64 variant is compiled
   if (kregs_for(sp.k) != 1) throw SlgError(SLG_ERR_UNSUPPORTED, "stamps build supports k <= 64 only");
-  slg::launch_score_kregs<1>(sp, max_terms, st);
+  slg::launch_score_kregs<1>(sp, max_terms, uniform, st);
   SLG_HIP(hipGetLastError());
   return;
 #else
   switch (kregs_for(sp.k)) {
-    case 1: slg::launch_score_kregs<1>(sp, max_terms, st); break;
-    case 2: slg::launch_score_kregs<2>(sp, max_terms, st); break;
-    case 4: slg::launch_score_kregs<4>(sp, max_terms, st); break;
-    case 8: slg::launch_score_kregs<8>(sp, max_terms, st); break;
-    default: slg::launch_score_kregs<16>(sp, max_terms, st); break;
+    case 1: slg::launch_score_kregs<1>(sp, max_terms, uniform, st); break;
+    case 2: slg::launch_score_kregs<2>(sp, max_terms, uniform, st); break;
+    case 4: slg::launch_score_kregs<4>(sp, max_terms, uniform, st); break;
+    case 8: slg::launch_score_kregs<8>(sp, max_terms, uniform, st); break;
+    default: slg::launch_score_kregs<16>(sp, max_terms, uniform, st); break;
   }
   SLG_HIP(hipGetLastError());
 #endif
@@ -617,16 +619,32 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
     q_sq_begin[nq] = (uint32_t)sqs.size();
 
     // ---- pass 2: rounds of ~kRoundTarget postings, slices of consecutive rounds ----
-    const uint32_t round_target = std::max<uint32_t>(64, std::min<uint32_t>(
+    const uint32_t round_target_packed = std::max<uint32_t>(64, std::min<uint32_t>(
         env_u32("SLG_ROUND_TARGET", slg::kRoundTarget), slg::kCap));
-    const uint32_t probe_target = std::max<uint32_t>(round_target, env_u32("SLG_PROBE_TARGET", 2048));
+    const uint32_t probe_target = std::max<uint32_t>(round_target_packed, env_u32("SLG_PROBE_TARGET", 2048));
     const uint32_t max_rps = std::max<uint32_t>(1, std::min<uint32_t>(
         env_u32("SLG_ROUNDS_PER_SLICE", slg::kDefaultRoundsPerSlice), slg::kMaxRoundsPerSlice));
     std::vector<uint32_t> slice_sq, slice_seg, bnd_sq;
     uint64_t n_bounds = 0, n_bnd = 0;
+    // one-list-per-slot kernel (slg_score_uni.hpp): few terms, no non-essential lists
+    const uint32_t uni_max_terms = std::min<uint32_t>(env_u32("SLG_UNIFORM_MAX_TERMS", 5), slg::kUniSlots);
+    b->uniform = env_u32("SLG_NO_UNIFORM", 0) == 0 && b->max_terms <= uni_max_terms;
+    for (size_t i = 0; i < sqs.size() && b->uniform; i++) {
+      const uint32_t full = sqs[i].n_terms >= 32 ? 0xFFFFFFFFu : ((1u << sqs[i].n_terms) - 1u);
+      if (sqs[i].ess_mask != full) b->uniform = false;
+    }
     for (size_t i = 0; i < sqs.size(); i++) {
       slg::RoundQuery &sq = sqs[i];
       const uint32_t dfL = terms[sq.term_begin + sq.longest].df;
+      uint32_t round_target = round_target_packed;
+      if (b->uniform) {
+        // every list is padded to a 64-lane slot (half a slot wasted per list on average): aim
+        // at (slots - terms + 1) slots of postings; measured optimum on config 2 (384 for 3 terms)
+        const uint32_t t = sq.n_terms;
+        const uint32_t dflt = 64u * (slg::kUniSlots > t ? slg::kUniSlots - t : 0u) + 64u;
+        round_target = std::max<uint32_t>(48, std::min<uint32_t>(
+            env_u32("SLG_UNIFORM_ROUND_TARGET", dflt), slg::kUniCap));
+      }
       // a round holds <= ~round_target postings of the essential lists (register slots) and
       // <= ~probe_target postings overall (non-essential lists are streamed per round), so
       // slices stay balanced whatever the mix
@@ -773,7 +791,7 @@ int slg_batch_run(slg_batch *b) {
         ev = &ix->prof_events[ix->prof_used++];
         SLG_HIP(hipEventRecord(ev->first, st));
       }
-      launch_score(sp, b->max_terms, st);
+      launch_score(sp, b->max_terms, b->uniform, st);
       if (ev) SLG_HIP(hipEventRecord(ev->second, st));
     }
     if (b->k > 0) {

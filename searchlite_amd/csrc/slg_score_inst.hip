@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "slg_score.hpp"
+#include "slg_score_uni.hpp"
 
 #ifndef SLG_INST_KREGS
 #error "compile with -DSLG_INST_KREGS={1,2,4,8,16}"
@@ -19,11 +20,17 @@ static void launch_tt(const RoundScoreParams &sp, hipStream_t st) {
 }
 
 template <int KREGS>
-void launch_score_kregs(const RoundScoreParams &sp, uint32_t max_terms, hipStream_t st);
+void launch_score_kregs(const RoundScoreParams &sp, uint32_t max_terms, bool uniform, hipStream_t st);
 
 template <>
 void launch_score_kregs<SLG_INST_KREGS>(const RoundScoreParams &sp, uint32_t max_terms,
-                                        hipStream_t st) {
+                                        bool uniform, hipStream_t st) {
+  if (uniform) {  // one list per register slot (slg_score_uni.hpp)
+    const uint32_t blocks = (sp.n_slices + kWavesPerBlock - 1) / kWavesPerBlock;
+    const size_t lds = (size_t)kWavesPerBlock * kUniWaveLds;
+    hipLaunchKernelGGL((score_uniform_kernel<SLG_INST_KREGS>), dim3(blocks), dim3(256), lds, st, sp);
+    return;
+  }
   if (max_terms <= 4)
     launch_tt<SLG_INST_KREGS, 4>(sp, st);
   else if (max_terms <= 8)

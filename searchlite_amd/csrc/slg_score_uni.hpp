@@ -1,0 +1,346 @@
+// slg_score_uni.hpp — the hot kernel for queries with <= kUniSlots terms (every benchmark
+// configuration): same algorithm as slg_score.hpp (exact pre-planned rounds, LDS bitmap-rank
+// accumulate, register top-k), but every 64-lane register slot holds postings of ONE list.
+//
+// Padding each list to a slot boundary makes the per-slot list id, weight, base address and
+// lane count wave-uniform scalars (one v_readlane each from a lane-held slot descriptor),
+// removes the per-lane list selects and the mixed-slot ordering paths of the packed kernel,
+// and lets the posting loads use scalar-base addressing.  Measured on config 2 it issues
+// ~2.5x fewer vector instructions per round than the packed layout.
+//
+// Restates query/wand.rs:459-566 (every posting scored, per-doc sums in ScorePlan leaf order,
+// planner.rs:122-135) and push_top_k (wand.rs:905-916); see slg_score.hpp for the phase-by-
+// phase description and DESIGN.md section 4.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "slg_score.hpp"
+
+namespace slg {
+
+constexpr int kUniSlots = 8;                 // 64-posting slots per round; also max lists
+constexpr int kUniCap = kUniSlots * 64;
+constexpr int kUniWaveLds = kSpanWords * 4 + kSpanWords * 4 + kUniCap * 4 + 64 * 4;
+
+template <int KREGS>
+__global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams p) {
+  constexpr int NS = kUniSlots;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wib = threadIdx.x >> 6;
+  const uint32_t slice = rfl(blockIdx.x * kWavesPerBlock + wib);
+  if (slice >= p.n_slices) return;  // waves are independent: no workgroup barrier anywhere
+
+  uint32_t *bm = reinterpret_cast<uint32_t *>(smem + (size_t)wib * kUniWaveLds);
+  uint32_t *pre = bm + kSpanWords;
+  uint32_t *vals = pre + kSpanWords;
+  uint4 *bm4 = reinterpret_cast<uint4 *>(bm);
+  uint4 *pre4 = reinterpret_cast<uint4 *>(pre);
+
+  const uint32_t sqi = rfl(p.slice_sq[slice]);
+  const RoundQuery s = p.sq[sqi];
+  const uint32_t T = rfl(s.n_terms);
+  const uint32_t rps = rfl(s.rounds_per_slice);
+  const uint32_t r0 = (slice - rfl(s.slice_begin)) * rps;
+  const uint32_t r_end = rfl(s.n_rounds) < r0 + rps ? rfl(s.n_rounds) : r0 + rps;
+  const uint32_t n_r = r_end - r0;
+  const SegDev sd = p.segs[s.seg];
+  const gu32_t gdocs = (gu32_t)sd.docs;
+  const gf32_t gimps = (gf32_t)sd.imps;
+  const gu32_t gdel = (gu32_t)sd.deleted;
+  const uint32_t k = p.k;
+
+  // lane t < T: list t's posting offset, weight, term id
+  uint64_t my_off = 0;
+  float my_w = 0.0f;
+  uint32_t my_term = 0;
+  if (lane < T) {
+    const TermRef tr = p.terms[s.term_begin + lane];
+    my_off = tr.off;
+    my_w = tr.weight;
+    my_term = tr.term;
+  }
+  // all cut points of the slice in one register (lane i: bounds[r0*T + i]); round doc starts
+  const uint32_t bflat = lane < (n_r + 1) * T ? p.bounds[s.bounds_begin + r0 * T + lane] : 0u;
+  const uint32_t dflat = lane <= n_r ? p.rdoc[s.rdoc_begin + r0 + lane] : 0u;
+
+  WaveTopK<KREGS, false> top;
+  top.init();
+  if (sd.champ != nullptr && k <= 1024u) {  // threshold seed (see slg_score.hpp)
+    float f = 0.0f;
+    if (lane < T && my_w > 0.0f)
+      f = my_w * ((const gf32_t)sd.champ)[(size_t)my_term * kChampions + champ_index(k)];
+    float best = 0.0f;
+    for (uint32_t t = 0; t < T; t++)
+      best = fmaxf(best, __int_as_float((int)rl((uint32_t)__float_as_int(f), t)));
+    const bool anyneg = __ballot(lane < T && !(my_w >= 0.0f)) != 0ull;
+    if (best > 0.0f && !anyneg) top.set_floor(best);
+  }
+  uint32_t n_scored = 0;
+
+  // One round's postings: slot jj holds <= 64 postings of one list.  The slot descriptors
+  // live across lanes: lane jj of st / scnt / sb_lo / sb_hi describes slot jj.
+  struct URound {
+    uint32_t doc[NS];
+    float imp[NS];
+    uint32_t st, scnt, sb_lo, sb_hi;
+    uint32_t nslots;  // uniform: slots needed (> NS: does not fit)
+  };
+
+  // ---- slot descriptors for per-list ranges [lo, lo+cnt) (lane t holds list t's values) ----
+  auto describe = [&](URound &r, const uint32_t lo, const uint32_t cnt) {
+    const uint32_t m = (cnt + 63u) >> 6;  // slots of my list
+    uint32_t ss = 0, run = 0;             // ss: first slot of my list
+    for (uint32_t t = 0; t < T; t++) {
+      ss = lane == t ? run : ss;
+      run += rl(m, t);
+    }
+    r.nslots = run;
+    // lane j: which list owns slot j = the last list whose first slot is <= j
+    uint32_t tj = 0;
+    for (uint32_t t = 1; t < T; t++) tj = lane >= rl(ss, t) ? t : tj;
+    const uint32_t l_ss = __shfl(ss, (int)tj, 64), l_cnt = __shfl(cnt, (int)tj, 64);
+    const uint64_t l_abs = (((uint64_t)__shfl((uint32_t)(my_off >> 32), (int)tj, 64) << 32) |
+                            __shfl((uint32_t)my_off, (int)tj, 64)) +
+                           __shfl(lo, (int)tj, 64);
+    const uint32_t kin = (lane - l_ss) * 64u;  // postings of the list before this slot
+    const bool used = lane < run && lane < (uint32_t)NS;
+    const uint32_t left = used && l_cnt > kin ? l_cnt - kin : 0u;
+    r.st = tj;
+    r.scnt = left < 64u ? left : 64u;
+    const uint64_t base = l_abs + kin;
+    r.sb_lo = (uint32_t)base;
+    r.sb_hi = (uint32_t)(base >> 32);
+  };
+
+  // ---- issue the loads of a described round ----
+  auto issue = [&](URound &r) {
+#pragma unroll
+    for (int jj = 0; jj < NS; jj++) {
+      const uint32_t c = rl(r.scnt, jj);
+      const uint64_t base = ((uint64_t)rl(r.sb_hi, jj) << 32) | rl(r.sb_lo, jj);
+      r.doc[jj] = kDocEnd;  // idle lanes: never inside any doc window
+      r.imp[jj] = 0.0f;
+      if (lane < c) {
+        r.doc[jj] = gdocs[base + lane];
+        r.imp[jj] = gimps[base + lane];
+      }
+    }
+  };
+
+  // ---- accumulate the postings of `e` whose docs lie in [wbase, wbase + wspan) ----
+  auto accumulate = [&](URound &e, const uint32_t wbase, const uint32_t wspan) {
+    // P0: clear the bitmap
+    bm4[lane] = make_uint4(0u, 0u, 0u, 0u);
+    bm4[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
+    wave_fence();
+    // P1: one bit per posting (transposed bitmap: doc d -> word d mod 512, bit d / 512); the
+    // returned old word tells which posting of a doc came first = the owner.  Slots are in
+    // list order and a slot holds one list, so the owner is the first list in term order.
+    uint32_t wi[NS], bit[NS], ownmask = 0;
+    {
+      uint32_t oldw[NS];
+#pragma unroll
+      for (int jj = 0; jj < NS; jj++) {
+        const uint32_t rel = e.doc[jj] - wbase;
+        wi[jj] = rel & (kSpanWords - 1);
+        bit[jj] = rel < wspan ? 1u << (rel >> 9) : 0u;  // rel < 16384 => rel >> 9 < 32
+        oldw[jj] = atomicOr(&bm[wi[jj]], bit[jj]);
+      }
+#pragma unroll
+      for (int jj = 0; jj < NS; jj++)
+        ownmask |= (bit[jj] & ~oldw[jj]) != 0u ? (1u << jj) : 0u;
+    }
+    wave_fence();
+    // P2: exclusive prefix popcount (lane l owns words 4l..4l+3 and 256+4l..256+4l+3)
+    {
+      const uint4 a = bm4[lane], b = bm4[lane + 64];
+      const uint32_t c0 = __popc(a.x), c1 = c0 + __popc(a.y), c2 = c1 + __popc(a.z),
+                     c3 = c2 + __popc(a.w), c4 = c3 + __popc(b.x), c5 = c4 + __popc(b.y),
+                     c6 = c5 + __popc(b.z), c7 = c6 + __popc(b.w);
+      const uint32_t incl = wave_incl_scan(c7);
+      const uint32_t ex = incl - c7;
+      pre4[lane] = make_uint4(ex, ex + c0, ex + c1, ex + c2);
+      pre4[lane + 64] = make_uint4(ex + c3, ex + c4, ex + c5, ex + c6);
+      n_scored += rl(incl, 63);
+    }
+    wave_fence();
+    // P3a: rank(doc) = accumulator slot; x = impact * weight (score_tf, query/wand.rs:285, the
+    // slot's list weight is a scalar); owners store 0.0 + x (`or_insert(0.0) += score`, :539)
+    uint32_t slot[NS];
+    {
+      uint32_t wd[NS], pf[NS];
+#pragma unroll
+      for (int jj = 0; jj < NS; jj++) {
+        wd[jj] = bm[wi[jj]];
+        pf[jj] = pre[wi[jj]];
+      }
+#pragma unroll
+      for (int jj = 0; jj < NS; jj++) {
+        const float w = __int_as_float((int)rl((uint32_t)__float_as_int(my_w), rl(e.st, jj)));
+        slot[jj] = (pf[jj] + __popc(wd[jj] & (bit[jj] - 1u))) & (kUniCap - 1);
+        if (bit[jj] != 0u) e.imp[jj] = e.imp[jj] * w;  // each posting is valid in one window
+        const bool own = (ownmask >> jj) & 1u;
+        vals[own ? slot[jj] : kUniCap + lane] = __float_as_uint(0.0f + e.imp[jj]);
+      }
+    }
+    wave_fence();
+    // P3b: later postings of a doc (it was first seen in an earlier list = an earlier slot)
+    // add to the owner's value, slot by slot: a wave's LDS operations execute in program
+    // order and slots are in list order, so the sum is ((0.0 + x_a) + x_b) + ... in term order.
+#pragma unroll
+    for (int jj = 1; jj < NS; jj++) {
+      const bool later = bit[jj] != 0u && !((ownmask >> jj) & 1u);
+      if (__ballot(later) != 0ull) {
+        const uint32_t old = vals[slot[jj]];
+        vals[later ? slot[jj] : kUniCap + lane] = __float_as_uint(__uint_as_float(old) + e.imp[jj]);
+        wave_fence();
+      }
+    }
+    wave_fence();
+    // P4: owners read the finished sums and offer them to the top-k
+    int32_t ctk[NS];
+    uint32_t passmask = 0;
+    {
+      uint32_t v[NS];
+#pragma unroll
+      for (int jj = 0; jj < NS; jj++) v[jj] = vals[slot[jj]];
+#pragma unroll
+      for (int jj = 0; jj < NS; jj++) {
+        const bool own = (ownmask >> jj) & 1u;
+        ctk[jj] = own ? total_key(__uint_as_float(v[jj])) : kSentinelTk;
+        passmask |= (own && top.passes(ctk[jj], 0u, e.doc[jj])) ? (1u << jj) : 0u;
+      }
+    }
+    if (__ballot(passmask != 0u) != 0ull) {
+#pragma unroll
+      for (int jj = 0; jj < NS; jj++) {
+        uint64_t m = __ballot(((passmask >> jj) & 1u) && top.passes(ctk[jj], 0u, e.doc[jj]));
+        while (m) {
+          const uint32_t l = (uint32_t)__builtin_ctzll(m);
+          const int32_t c_tk = (int32_t)rl((uint32_t)ctk[jj], l);
+          const uint32_t c_doc = rl(e.doc[jj], l);
+          if (!(gdel && ((gdel[c_doc >> 5] >> (c_doc & 31)) & 1u)))  // accept()
+            top.insert(c_tk, 0u, c_doc, k, lane);
+          m &= m - 1;
+          m &= __ballot(top.passes(ctk[jj], 0u, e.doc[jj]));
+        }
+      }
+    }
+    wave_fence();
+  };
+
+  // ---- all doc windows of the loaded postings with docs in [dlo, dhi) ----
+  auto windows = [&](URound &e, const uint32_t dlo, const uint32_t dhi) {
+    uint32_t wbase = dlo & ~31u;
+    if (dhi - wbase <= kSpan) {  // the common case: one window
+      accumulate(e, wbase, dhi - wbase);
+      return;
+    }
+    for (;;) {
+      const uint32_t wend = (dhi - wbase) < kSpan ? dhi : wbase + kSpan;
+      accumulate(e, wbase, wend - wbase);
+      // next window starts at the smallest doc not yet covered
+      uint32_t mn = kDocEnd;
+#pragma unroll
+      for (int jj = 0; jj < NS; jj++) mn = (e.doc[jj] >= wend && e.doc[jj] < mn) ? e.doc[jj] : mn;
+      mn = wave_min(mn);
+      if (mn >= dhi) break;
+      wbase = mn & ~31u;
+    }
+  };
+
+  // lane t < T: cut points of round rr and rr + 1 of this slice
+  auto cuts = [&](const uint32_t rr, uint32_t &lo, uint32_t &hi) {
+    const uint32_t src = rr * T + lane;
+    const uint32_t a = __shfl(bflat, src & 63, 64), b = __shfl(bflat, (src + T) & 63, 64);
+    lo = lane < T ? a : 0u;
+    hi = lane < T ? b : 0u;
+  };
+  auto lane_sum_T = [&](const uint32_t v) {
+    uint32_t R = 0;
+    for (uint32_t t = 0; t < T; t++) R += rl(v, t);
+    return R;
+  };
+
+  // ---- driver: planned rounds are prefetched one ahead (`en` loads while `ew` is processed);
+  //      a round that needs more than NS slots is streamed in chunks cut at a common doc id ----
+  URound ew, en;
+  uint32_t lo_n, hi_n;
+  cuts(0, lo_n, hi_n);
+  describe(en, lo_n, hi_n - lo_n);
+  if (en.nslots <= (uint32_t)NS) issue(en);
+  for (uint32_t rr = 0; rr < n_r; rr++) {
+    const bool big = en.nslots > (uint32_t)NS;
+    uint32_t ocur = lo_n;
+    const uint32_t oend = hi_n;
+    if (!big) ew = en;
+    if (rr + 1 < n_r) {  // prefetch the next round
+      cuts(rr + 1, lo_n, hi_n);
+      describe(en, lo_n, hi_n - lo_n);
+      if (en.nslots <= (uint32_t)NS) issue(en);
+    }
+    const uint32_t dlo = rl(dflat, rr), dhi = rl(dflat, rr + 1);
+    if (p.dbg & 4u) continue;
+    if (!big) {
+      if (ew.nslots != 0) windows(ew, dlo, dhi);
+      continue;
+    }
+    // ---- over-full round: chunks of <= NS slots; each list gets >= 1 slot, the rest in
+    //      proportion to what it has left; the chunk is cut at the smallest "last loaded doc"
+    //      of the lists that did not finish ----
+    uint32_t guard = 0;
+    for (;;) {
+      const uint32_t rem = oend - ocur;
+      const uint32_t nne = (uint32_t)__popcll(__ballot(rem != 0u));
+      const uint32_t R = lane_sum_T(rem);
+      if (R == 0 || ++guard > (1u << 22)) break;
+      const uint32_t need = lane_sum_T((rem + 63u) >> 6);
+      uint32_t chunk = rem;
+      if (need > (uint32_t)NS) {
+        const float share = (float)(NS - nne) * ((float)rem / (float)R);
+        const uint32_t mslots = rem == 0u ? 0u : 1u + (uint32_t)share;
+        chunk = rem < mslots * 64u ? rem : mslots * 64u;
+      }
+      uint32_t lastdoc = kDocEnd, firstdoc = kDocEnd;
+      if (chunk < rem) lastdoc = gdocs[my_off + ocur + chunk - 1];
+      if (rem > 0) firstdoc = gdocs[my_off + ocur];
+      describe(ew, ocur, chunk);
+      issue(ew);
+      uint32_t bound = kDocEnd, cdlo = kDocEnd;
+      for (uint32_t t = 0; t < T; t++) {
+        const uint32_t ld = rl(lastdoc, t), fd = rl(firstdoc, t);
+        bound = ld < bound ? ld : bound;
+        cdlo = fd < cdlo ? fd : cdlo;
+      }
+      const uint32_t cdhi = bound == kDocEnd ? dhi : bound + 1u;
+      // what each list consumed: its postings with doc < cdhi (a prefix of its slots)
+      uint32_t consumed = 0;
+#pragma unroll
+      for (int jj = 0; jj < NS; jj++) {
+        const uint32_t cnt = (uint32_t)__popcll(__ballot(ew.doc[jj] < cdhi));
+        consumed += lane == rl(ew.st, jj) ? cnt : 0u;
+        ew.doc[jj] = ew.doc[jj] < cdhi ? ew.doc[jj] : kDocEnd;  // the rest waits for the next chunk
+      }
+      ocur += consumed;
+      windows(ew, cdlo, cdhi);
+    }
+  }
+
+  // ---- write this slice's candidates (sorted best-first; sentinel-padded) ----
+  int32_t *otk = p.slice_tk + (size_t)slice * k;
+  uint32_t *odoc = p.slice_doc + (size_t)slice * k;
+#pragma unroll
+  for (int r = 0; r < KREGS; r++) {
+    const uint32_t pos = lane * KREGS + r;
+    if (pos < k) {
+      otk[pos] = top.tk[r];
+      odoc[pos] = top.doc[r];
+    }
+  }
+  if (p.q_scored && lane == 0 && n_scored) atomicAdd(&p.q_scored[s.q], n_scored);
+}
+
+}  // namespace slg

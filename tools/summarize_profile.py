@@ -21,20 +21,20 @@ for p in ("pmc_a", "pmc_b", "pmc_c", "pmc_d"):
         continue
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        if "score_rounds" in r["Kernel_Name"]:
+        if "score_rounds" in r["Kernel_Name"] or "score_uniform" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
             vals["VGPR_Count"] = r.get("VGPR_Count")
             vals["SGPR_Count"] = r.get("SGPR_Count")
             vals["LDS_Block_Size"] = r.get("LDS_Block_Size")
     for c, v in acc.items():
         vals[c] = sum(v) / len(v)
-print("== score_rounds_kernel PMC averages per launch ==")
+print("== scoring kernel PMC averages per launch ==")
 for k in sorted(vals):
     print(f"{k:24s} {vals[k]}")
 if "FETCH_SIZE" in vals:
     fetch = vals["FETCH_SIZE"] * 1024 * 2  # gfx950: FETCH_SIZE reports half of a wide stream
     write = vals.get("WRITE_SIZE", 0.0) * 1024
-    out = {"kernel": "score_rounds_kernel", "fetch_bytes_corrected": fetch, "write_bytes": write,
+    out = {"kernel": "score_uniform_kernel", "fetch_bytes_corrected": fetch, "write_bytes": write,
            "hbm_bytes_per_launch": fetch + write,
            "note": "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB counters, "
                    "separate --pmc passes"}
