@@ -232,26 +232,6 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
     wave_fence();
   };
 
-  // ---- all doc windows of the loaded postings with docs in [dlo, dhi) ----
-  auto windows = [&](URound &e, const uint32_t dlo, const uint32_t dhi) {
-    uint32_t wbase = dlo & ~31u;
-    if (dhi - wbase <= kSpan) {  // the common case: one window
-      accumulate(e, wbase, dhi - wbase);
-      return;
-    }
-    for (;;) {
-      const uint32_t wend = (dhi - wbase) < kSpan ? dhi : wbase + kSpan;
-      accumulate(e, wbase, wend - wbase);
-      // next window starts at the smallest doc not yet covered
-      uint32_t mn = kDocEnd;
-#pragma unroll
-      for (int jj = 0; jj < NS; jj++) mn = (e.doc[jj] >= wend && e.doc[jj] < mn) ? e.doc[jj] : mn;
-      mn = wave_min(mn);
-      if (mn >= dhi) break;
-      wbase = mn & ~31u;
-    }
-  };
-
   // lane t < T: cut points of round rr and rr + 1 of this slice
   auto cuts = [&](const uint32_t rr, uint32_t &lo, uint32_t &hi) {
     const uint32_t src = rr * T + lane;
@@ -266,7 +246,8 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
   };
 
   // ---- driver: planned rounds are prefetched one ahead (`en` loads while `ew` is processed);
-  //      a round that needs more than NS slots is streamed in chunks cut at a common doc id ----
+  //      a round that needs more than NS slots is streamed in chunks cut at a common doc id.
+  //      Both paths and all doc windows share ONE accumulate site (code size / I-cache). ----
   URound ew, en;
   uint32_t lo_n, hi_n;
   cuts(0, lo_n, hi_n);
@@ -282,51 +263,64 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
       describe(en, lo_n, hi_n - lo_n);
       if (en.nslots <= (uint32_t)NS) issue(en);
     }
-    const uint32_t dlo = rl(dflat, rr), dhi = rl(dflat, rr + 1);
+    uint32_t dlo = rl(dflat, rr), dhi = rl(dflat, rr + 1);
+    const uint32_t rhi = dhi;
     if (p.dbg & 4u) continue;
-    if (!big) {
-      if (ew.nslots != 0) windows(ew, dlo, dhi);
-      continue;
-    }
-    // ---- over-full round: chunks of <= NS slots; each list gets >= 1 slot, the rest in
-    //      proportion to what it has left; the chunk is cut at the smallest "last loaded doc"
-    //      of the lists that did not finish ----
     uint32_t guard = 0;
-    for (;;) {
-      const uint32_t rem = oend - ocur;
-      const uint32_t nne = (uint32_t)__popcll(__ballot(rem != 0u));
-      const uint32_t R = lane_sum_T(rem);
-      if (R == 0 || ++guard > (1u << 22)) break;
-      const uint32_t need = lane_sum_T((rem + 63u) >> 6);
-      uint32_t chunk = rem;
-      if (need > (uint32_t)NS) {
-        const float share = (float)(NS - nne) * ((float)rem / (float)R);
-        const uint32_t mslots = rem == 0u ? 0u : 1u + (uint32_t)share;
-        chunk = rem < mslots * 64u ? rem : mslots * 64u;
-      }
-      uint32_t lastdoc = kDocEnd, firstdoc = kDocEnd;
-      if (chunk < rem) lastdoc = gdocs[my_off + ocur + chunk - 1];
-      if (rem > 0) firstdoc = gdocs[my_off + ocur];
-      describe(ew, ocur, chunk);
-      issue(ew);
-      uint32_t bound = kDocEnd, cdlo = kDocEnd;
-      for (uint32_t t = 0; t < T; t++) {
-        const uint32_t ld = rl(lastdoc, t), fd = rl(firstdoc, t);
-        bound = ld < bound ? ld : bound;
-        cdlo = fd < cdlo ? fd : cdlo;
-      }
-      const uint32_t cdhi = bound == kDocEnd ? dhi : bound + 1u;
-      // what each list consumed: its postings with doc < cdhi (a prefix of its slots)
-      uint32_t consumed = 0;
+    do {
+      if (big) {
+        // next chunk of an over-full round: every list gets >= 1 slot, the rest in proportion
+        // to what it has left; the chunk ends at the smallest "last loaded doc" of the lists
+        // that did not finish
+        const uint32_t rem = oend - ocur;
+        const uint32_t nne = (uint32_t)__popcll(__ballot(rem != 0u));
+        const uint32_t R = lane_sum_T(rem);
+        if (R == 0 || ++guard > (1u << 22)) break;
+        const uint32_t need = lane_sum_T((rem + 63u) >> 6);
+        uint32_t chunk = rem;
+        if (need > (uint32_t)NS) {
+          const float share = (float)(NS - nne) * ((float)rem / (float)R);
+          const uint32_t mslots = rem == 0u ? 0u : 1u + (uint32_t)share;
+          chunk = rem < mslots * 64u ? rem : mslots * 64u;
+        }
+        uint32_t lastdoc = kDocEnd, firstdoc = kDocEnd;
+        if (chunk < rem) lastdoc = gdocs[my_off + ocur + chunk - 1];
+        if (rem > 0) firstdoc = gdocs[my_off + ocur];
+        describe(ew, ocur, chunk);
+        issue(ew);
+        uint32_t bound = kDocEnd;
+        dlo = kDocEnd;
+        for (uint32_t t = 0; t < T; t++) {
+          const uint32_t ld = rl(lastdoc, t), fd = rl(firstdoc, t);
+          bound = ld < bound ? ld : bound;
+          dlo = fd < dlo ? fd : dlo;
+        }
+        dhi = bound == kDocEnd ? rhi : bound + 1u;
+        // what each list consumed: its postings with doc < dhi (a prefix of its slots)
+        uint32_t consumed = 0;
 #pragma unroll
-      for (int jj = 0; jj < NS; jj++) {
-        const uint32_t cnt = (uint32_t)__popcll(__ballot(ew.doc[jj] < cdhi));
-        consumed += lane == rl(ew.st, jj) ? cnt : 0u;
-        ew.doc[jj] = ew.doc[jj] < cdhi ? ew.doc[jj] : kDocEnd;  // the rest waits for the next chunk
+        for (int jj = 0; jj < NS; jj++) {
+          const uint32_t cnt = (uint32_t)__popcll(__ballot(ew.doc[jj] < dhi));
+          consumed += lane == rl(ew.st, jj) ? cnt : 0u;
+          ew.doc[jj] = ew.doc[jj] < dhi ? ew.doc[jj] : kDocEnd;  // the rest: next chunk
+        }
+        ocur += consumed;
       }
-      ocur += consumed;
-      windows(ew, cdlo, cdhi);
-    }
+      if (ew.nslots == 0) break;
+      // doc windows: one in the common case (the postings span <= kSpan docs)
+      uint32_t wbase = dlo & ~31u;
+      for (;;) {
+        const uint32_t wend = (dhi - wbase) <= kSpan ? dhi : wbase + kSpan;
+        accumulate(ew, wbase, wend - wbase);
+        if (wend == dhi) break;
+        uint32_t mn = kDocEnd;  // next window starts at the smallest doc not yet covered
+#pragma unroll
+        for (int jj = 0; jj < NS; jj++) mn = (ew.doc[jj] >= wend && ew.doc[jj] < mn) ? ew.doc[jj] : mn;
+        mn = wave_min(mn);
+        if (mn >= dhi) break;
+        wbase = mn & ~31u;
+      }
+    } while (big);
   }
 
   // ---- write this slice's candidates (sorted best-first; sentinel-padded) ----
