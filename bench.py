@@ -126,10 +126,9 @@ def main():
     t_score = torch.as_tensor(_DevArray(d_score, (nq, k), "<f4"), device="cuda")
     t_count = torch.as_tensor(_DevArray(d_count, (nq,), "<i4"), device="cuda")
     if use_dist:
-        g_doc = torch.empty((world, nq, k), dtype=torch.int32, device="cuda")
-        g_seg = torch.empty_like(g_doc)
-        g_score = torch.empty((world, nq, k), dtype=torch.float32, device="cuda")
-        g_count = torch.empty((world, nq), dtype=torch.int32, device="cuda")
+        blk_ptr, blk_bytes = batch.device_result_block()
+        t_block = torch.as_tensor(_DevArray(blk_ptr, (blk_bytes // 4,), "<i4"), device="cuda")
+        g_block = torch.empty((world * (blk_bytes // 4),), dtype=torch.int32, device="cuda")
         m_doc = torch.empty((nq, k), dtype=torch.int32, device="cuda")
         m_seg = torch.empty_like(m_doc)
         m_score = torch.empty((nq, k), dtype=torch.float32, device="cuda")
@@ -162,12 +161,16 @@ def main():
                 ev_b[step_no[0] - args.warmup].record()
             step_no[0] += 1
         if use_dist:
-            # per-rank top-k exchanged over xGMI: Q*k*(4+4+4)+Q*4 bytes per rank
-            dist.all_gather_into_tensor(g_doc, t_doc)
-            dist.all_gather_into_tensor(g_seg, t_seg)
-            dist.all_gather_into_tensor(g_score, t_score)
-            dist.all_gather_into_tensor(g_count, t_count)
+            # per-rank top-k exchanged over xGMI in ONE all-gather: the contiguous block
+            # doc|seg|score|count = (3k+1)*Q*4 bytes per rank
+            dist.all_gather_into_tensor(g_block, t_block)
             if shard_mode:  # api/reader.rs:2776-2778 across shards
+                n_ = nq * k
+                gb = g_block.view(world, -1)
+                g_doc = gb[:, :n_].contiguous()
+                g_seg = gb[:, n_:2 * n_].contiguous()
+                g_score = gb[:, 2 * n_:3 * n_].contiguous()
+                g_count = gb[:, 3 * n_:].contiguous()
                 index.merge_shards_device(world, nq, k, g_doc.data_ptr(), g_seg.data_ptr(),
                                           g_score.data_ptr(), g_count.data_ptr(), 1,
                                           m_doc.data_ptr(), m_seg.data_ptr(), m_score.data_ptr(),

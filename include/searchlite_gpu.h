@@ -166,6 +166,10 @@ int slg_batch_fetch(slg_batch *batch, uint32_t *out_doc, uint32_t *out_seg, floa
  * device-side consumers (RCCL all-gather of per-shard top-k, rerank). */
 int slg_batch_device_results(slg_batch *batch, void **d_doc, void **d_seg, void **d_score,
                              void **d_count);
+/* The four result arrays live back to back in ONE device allocation, in the order
+ * doc[nq*k] | seg[nq*k] | score[nq*k] | count[nq] (4-byte elements, so (3*k+1)*nq*4 bytes):
+ * a multi-GPU caller exchanges the per-shard top-k with a single all-gather of this block. */
+int slg_batch_device_result_block(slg_batch *batch, void **d_block, uint64_t *n_bytes);
 /* Planning facts: total postings the batch scores, number of work slices, and the
  * algorithmic byte count 12*postings + 8*k*nq. */
 int slg_batch_info(const slg_batch *batch, uint64_t *n_postings, uint32_t *n_slices,

@@ -66,6 +66,15 @@ def load():
             f"{path} is missing: the HIP extension is not built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
             "searchlite_amd has no CPU fallback.")
+    if os.environ.get("SLG_NO_TORCH_PRELOAD", "0") == "0":
+        # PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64.  Two HIP runtimes in one
+        # process do not share the GPU (the second to initialise reports "no HIP GPUs"), so
+        # when torch is installed load it first: libsearchlite_gpu.so then binds to the HIP
+        # runtime that is already resident (same SONAME).
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(path)
     vp, u32, i32, f32 = C.c_void_p, C.c_uint32, C.c_int, C.c_float
     sigs = {
@@ -82,6 +91,7 @@ def load():
         "slg_batch_sync": (i32, [vp]),
         "slg_batch_fetch": (i32, [vp, vp, vp, vp, vp, vp]),
         "slg_batch_device_results": (i32, [vp, vp, vp, vp, vp]),
+        "slg_batch_device_result_block": (i32, [vp, vp, vp]),
         "slg_batch_info": (i32, [vp, vp, vp, vp]),
         "slg_batch_destroy": (None, [vp]),
         "slg_merge_shards_device": (i32, [vp, u32, u32, u32, vp, vp, vp, vp, u32, vp, vp, vp, vp]),

@@ -145,7 +145,9 @@ struct slg_batch {
   const uint32_t *d_bnd_sq = nullptr;
   const slg::QueryRef *d_queries = nullptr;
   DevBuf d_bounds, d_rdoc, d_slice_tk, d_slice_doc, d_q_scored;
-  DevBuf d_out_doc, d_out_seg, d_out_score, d_out_count;
+  DevBuf d_out;  // doc | seg | score | count, contiguous
+  uint32_t *d_out_doc = nullptr, *d_out_seg = nullptr, *d_out_count = nullptr;
+  float *d_out_score = nullptr;
   DevBuf d_stamps;  // SLG_STAMPS diagnostic builds
 };
 
@@ -722,10 +724,11 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
     b->d_slice_tk.alloc((size_t)b->n_slices * k * 4);
     b->d_slice_doc.alloc((size_t)b->n_slices * k * 4);
     b->d_q_scored.alloc((size_t)nq * 4);
-    b->d_out_doc.alloc((size_t)nq * k * 4);
-    b->d_out_seg.alloc((size_t)nq * k * 4);
-    b->d_out_score.alloc((size_t)nq * k * 4);
-    b->d_out_count.alloc((size_t)nq * 4);
+    b->d_out.alloc(((size_t)nq * k * 3 + nq) * 4);
+    b->d_out_doc = b->d_out.as<uint32_t>();
+    b->d_out_seg = b->d_out_doc + (size_t)nq * k;
+    b->d_out_score = reinterpret_cast<float *>(b->d_out_seg + (size_t)nq * k);
+    b->d_out_count = b->d_out_seg + (size_t)nq * k * 2;
     SLG_HIP(hipStreamSynchronize(ix->stream));  // pinned staging buffer is freed on return
   });
   if (rc != SLG_OK) {
@@ -800,15 +803,15 @@ int slg_batch_run(slg_batch *b) {
       mp.slice_seg = b->d_slice_seg;
       mp.slice_tk = b->d_slice_tk.as<int32_t>();
       mp.slice_doc = b->d_slice_doc.as<uint32_t>();
-      mp.out_doc = b->d_out_doc.as<uint32_t>();
-      mp.out_seg = b->d_out_seg.as<uint32_t>();
-      mp.out_score = b->d_out_score.as<float>();
-      mp.out_count = b->d_out_count.as<uint32_t>();
+      mp.out_doc = b->d_out_doc;
+      mp.out_seg = b->d_out_seg;
+      mp.out_score = b->d_out_score;
+      mp.out_count = b->d_out_count;
       mp.nq = b->nq;
       mp.k = b->k;
       launch_merge(mp, st);
     } else {
-      SLG_HIP(hipMemsetAsync(b->d_out_count.p, 0, (size_t)b->nq * 4, st));
+      SLG_HIP(hipMemsetAsync(b->d_out_count, 0, (size_t)b->nq * 4, st));
     }
   });
 }
@@ -833,13 +836,13 @@ int slg_batch_fetch(slg_batch *b, uint32_t *out_doc, uint32_t *out_seg, float *o
     hipStream_t st = ix->stream;
     const size_t n = (size_t)b->nq * b->k;
     if (n) {
-      SLG_HIP(hipMemcpyAsync(out_doc, b->d_out_doc.p, n * 4, hipMemcpyDeviceToHost, st));
-      SLG_HIP(hipMemcpyAsync(out_seg, b->d_out_seg.p, n * 4, hipMemcpyDeviceToHost, st));
-      SLG_HIP(hipMemcpyAsync(out_score, b->d_out_score.p, n * 4, hipMemcpyDeviceToHost, st));
+      SLG_HIP(hipMemcpyAsync(out_doc, b->d_out_doc, n * 4, hipMemcpyDeviceToHost, st));
+      SLG_HIP(hipMemcpyAsync(out_seg, b->d_out_seg, n * 4, hipMemcpyDeviceToHost, st));
+      SLG_HIP(hipMemcpyAsync(out_score, b->d_out_score, n * 4, hipMemcpyDeviceToHost, st));
     }
     std::vector<uint32_t> scored;
     if (b->nq) {
-      SLG_HIP(hipMemcpyAsync(out_count, b->d_out_count.p, (size_t)b->nq * 4, hipMemcpyDeviceToHost, st));
+      SLG_HIP(hipMemcpyAsync(out_count, b->d_out_count, (size_t)b->nq * 4, hipMemcpyDeviceToHost, st));
       if (stats) {
         scored.resize(b->nq);
         SLG_HIP(hipMemcpyAsync(scored.data(), b->d_q_scored.p, (size_t)b->nq * 4,
@@ -861,10 +864,18 @@ int slg_batch_device_results(slg_batch *b, void **d_doc, void **d_seg, void **d_
                              void **d_count) {
   return guarded([&] {
     SLG_REQUIRE(b != nullptr, "batch is NULL");
-    if (d_doc) *d_doc = b->d_out_doc.p;
-    if (d_seg) *d_seg = b->d_out_seg.p;
-    if (d_score) *d_score = b->d_out_score.p;
-    if (d_count) *d_count = b->d_out_count.p;
+    if (d_doc) *d_doc = b->d_out_doc;
+    if (d_seg) *d_seg = b->d_out_seg;
+    if (d_score) *d_score = b->d_out_score;
+    if (d_count) *d_count = b->d_out_count;
+  });
+}
+
+int slg_batch_device_result_block(slg_batch *b, void **d_block, uint64_t *n_bytes) {
+  return guarded([&] {
+    SLG_REQUIRE(b != nullptr, "batch is NULL");
+    if (d_block) *d_block = b->d_out.p;
+    if (n_bytes) *n_bytes = ((uint64_t)b->nq * b->k * 3 + b->nq) * 4;
   });
 }
 

@@ -35,6 +35,35 @@ def batch_result_tensors(batch):
             torch.as_tensor(_DevArray(d_count, (nq,), "<i4"), device="cuda"))
 
 
+def batch_result_block(batch):
+    """Zero-copy int32 view of the contiguous doc|seg|score|count block of a PreparedBatch."""
+    import torch
+    ptr, nb = batch.device_result_block()
+    return torch.as_tensor(_DevArray(ptr, (nb // 4,), "<i4"), device="cuda")
+
+
+def split_result_block(block, nq: int, k: int):
+    """[..., (3k+1)*nq] int32 block(s) -> (doc, seg, score(f32 view), count) views."""
+    import torch
+    n = nq * k
+    lead = tuple(block.shape[:-1])
+    doc = block[..., :n].reshape(lead + (nq, k))
+    seg = block[..., n:2 * n].reshape(lead + (nq, k))
+    score = block[..., 2 * n:3 * n].view(torch.float32).reshape(lead + (nq, k))
+    count = block[..., 3 * n:3 * n + nq]
+    return doc, seg, score, count
+
+
+def all_gather_block(block, group=None):
+    """ONE collective per step: every rank's result block -> [world, (3k+1)*nq]."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    out = torch.empty((world * block.shape[0],), dtype=block.dtype, device=block.device)
+    dist.all_gather_into_tensor(out, block, group=group)
+    return out.view(world, block.shape[0])
+
+
 def all_gather_topk(doc, seg, score, count, group=None):
     """One logical exchange of the per-rank top-k: -> tensors shaped [world, nq, k] / [world, nq]."""
     import torch
@@ -106,9 +135,11 @@ class ShardedSearcher:
         (doc[nq,k], seg[nq,k] = shard*seg_stride+seg, score[nq,k], count[nq])."""
         import torch
         batch.run()
-        t = batch_result_tensors(batch)
-        g_doc, g_seg, g_score, g_count = all_gather_topk(*t, group=self.group)
         nq, k = batch.nq, batch.k
+        g = all_gather_block(batch_result_block(batch), group=self.group)  # one exchange
+        g_doc, g_seg, g_score, g_count = split_result_block(g, nq, k)
+        g_doc, g_seg, g_score, g_count = (g_doc.contiguous(), g_seg.contiguous(),
+                                          g_score.contiguous(), g_count.contiguous())
         m_doc = torch.empty((nq, k), dtype=torch.int32, device="cuda")
         m_seg = torch.empty_like(m_doc)
         m_score = torch.empty((nq, k), dtype=torch.float32, device="cuda")

@@ -234,6 +234,12 @@ class PreparedBatch:
         N.check(self._lib.slg_batch_device_results(self._h, *[C.addressof(p) for p in ptrs]))
         return tuple(p.value for p in ptrs)
 
+    def device_result_block(self):
+        """-> (address, n_bytes) of the contiguous doc|seg|score|count block."""
+        ptr, nb = C.c_void_p(), C.c_uint64()
+        N.check(self._lib.slg_batch_device_result_block(self._h, C.addressof(ptr), C.addressof(nb)))
+        return ptr.value, nb.value
+
     def fetch(self, want_stats: bool = False):
         nq, k = self.nq, self.k
         out_doc = np.zeros((nq, k), dtype=np.uint32)

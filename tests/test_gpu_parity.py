@@ -350,3 +350,73 @@ def test_maxscore_pruning_is_exact(gpu, oracle, monkeypatch):
     want = oracle.search_batch([seg], offs, terms, w, 31, strategy=oracle.BM25, n_threads=8)
     with gpu.GpuIndex([seg]) as ix:
         assert_same_hits(ix.search_batch(offs, terms, w, 31, gpu.Bmw), want, 0.0, "maxscore T=5")
+
+
+# ---- cross-shard merge kernel (config 4 shape, emulated on one GPU) ----------------------------
+def test_merge_shards_device_matches_multi_segment_oracle(gpu, oracle):
+    """Three shards scored independently (as three ranks would), their result blocks
+    concatenated shard-major exactly as the RCCL all-gather delivers them, merged by
+    slg_merge_shards_device: must equal the oracle run on the three shards as three segments
+    (api/reader.rs:2776-2778 with segment_ord = shard)."""
+    import torch
+    from searchlite_amd import dist as sdist
+    rng = np.random.default_rng(31)
+    segs = [random_segment(rng, 1500 + 200 * i, 40, 20) for i in range(3)]
+    nq, k = 24, 21
+    offs, terms, w = random_queries(rng, nq, 3, 40, n_segs=3, weights=True)
+    want = _oracle_batch(oracle, segs, offs, terms, w, k)
+    blocks, keep = [], []
+    for i, seg in enumerate(segs):
+        ix = gpu.GpuIndex([seg])
+        ix.set_stream(torch.cuda.current_stream().cuda_stream)
+        b = ix.prepare(offs, terms[:, i:i + 1].copy(), w, k)
+        b.run()
+        blocks.append(sdist.batch_result_block(b).clone())
+        keep.append((ix, b))
+    g = torch.stack(blocks)                       # [shards, (3k+1)*nq] as all_gather_block returns
+    g_doc, g_seg, g_score, g_count = [x.contiguous() for x in sdist.split_result_block(g, nq, k)]
+    m_doc = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+    m_seg = torch.empty_like(m_doc)
+    m_score = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    m_count = torch.empty((nq,), dtype=torch.int32, device="cuda")
+    keep[0][0].merge_shards_device(3, nq, k, g_doc.data_ptr(), g_seg.data_ptr(), g_score.data_ptr(),
+                                   g_count.data_ptr(), 1, m_doc.data_ptr(), m_seg.data_ptr(),
+                                   m_score.data_ptr(), m_count.data_ptr())
+    torch.cuda.synchronize()
+    got = (m_doc.cpu().numpy().view(np.uint32), m_seg.cpu().numpy().view(np.uint32),
+           m_score.cpu().numpy(), m_count.cpu().numpy().view(np.uint32))
+    assert_same_hits(got, want, 0.0, "merge_shards_device")
+    for ix, b in keep:
+        b.close()
+        ix.close()
+
+
+def test_sharded_searcher_one_rank_rccl(gpu, oracle):
+    """ShardedSearcher end to end on one rank: RCCL all-gather of the result block + device merge."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as tdist
+    from searchlite_amd import dist as sdist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rng = np.random.default_rng(32)
+        segs = [random_segment(rng, 1200, 30, 15), random_segment(rng, 900, 30, 15)]
+        offs, terms, w = random_queries(rng, 10, 3, 30, n_segs=2)
+        want = _oracle_batch(oracle, segs, offs, terms, w, 11)
+        with gpu.GpuIndex(segs) as ix:
+            ss = sdist.ShardedSearcher(ix)
+            b = ss.prepare(offs, terms, w, 11)
+            m_doc, m_seg, m_score, m_count = ss.run(b)
+            torch.cuda.synchronize()
+            got = (m_doc.cpu().numpy().view(np.uint32), m_seg.cpu().numpy().view(np.uint32),
+                   m_score.cpu().numpy(), m_count.cpu().numpy().view(np.uint32))
+            b.close()
+        assert_same_hits(got, want, 0.0, "sharded searcher, one rank")
+    finally:
+        tdist.destroy_process_group()
