@@ -420,3 +420,22 @@ def test_sharded_searcher_one_rank_rccl(gpu, oracle):
         assert_same_hits(got, want, 0.0, "sharded searcher, one rank")
     finally:
         tdist.destroy_process_group()
+
+
+# ---- the C++ host mirror (include/searchlite_gpu.hpp) ---------------------------------------------
+def test_cpp_host_mirror_replays_wand_rs_unit_tests(gpu, tmp_path):
+    """tests/cpp/wand_tests.cpp = query/wand.rs:951-1052 through execute_top_k / RankedDoc /
+    QueryStats of the C++ mirror, linked against libsearchlite_gpu.so."""
+    import os
+    import subprocess
+    from searchlite_amd import _native
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "wand_tests")
+    libdir = os.path.dirname(_native.lib_path())
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "wand_tests.cpp"), "-o", exe,
+                           "-L", libdir, "-lsearchlite_gpu", f"-Wl,-rpath,{libdir}",
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all passed" in out.stdout
