@@ -655,7 +655,8 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
       nr = std::max<uint64_t>(1, std::min<uint64_t>(nr, dfL));
       const uint32_t rps = std::max<uint32_t>(1, std::min<uint32_t>(max_rps, 64 / sq.n_terms - 1));
       const uint64_t S = (nr + rps - 1) / rps;
-      SLG_REQUIRE(nr < 0x7FFFFFFFull && slice_sq.size() + S < 0x7FFFFFFFull,
+      SLG_REQUIRE(nr < 0x7FFFFFFFull && slice_sq.size() + S < 0x7FFFFFFFull &&
+                      (slice_sq.size() + S) * (uint64_t)std::max<uint32_t>(k, 1) < 0xFFFFFFFFull,
                   "batch too large (rounds)");
       sq.n_rounds = (uint32_t)nr;
       sq.rounds_per_slice = rps;

@@ -343,15 +343,16 @@ __global__ void __launch_bounds__(256) merge_topk_kernel(MergeParams p) {
   const QueryRef qr = p.queries[q];
   WaveTopK<KREGS, true> top;
   top.init();
-  const uint64_t f0 = (uint64_t)qr.slice_begin * k, f1 = (uint64_t)qr.slice_end * k;
-  for (uint64_t base = f0; base < f1; base += 64) {
-    const uint64_t f = base + lane;
+  // candidate arrays are indexed slice*k + i; the host guarantees n_slices*k < 2^32
+  const uint32_t f0 = qr.slice_begin * k, f1 = qr.slice_end * k;
+  for (uint32_t base = f0; base < f1; base += 64) {
+    const uint32_t f = base + lane;
     int32_t ctk = kSentinelTk;
     uint32_t cdoc = 0xFFFFFFFFu, cseg = 0xFFFFFFFFu;
     if (f < f1) {
       ctk = p.slice_tk[f];
       cdoc = p.slice_doc[f];
-      cseg = p.slice_seg[(uint32_t)(f / k)];
+      cseg = p.slice_seg[f / k];
     }
     const bool valid = !(ctk == kSentinelTk && cdoc == 0xFFFFFFFFu);
     uint64_t m = __ballot(valid && top.passes(ctk, cseg, cdoc));

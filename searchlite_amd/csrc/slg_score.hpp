@@ -85,6 +85,24 @@ static __global__ void __launch_bounds__(256) partition_rounds_kernel(RoundPartP
     } else {
       const uint32_t *d = docs + me.off;
       uint32_t lo = 0, hi = me.df;  // first index with d[idx] >= target
+      // bracket around the position a uniform doc-id distribution predicts (widened until it
+      // holds the answer), then bisect: ~10 dependent loads instead of ~log2(df)
+      {
+        const uint32_t nd = p.segs[s.seg].n_docs;
+        const uint32_t g = (uint32_t)(((uint64_t)me.df * target) / (nd ? nd : 1u));
+        for (uint32_t w = 64; w < me.df; w <<= 3) {
+          const uint32_t a = g > w ? g - w : 0u;
+          const uint32_t b = (uint64_t)g + w < me.df ? g + w : me.df;
+          const bool lo_ok = a == 0u || d[a - 1] < target;   // answer >= a
+          const bool hi_ok = b == me.df || d[b - 1] >= target;  // answer <= b - 1 < b
+          if (lo_ok && hi_ok) {
+            lo = a;
+            hi = b == me.df ? me.df : b - 1;  // d[b-1] >= target: answer <= b-1
+            if (b != me.df) hi = b - 1;
+            break;
+          }
+        }
+      }
       while (lo < hi) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
         if (d[mid] < target)

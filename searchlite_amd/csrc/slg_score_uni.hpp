@@ -79,6 +79,10 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
     if (best > 0.0f && !anyneg) top.set_floor(best);
   }
   uint32_t n_scored = 0;
+#ifdef SLG_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_ins = 0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
 
   // One round's postings: slot jj holds <= 64 postings of one list.  The slot descriptors
   // live across lanes: lane jj of st / scnt / sb_lo / sb_hi describes slot jj.
@@ -132,6 +136,7 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
 
   // ---- accumulate the postings of `e` whose docs lie in [wbase, wbase + wspan) ----
   auto accumulate = [&](URound &e, const uint32_t wbase, const uint32_t wspan) {
+    SLG_STAMP(1);
     // P0: clear the bitmap
     bm4[lane] = make_uint4(0u, 0u, 0u, 0u);
     bm4[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
@@ -154,6 +159,7 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
         ownmask |= (bit[jj] & ~oldw[jj]) != 0u ? (1u << jj) : 0u;
     }
     wave_fence();
+    SLG_STAMP(2);
     // P2: exclusive prefix popcount (lane l owns words 4l..4l+3 and 256+4l..256+4l+3)
     {
       const uint4 a = bm4[lane], b = bm4[lane + 64];
@@ -167,6 +173,7 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
       n_scored += rl(incl, 63);
     }
     wave_fence();
+    SLG_STAMP(3);
     // P3a: rank(doc) = accumulator slot; x = impact * weight (score_tf, query/wand.rs:285, the
     // slot's list weight is a scalar); owners store 0.0 + x (`or_insert(0.0) += score`, :539)
     uint32_t slot[NS];
@@ -200,6 +207,7 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
       }
     }
     wave_fence();
+    SLG_STAMP(4);
     // P4: owners read the finished sums and offer them to the top-k
     int32_t ctk[NS];
     uint32_t passmask = 0;
@@ -224,12 +232,16 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
           const uint32_t c_doc = rl(e.doc[jj], l);
           if (!(gdel && ((gdel[c_doc >> 5] >> (c_doc & 31)) & 1u)))  // accept()
             top.insert(c_tk, 0u, c_doc, k, lane);
+#ifdef SLG_STAMPS
+          st_ins++;
+#endif
           m &= m - 1;
           m &= __ballot(top.passes(ctk[jj], 0u, e.doc[jj]));
         }
       }
     }
     wave_fence();
+    SLG_STAMP(5);
   };
 
   // lane t < T: cut points of round rr and rr + 1 of this slice
@@ -258,12 +270,17 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
     uint32_t ocur = lo_n;
     const uint32_t oend = hi_n;
     if (!big) ew = en;
+#ifdef SLG_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    SLG_STAMP(6);
     if (rr + 1 < n_r) {  // prefetch the next round
       cuts(rr + 1, lo_n, hi_n);
       describe(en, lo_n, hi_n - lo_n);
       if (en.nslots <= (uint32_t)NS) issue(en);
     }
     uint32_t dlo = rl(dflat, rr), dhi = rl(dflat, rr + 1);
+    SLG_STAMP(0);
     const uint32_t rhi = dhi;
     if (p.dbg & 4u) continue;
     uint32_t guard = 0;
@@ -335,6 +352,12 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
     }
   }
   if (p.q_scored && lane == 0 && n_scored) atomicAdd(&p.q_scored[s.q], n_scored);
+#ifdef SLG_STAMPS
+  SLG_STAMP(7);
+  st_acc[7] = st_ins;
+  if (p.stamps && lane == 0)
+    for (int i = 0; i < 8; i++) p.stamps[(size_t)slice * 8 + i] = st_acc[i];
+#endif
 }
 
 }  // namespace slg
