@@ -348,6 +348,8 @@ void stage_segment(slg_index *ix, SegHost &sh, const slg_segment_desc &d) {
       slg::ChampParams cp{};
       cp.term_offsets = d_offs.as<uint64_t>();
       cp.imps = sh.d_imps.as<float>();
+      cp.docs = sh.d_docs.as<uint32_t>();
+      cp.deleted = sh.d_deleted.as<uint32_t>();
       cp.champ = sh.d_champ.as<float>();
       cp.n_terms = d.n_terms;
       const uint32_t cblocks = std::min<uint32_t>((d.n_terms + 3) / 4, 256u * 16);
@@ -624,8 +626,6 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
     const uint32_t round_target_packed = std::max<uint32_t>(64, std::min<uint32_t>(
         env_u32("SLG_ROUND_TARGET", slg::kRoundTarget), slg::kCap));
     const uint32_t probe_target = std::max<uint32_t>(round_target_packed, env_u32("SLG_PROBE_TARGET", 2048));
-    const uint32_t max_rps = std::max<uint32_t>(1, std::min<uint32_t>(
-        env_u32("SLG_ROUNDS_PER_SLICE", slg::kDefaultRoundsPerSlice), slg::kMaxRoundsPerSlice));
     std::vector<uint32_t> slice_sq, slice_seg, bnd_sq;
     uint64_t n_bounds = 0, n_bnd = 0;
     // one-list-per-slot kernel (slg_score_uni.hpp): few terms, no non-essential lists
@@ -635,6 +635,14 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
       const uint32_t full = sqs[i].n_terms >= 32 ? 0xFFFFFFFFu : ((1u << sqs[i].n_terms) - 1u);
       if (sqs[i].ess_mask != full) b->uniform = false;
     }
+    // rounds per slice: short slices pack the tail of the launch better (one wave per slice,
+    // ~5 generations of waves per SIMD on config 2).  The uniform kernel's slices are cheap to
+    // start (threshold seed + buffered top-k) as long as k is small: every slice writes k
+    // candidates for the merge (measured: config 2 k=11 best at 4, config 3 k=101 best at 8).
+    const uint32_t max_rps = std::max<uint32_t>(1, std::min<uint32_t>(
+        env_u32("SLG_ROUNDS_PER_SLICE", b->uniform && k <= 64 ? slg::kUniRoundsPerSlice
+                                                               : slg::kDefaultRoundsPerSlice),
+        slg::kMaxRoundsPerSlice));
     for (size_t i = 0; i < sqs.size(); i++) {
       slg::RoundQuery &sq = sqs[i];
       const uint32_t dfL = terms[sq.term_begin + sq.longest].df;

@@ -205,6 +205,135 @@ struct WaveTopK {
   }
 };
 
+// ---- buffered wave top-k (one segment) ------------------------------------------------------
+// push_top_k (query/wand.rs:905-916) without a per-candidate sorted insert: a candidate that
+// beats the current threshold is appended to a per-wave LDS buffer (one ds_write for all passing
+// lanes of a slot); only when the buffer is full, and once at the end, are the entries ranked
+// (every lane counts the entries better than its own) and the k best kept.  The threshold is
+// the k-th best after a ranking, the up-front floor before, so it is always a valid lower bound
+// of the final k-th score: the surviving set is exactly the top-k under (score desc, doc asc).
+//
+// Entries are single 64-bit keys: (order-preserving score bits << 32) | ~doc, so "better" is
+// one unsigned 64-bit compare.
+__device__ __forceinline__ uint32_t ordered_score(float x) {
+  const int32_t b = __float_as_int(x);  // == total_key(x) ^ 0x80000000
+  return (uint32_t)b ^ ((uint32_t)(b >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ uint64_t cand_key(float score, uint32_t doc) {
+  return ((uint64_t)ordered_score(score) << 32) | (uint32_t)~doc;
+}
+
+template <int KREGS>
+struct BufTopK {
+  static constexpr uint32_t kEntries = 128u * KREGS;  // >= k + 64 for k <= 64 * KREGS
+  static constexpr int E = 2 * KREGS;                 // entries per lane while ranking
+  uint64_t *buf;   // LDS [kEntries]
+  uint32_t count;  // uniform: entries held
+  uint64_t th;     // uniform: a candidate passes iff key > th
+
+  __device__ __forceinline__ void init(uint64_t *lds) {
+    buf = lds;
+    count = 0;
+    th = 0;  // any real doc passes (~doc > 0)
+  }
+  // At least k docs score >= f.  Candidates equal to f still pass (doc-id tie break later).
+  __device__ __forceinline__ void set_floor(float f) {
+    th = ((uint64_t)ordered_score(f) << 32) - 1ull;
+  }
+  __device__ __forceinline__ bool passes(uint64_t key) const { return key > th; }
+
+  // drop deleted docs (accept(), query/wand.rs:905), rank the rest, keep the k best sorted at
+  // buf[0..count), refresh the threshold.  Deleted docs are filtered here, before anything is
+  // ranked, so they never influence the threshold.
+  __device__ __forceinline__ void compact(uint32_t k, uint32_t lane, const uint32_t *deleted) {
+    uint64_t e[E];
+    uint32_t rank[E];
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+      const uint32_t idx = lane + 64u * i;
+      e[i] = idx < count ? buf[idx] : 0ull;
+      rank[i] = 0;
+    }
+    if (deleted) {
+#pragma unroll
+      for (int i = 0; i < E; i++) {
+        const uint32_t doc = ~(uint32_t)e[i];
+        if (e[i] != 0ull && ((deleted[doc >> 5] >> (doc & 31)) & 1u)) e[i] = 0ull;
+      }
+    }
+    uint32_t nvalid = 0;
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+      if (64u * i < count) {  // uniform
+        nvalid += (uint32_t)__popcll(__ballot(e[i] != 0ull));
+        const uint32_t n_i = count - 64u * i < 64u ? count - 64u * i : 64u;
+        for (uint32_t l = 0; l < n_i; l++) {
+          const uint64_t c = ((uint64_t)rl((uint32_t)(e[i] >> 32), l) << 32) | rl((uint32_t)e[i], l);
+#pragma unroll
+          for (int j = 0; j < E; j++) rank[j] += c > e[j] ? 1u : 0u;
+        }
+      }
+    }
+    wave_fence();
+#pragma unroll
+    for (int i = 0; i < E; i++)
+      if (e[i] != 0ull && rank[i] < k) buf[rank[i]] = e[i];
+    wave_fence();
+    count = nvalid < k ? nvalid : k;
+    if (nvalid >= k) {
+      const uint64_t kth = buf[k - 1];
+      const uint64_t u = ((uint64_t)rfl((uint32_t)(kth >> 32)) << 32) | rfl((uint32_t)kth);
+      th = u > th ? u : th;
+    }
+  }
+
+  // split-key forms (the hot path keeps 32-bit halves: hi = ordered score, lo = ~doc)
+  __device__ __forceinline__ bool passes(uint32_t hi, uint32_t lo) const {
+    const uint32_t th_hi = (uint32_t)(th >> 32), th_lo = (uint32_t)th;
+    return hi > th_hi || (hi == th_hi && lo > th_lo);
+  }
+  // append the candidates of the lanes with `pass` set (pass implies key > th); the caller
+  // has checked that they fit (count + popcount <= kEntries)
+  __device__ __forceinline__ void append(bool pass, uint32_t hi, uint32_t lo, uint32_t lane) {
+    const uint64_t m = __ballot(pass);
+    if (m == 0ull) return;
+    const uint32_t dest =
+        count + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    uint32_t *b32 = reinterpret_cast<uint32_t *>(buf);
+    if (pass) {
+      b32[2 * dest] = lo;
+      b32[2 * dest + 1] = hi;
+    }
+    count += (uint32_t)__popcll(m);
+  }
+  // same, ranking first when the buffer would overflow (<= 64 candidates always fit after it)
+  __device__ __forceinline__ void append_checked(bool pass, uint32_t hi, uint32_t lo, uint32_t k,
+                                                 uint32_t lane, const uint32_t *deleted) {
+    if (count + (uint32_t)__popcll(__ballot(pass)) > kEntries) {
+      compact(k, lane, deleted);
+      pass = pass && passes(hi, lo);
+    }
+    append(pass, hi, lo, lane);
+  }
+
+  // final candidates of this wave: k entries (int32 total_key, doc), sentinel padded (best
+  // first when they were ranked; the merge does not rely on the order)
+  __device__ __forceinline__ void write_out(int32_t *otk, uint32_t *odoc, uint32_t k, uint32_t lane,
+                                            const uint32_t *deleted) {
+    if (count > k || (deleted && count)) compact(k, lane, deleted);
+    wave_fence();
+#pragma unroll
+    for (int r = 0; r < KREGS; r++) {
+      const uint32_t pos = lane + 64u * r;
+      if (pos < k) {
+        const uint64_t e = pos < count ? buf[pos] : 0ull;
+        otk[pos] = pos < count ? (int32_t)((uint32_t)(e >> 32) ^ 0x80000000u) : kSentinelTk;
+        odoc[pos] = ~(uint32_t)e;
+      }
+    }
+  }
+};
+
 // ---- staging: per-posting impact ---------------------------------------------------------
 // impact = bm25(tf, df, doc_len, avgdl, docs, k1, b) exactly as score_tf computes `base`
 // (query/wand.rs:279-285 -> query/bm25.rs:1-6); idf is computed on the host with libm
@@ -272,6 +401,8 @@ static __global__ void __launch_bounds__(256) stage_impacts_kernel(StageParams p
 struct ChampParams {
   const uint64_t *term_offsets;  // [V+1]
   const float *imps;             // [P]
+  const uint32_t *docs;          // [P]
+  const uint32_t *deleted;       // bitmap words or nullptr: deleted docs never count (accept())
   float *champ;                  // [V * kChampions]
   uint32_t n_terms;
 };
@@ -287,7 +418,11 @@ static __global__ void __launch_bounds__(256) stage_champions_kernel(ChampParams
     for (int r = 0; r < 16; r++) m[r] = 0.0f;
     for (uint64_t i0 = a; i0 < b; i0 += 64) {
       const uint64_t i = i0 + lane;
-      const float x = i < b ? p.imps[i] : 0.0f;
+      float x = i < b ? p.imps[i] : 0.0f;
+      if (p.deleted && i < b) {
+        const uint32_t d = p.docs[i];
+        if ((p.deleted[d >> 5] >> (d & 31)) & 1u) x = 0.0f;
+      }
       if (__ballot(x > m[15]) == 0ull) continue;  // nobody improves: the common case
 #pragma unroll
       for (int r = 15; r >= 1; r--) m[r] = x > m[r - 1] ? m[r - 1] : (x > m[r] ? x : m[r]);

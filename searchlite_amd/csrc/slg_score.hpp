@@ -39,6 +39,7 @@ constexpr int kCap = kNSlot * 64;         // postings per round
 constexpr int kRoundTarget = 416;         // planned postings per round (host + partition)
 constexpr int kMaxRoundsPerSlice = 16;  // and (rounds+1)*T <= 64: cut points live in one VGPR
 constexpr int kDefaultRoundsPerSlice = 8;
+constexpr int kUniRoundsPerSlice = 4;     // uniform kernel (slg_score_uni.hpp)
 constexpr int kSpanWords = 512;           // bitmap words per window
 constexpr uint32_t kSpan = kSpanWords * 32;  // docs per window
 // per-wave LDS: bitmap words, exclusive prefix popcounts, accumulators

@@ -2,6 +2,7 @@
 // the score_rounds_kernel instantiations compile in parallel.  slg_api.hip calls
 // slg::launch_score_kregs<N>() declared below.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "slg_score.hpp"
 #include "slg_score_uni.hpp"
@@ -25,10 +26,16 @@ void launch_score_kregs(const RoundScoreParams &sp, uint32_t max_terms, bool uni
 template <>
 void launch_score_kregs<SLG_INST_KREGS>(const RoundScoreParams &sp, uint32_t max_terms,
                                         bool uniform, hipStream_t st) {
-  if (uniform) {  // one list per register slot (slg_score_uni.hpp)
-    const uint32_t blocks = (sp.n_slices + kWavesPerBlock - 1) / kWavesPerBlock;
-    const size_t lds = (size_t)kWavesPerBlock * kUniWaveLds;
-    hipLaunchKernelGGL((score_uniform_kernel<SLG_INST_KREGS>), dim3(blocks), dim3(256), lds, st, sp);
+  if (uniform) {  // one list per register slot (slg_score_uni.hpp); waves are independent, so
+                  // one-wave workgroups: a finished wave frees its slot and LDS at once
+    static const uint32_t wpb = [] {
+      const char *e = getenv("SLG_UNI_WAVES_PER_BLOCK");
+      const uint32_t v = e ? (uint32_t)atoi(e) : 1u;
+      return v >= 1 && v <= 4 ? v : 1u;
+    }();
+    const uint32_t blocks = (sp.n_slices + wpb - 1) / wpb;
+    const size_t lds = (size_t)wpb * uni_wave_lds(SLG_INST_KREGS);
+    hipLaunchKernelGGL((score_uniform_kernel<SLG_INST_KREGS>), dim3(blocks), dim3(64 * wpb), lds, st, sp);
     return;
   }
   if (max_terms <= 4)

@@ -22,7 +22,12 @@ namespace slg {
 
 constexpr int kUniSlots = 8;                 // 64-posting slots per round; also max lists
 constexpr int kUniCap = kUniSlots * 64;
-constexpr int kUniWaveLds = kSpanWords * 4 + kSpanWords * 4 + kUniCap * 4 + 64 * 4;
+constexpr int kUniWaveLdsBase = kSpanWords * 4 + kSpanWords * 4 + kUniCap * 4 + 64 * 4;
+// k <= 256 (KREGS <= 4): buffered top-k in LDS (BufTopK); larger k: register-sorted WaveTopK
+constexpr bool uni_buffered(int kregs) { return kregs <= 4; }
+constexpr int uni_wave_lds(int kregs) {
+  return kUniWaveLdsBase + (uni_buffered(kregs) ? 128 * kregs * 8 : 0);
+}
 
 template <int KREGS>
 __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams p) {
@@ -30,10 +35,11 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wib = threadIdx.x >> 6;
-  const uint32_t slice = rfl(blockIdx.x * kWavesPerBlock + wib);
+  const uint32_t slice = rfl(blockIdx.x * (blockDim.x >> 6) + wib);
   if (slice >= p.n_slices) return;  // waves are independent: no workgroup barrier anywhere
 
-  uint32_t *bm = reinterpret_cast<uint32_t *>(smem + (size_t)wib * kUniWaveLds);
+  constexpr bool BUF = uni_buffered(KREGS);
+  uint32_t *bm = reinterpret_cast<uint32_t *>(smem + (size_t)wib * uni_wave_lds(KREGS));
   uint32_t *pre = bm + kSpanWords;
   uint32_t *vals = pre + kSpanWords;
   uint4 *bm4 = reinterpret_cast<uint4 *>(bm);
@@ -66,8 +72,10 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
   const uint32_t bflat = lane < (n_r + 1) * T ? p.bounds[s.bounds_begin + r0 * T + lane] : 0u;
   const uint32_t dflat = lane <= n_r ? p.rdoc[s.rdoc_begin + r0 + lane] : 0u;
 
-  WaveTopK<KREGS, false> top;
+  WaveTopK<BUF ? 1 : KREGS, false> top;  // k > 256
+  BufTopK<BUF ? KREGS : 1> btop;          // k <= 256
   top.init();
+  btop.init(reinterpret_cast<uint64_t *>(vals + kUniCap + 64));
   if (sd.champ != nullptr && k <= 1024u) {  // threshold seed (see slg_score.hpp)
     float f = 0.0f;
     if (lane < T && my_w > 0.0f)
@@ -76,7 +84,12 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
     for (uint32_t t = 0; t < T; t++)
       best = fmaxf(best, __int_as_float((int)rl((uint32_t)__float_as_int(f), t)));
     const bool anyneg = __ballot(lane < T && !(my_w >= 0.0f)) != 0ull;
-    if (best > 0.0f && !anyneg) top.set_floor(best);
+    if (best > 0.0f && !anyneg) {
+      if (BUF)
+        btop.set_floor(best);
+      else
+        top.set_floor(best);
+    }
   }
   uint32_t n_scored = 0;
 #ifdef SLG_STAMPS
@@ -209,34 +222,64 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
     wave_fence();
     SLG_STAMP(4);
     // P4: owners read the finished sums and offer them to the top-k
-    int32_t ctk[NS];
-    uint32_t passmask = 0;
-    {
-      uint32_t v[NS];
+    uint32_t v[NS];
 #pragma unroll
-      for (int jj = 0; jj < NS; jj++) v[jj] = vals[slot[jj]];
+    for (int jj = 0; jj < NS; jj++) v[jj] = vals[slot[jj]];
+    if constexpr (BUF) {
+      uint32_t okey[NS], passmask = 0;
+#pragma unroll
+      for (int jj = 0; jj < NS; jj++) {
+        const bool own = (ownmask >> jj) & 1u;
+        okey[jj] = ordered_score(__uint_as_float(v[jj]));
+        passmask |= (own && btop.passes(okey[jj], ~e.doc[jj])) ? (1u << jj) : 0u;
+      }
+      if (__ballot(passmask != 0u) != 0ull) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int jj = 0; jj < NS; jj++) tot += (uint32_t)__popcll(__ballot((passmask >> jj) & 1u));
+#ifdef SLG_STAMPS
+        st_ins += tot;
+#endif
+        if (btop.count + tot <= btop.kEntries) {  // the common case: everything fits
+#pragma unroll
+          for (int jj = 0; jj < NS; jj++)
+            btop.append((passmask >> jj) & 1u, okey[jj], ~e.doc[jj], lane);
+        } else {  // rank-and-trim between slots; one site, slot registers selected at run time
+#pragma unroll 1
+          for (uint32_t it = 0; it < (uint32_t)NS; it++) {
+            uint32_t ok = okey[0], dc = e.doc[0];
+#pragma unroll
+            for (int j = 1; j < NS; j++) {
+              ok = it == (uint32_t)j ? okey[j] : ok;
+              dc = it == (uint32_t)j ? e.doc[j] : dc;
+            }
+            btop.append_checked(((passmask >> it) & 1u) && btop.passes(ok, ~dc), ok, ~dc, k, lane,
+                                (const uint32_t *)gdel);
+          }
+        }
+      }
+    } else {
+      int32_t ctk[NS];
+      uint32_t passmask = 0;
 #pragma unroll
       for (int jj = 0; jj < NS; jj++) {
         const bool own = (ownmask >> jj) & 1u;
         ctk[jj] = own ? total_key(__uint_as_float(v[jj])) : kSentinelTk;
         passmask |= (own && top.passes(ctk[jj], 0u, e.doc[jj])) ? (1u << jj) : 0u;
       }
-    }
-    if (__ballot(passmask != 0u) != 0ull) {
+      if (__ballot(passmask != 0u) != 0ull) {
 #pragma unroll
-      for (int jj = 0; jj < NS; jj++) {
-        uint64_t m = __ballot(((passmask >> jj) & 1u) && top.passes(ctk[jj], 0u, e.doc[jj]));
-        while (m) {
-          const uint32_t l = (uint32_t)__builtin_ctzll(m);
-          const int32_t c_tk = (int32_t)rl((uint32_t)ctk[jj], l);
-          const uint32_t c_doc = rl(e.doc[jj], l);
-          if (!(gdel && ((gdel[c_doc >> 5] >> (c_doc & 31)) & 1u)))  // accept()
-            top.insert(c_tk, 0u, c_doc, k, lane);
-#ifdef SLG_STAMPS
-          st_ins++;
-#endif
-          m &= m - 1;
-          m &= __ballot(top.passes(ctk[jj], 0u, e.doc[jj]));
+        for (int jj = 0; jj < NS; jj++) {
+          uint64_t m = __ballot(((passmask >> jj) & 1u) && top.passes(ctk[jj], 0u, e.doc[jj]));
+          while (m) {
+            const uint32_t l = (uint32_t)__builtin_ctzll(m);
+            const int32_t c_tk = (int32_t)rl((uint32_t)ctk[jj], l);
+            const uint32_t c_doc = rl(e.doc[jj], l);
+            if (!(gdel && ((gdel[c_doc >> 5] >> (c_doc & 31)) & 1u)))  // accept()
+              top.insert(c_tk, 0u, c_doc, k, lane);
+            m &= m - 1;
+            m &= __ballot(top.passes(ctk[jj], 0u, e.doc[jj]));
+          }
         }
       }
     }
@@ -343,12 +386,16 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
   // ---- write this slice's candidates (sorted best-first; sentinel-padded) ----
   int32_t *otk = p.slice_tk + (size_t)slice * k;
   uint32_t *odoc = p.slice_doc + (size_t)slice * k;
+  if constexpr (BUF) {
+    btop.write_out(otk, odoc, k, lane, (const uint32_t *)gdel);
+  } else {
 #pragma unroll
-  for (int r = 0; r < KREGS; r++) {
-    const uint32_t pos = lane * KREGS + r;
-    if (pos < k) {
-      otk[pos] = top.tk[r];
-      odoc[pos] = top.doc[r];
+    for (int r = 0; r < KREGS; r++) {
+      const uint32_t pos = lane * KREGS + r;
+      if (pos < k) {
+        otk[pos] = top.tk[r];
+        odoc[pos] = top.doc[r];
+      }
     }
   }
   if (p.q_scored && lane == 0 && n_scored) atomicAdd(&p.q_scored[s.q], n_scored);

@@ -118,6 +118,24 @@ def test_deleted_docs_and_stats(gpu, oracle):
         assert pruned[4][q].scored_docs <= want[4][q].scored_docs
 
 
+def test_deleted_winners_do_not_seed_the_threshold(gpu, oracle):
+    """Every query's best 30 docs are deleted: a threshold seed (champion impacts) computed from
+    deleted postings would prune the docs that now win."""
+    rng = np.random.default_rng(15)
+    seg = random_segment(rng, 4000, 24, 20)
+    offs, terms, w = random_queries(rng, 12, 3, 24)
+    first = _oracle_batch(oracle, [seg], offs, terms, w, 31)
+    dead = sorted({int(first[0][q, i]) for q in range(12) for i in range(int(first[3][q]))})
+    seg.set_deleted(dead)
+    want = _oracle_batch(oracle, [seg], offs, terms, w, 11)
+    assert not (set(want[0][:, :5].ravel().tolist()) & set(dead))
+    with gpu.GpuIndex([seg]) as ix:
+        for strat in (gpu.Bm25, gpu.Wand, gpu.Bmw):
+            assert_same_hits(ix.search_batch(offs, terms, w, 11, strat), want, 0.0, "dead winners")
+        assert_same_hits(ix.search_batch(offs, terms, w, 101), _oracle_batch(oracle, [seg], offs, terms, w, 101),
+                         0.0, "dead winners, k=101")
+
+
 def test_ragged_and_empty_inputs(gpu, oracle):
     rng = np.random.default_rng(3)
     seg = random_segment(rng, 300, 12, 10)
