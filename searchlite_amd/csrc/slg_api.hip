@@ -142,6 +142,7 @@ struct slg_batch {
   const slg::TermRef *d_terms = nullptr;
   const uint32_t *d_slice_sq = nullptr;
   const uint32_t *d_slice_seg = nullptr;
+  const uint32_t *d_slice_order = nullptr;
   const uint32_t *d_bnd_sq = nullptr;
   const slg::QueryRef *d_queries = nullptr;
   DevBuf d_bounds, d_rdoc, d_slice_tk, d_slice_doc, d_q_scored;
@@ -643,6 +644,10 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
         env_u32("SLG_ROUNDS_PER_SLICE", b->uniform && k <= 64 ? slg::kUniRoundsPerSlice
                                                                : slg::kDefaultRoundsPerSlice),
         slg::kMaxRoundsPerSlice));
+    const bool rps_pinned = getenv("SLG_ROUNDS_PER_SLICE") != nullptr;
+    const uint32_t rps_cap = std::max<uint32_t>(max_rps, std::min<uint32_t>(
+        env_u32("SLG_MAX_ROUNDS_PER_SLICE", slg::kMaxRoundsPerSlice), slg::kMaxRoundsPerSlice));
+    const uint32_t slices_per_sq = std::max<uint32_t>(1, env_u32("SLG_SLICES_PER_SUBQUERY", 16));
     for (size_t i = 0; i < sqs.size(); i++) {
       slg::RoundQuery &sq = sqs[i];
       const uint32_t dfL = terms[sq.term_begin + sq.longest].df;
@@ -661,7 +666,12 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
       uint64_t nr = (sq_postings[i] + round_target - 1) / round_target;
       nr = std::max<uint64_t>(nr, (sq_postings_all[i] + probe_target - 1) / probe_target);
       nr = std::max<uint64_t>(1, std::min<uint64_t>(nr, dfL));
-      const uint32_t rps = std::max<uint32_t>(1, std::min<uint32_t>(max_rps, 64 / sq.n_terms - 1));
+      // sub-queries with many rounds get longer slices (fewer candidate lists for the merge,
+      // whose time is set by the heaviest query); they are launched first (slice_order below)
+      uint32_t want_rps = max_rps;
+      if (!rps_pinned) want_rps = (uint32_t)std::min<uint64_t>(
+          std::max<uint64_t>(max_rps, (nr + slices_per_sq - 1) / slices_per_sq), rps_cap);
+      const uint32_t rps = std::max<uint32_t>(1, std::min<uint32_t>(want_rps, 64 / sq.n_terms - 1));
       const uint64_t S = (nr + rps - 1) / rps;
       SLG_REQUIRE(nr < 0x7FFFFFFFull && slice_sq.size() + S < 0x7FFFFFFFull &&
                       (slice_sq.size() + S) * (uint64_t)std::max<uint32_t>(k, 1) < 0xFFFFFFFFull,
@@ -691,6 +701,26 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
         qrefs[q].slice_end = sqs[e - 1].slice_begin + sqs[e - 1].n_slices;
       }
     }
+    // launch order: slices with the most rounds first (counting sort, stable), so the short
+    // ones fill the tail of the launch
+    std::vector<uint32_t> slice_order(slice_sq.size());
+    {
+      std::vector<uint32_t> nrounds(slice_sq.size());
+      uint32_t hist[slg::kMaxRoundsPerSlice + 2] = {0};
+      for (size_t i = 0; i < sqs.size(); i++) {
+        const slg::RoundQuery &sq = sqs[i];
+        for (uint32_t j = 0; j < sq.n_slices; j++) {
+          const uint32_t r0 = j * sq.rounds_per_slice;
+          const uint32_t n = std::min<uint32_t>(sq.rounds_per_slice, sq.n_rounds - r0);
+          nrounds[sq.slice_begin + j] = n;
+          hist[slg::kMaxRoundsPerSlice - n + 1]++;  // bucket 0 = most rounds
+        }
+      }
+      for (int i = 1; i <= slg::kMaxRoundsPerSlice + 1; i++) hist[i] += hist[i - 1];
+      const bool lpt = env_u32("SLG_NO_SLICE_ORDER", 0) == 0;
+      for (size_t sidx = 0; sidx < slice_sq.size(); sidx++)
+        slice_order[lpt ? hist[slg::kMaxRoundsPerSlice - nrounds[sidx]]++ : sidx] = (uint32_t)sidx;
+    }
     b->n_sq = (uint32_t)sqs.size();
     b->n_terms = (uint32_t)terms.size();
     b->n_slices = (uint32_t)slice_sq.size();
@@ -703,6 +733,7 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
     const size_t o_slice = place<uint32_t>(cur, slice_sq.size());
     const size_t o_bnd = place<uint32_t>(cur, bnd_sq.size());
     const size_t o_sseg = place<uint32_t>(cur, slice_seg.size());
+    const size_t o_sord = place<uint32_t>(cur, slice_order.size());
     const size_t o_q = place<slg::QueryRef>(cur, qrefs.size());
     const size_t total = (cur + 15) & ~(size_t)15;
     void *hbuf = nullptr;
@@ -717,6 +748,7 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
     if (!slice_sq.empty()) std::memcpy(hb + o_slice, slice_sq.data(), slice_sq.size() * 4);
     if (!bnd_sq.empty()) std::memcpy(hb + o_bnd, bnd_sq.data(), bnd_sq.size() * 4);
     if (!slice_seg.empty()) std::memcpy(hb + o_sseg, slice_seg.data(), slice_seg.size() * 4);
+    if (!slice_order.empty()) std::memcpy(hb + o_sord, slice_order.data(), slice_order.size() * 4);
     if (!qrefs.empty()) std::memcpy(hb + o_q, qrefs.data(), qrefs.size() * sizeof(slg::QueryRef));
     b->d_desc.alloc(total);
     SLG_HIP(hipMemcpyAsync(b->d_desc.p, hbuf, total, hipMemcpyHostToDevice, ix->stream));
@@ -726,6 +758,7 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
     b->d_slice_sq = reinterpret_cast<const uint32_t *>(db + o_slice);
     b->d_bnd_sq = reinterpret_cast<const uint32_t *>(db + o_bnd);
     b->d_slice_seg = reinterpret_cast<const uint32_t *>(db + o_sseg);
+    b->d_slice_order = reinterpret_cast<const uint32_t *>(db + o_sord);
     b->d_queries = reinterpret_cast<const slg::QueryRef *>(db + o_q);
 
     b->d_bounds.alloc((size_t)n_bounds * 4);
@@ -778,6 +811,7 @@ int slg_batch_run(slg_batch *b) {
       sp.sq = b->d_sq;
       sp.terms = b->d_terms;
       sp.slice_sq = b->d_slice_sq;
+      sp.slice_order = b->d_slice_order;
       sp.segs = ix->d_segs.as<slg::SegDev>();
       sp.bounds = b->d_bounds.as<uint32_t>();
       sp.rdoc = b->d_rdoc.as<uint32_t>();

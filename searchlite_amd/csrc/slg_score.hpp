@@ -143,6 +143,7 @@ struct RoundScoreParams {
   const RoundQuery *sq;
   const TermRef *terms;
   const uint32_t *slice_sq;
+  const uint32_t *slice_order;  // [n_slices] wave w runs slice slice_order[w] (most rounds first)
   const SegDev *segs;
   const uint32_t *bounds;
   const uint32_t *rdoc;
@@ -208,8 +209,9 @@ __global__ void __launch_bounds__(256) score_rounds_kernel(RoundScoreParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wib = threadIdx.x >> 6;
-  const uint32_t slice = rfl(blockIdx.x * kWavesPerBlock + wib);
-  if (slice >= p.n_slices) return;  // waves are independent: no workgroup barrier anywhere
+  const uint32_t widx = rfl(blockIdx.x * kWavesPerBlock + wib);
+  if (widx >= p.n_slices) return;  // waves are independent: no workgroup barrier anywhere
+  const uint32_t slice = rfl(p.slice_order[widx]);
 
   uint32_t *bm = reinterpret_cast<uint32_t *>(smem + (size_t)wib * kScoreWaveLds);
   uint32_t *pre = bm + kSpanWords;

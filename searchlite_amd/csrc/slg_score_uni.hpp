@@ -35,8 +35,9 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wib = threadIdx.x >> 6;
-  const uint32_t slice = rfl(blockIdx.x * (blockDim.x >> 6) + wib);
-  if (slice >= p.n_slices) return;  // waves are independent: no workgroup barrier anywhere
+  const uint32_t widx = rfl(blockIdx.x * (blockDim.x >> 6) + wib);
+  if (widx >= p.n_slices) return;  // waves are independent: no workgroup barrier anywhere
+  const uint32_t slice = rfl(p.slice_order[widx]);
 
   constexpr bool BUF = uni_buffered(KREGS);
   uint32_t *bm = reinterpret_cast<uint32_t *>(smem + (size_t)wib * uni_wave_lds(KREGS));
