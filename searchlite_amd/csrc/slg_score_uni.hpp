@@ -69,9 +69,12 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
     my_w = tr.weight;
     my_term = tr.term;
   }
+  const uint32_t my_off_lo = (uint32_t)my_off, my_off_hi = (uint32_t)(my_off >> 32);
   // all cut points of the slice in one register (lane i: bounds[r0*T + i]); round doc starts
   const uint32_t bflat = lane < (n_r + 1) * T ? p.bounds[s.bounds_begin + r0 * T + lane] : 0u;
   const uint32_t dflat = lane <= n_r ? p.rdoc[s.rdoc_begin + r0 + lane] : 0u;
+  // lane i = r*T + t: postings of list t in round r
+  const uint32_t dcnt = __shfl(bflat, (lane + T) & 63u, 64) - bflat;
 
   WaveTopK<BUF ? 1 : KREGS, false> top;  // k > 256
   BufTopK<BUF ? KREGS : 1> btop;          // k <= 256
@@ -98,47 +101,84 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
 
-  // One round's postings: slot jj holds <= 64 postings of one list.  The slot descriptors
-  // live across lanes: lane jj of st / scnt / sb_lo / sb_hi describes slot jj.
+  // One round's postings: slot jj holds <= 64 postings of one list.  A slot is described by one
+  // lane of a Desc (list, postings in the slot, 64-bit index of its first posting); the slots of
+  // a round are the 8 lanes starting at `dbase`.
+  struct Desc {
+    uint32_t st, cnt, lo, hi;
+    uint32_t nsl;  // slots the round needs (> NS: it does not fit and is streamed in chunks)
+  };
   struct URound {
     uint32_t doc[NS];
     float imp[NS];
-    uint32_t st, scnt, sb_lo, sb_hi;
-    uint32_t nslots;  // uniform: slots needed (> NS: does not fit)
+    uint32_t st;      // copy of the Desc's list ids (the Desc may be rebuilt while this round waits)
+    uint32_t dbase;   // uniform: first descriptor lane of this round
+    uint32_t nslots;  // uniform
   };
 
-  // ---- slot descriptors for per-list ranges [lo, lo+cnt) (lane t holds list t's values) ----
-  auto describe = [&](URound &r, const uint32_t lo, const uint32_t cnt) {
+  // ---- descriptors of 8 consecutive planned rounds at once: lane 8*i + j = slot j of round
+  //      g0 + i (per-round cost: a few readlanes instead of a prefix scan over the lists) ----
+  auto describe_group = [&](Desc &d, const uint32_t g0) {
+    const uint32_t ri = g0 + (lane >> 3), j = lane & 7u;
+    const bool rv = ri < n_r;
+    uint32_t run = 0;  // slots of the lists before list t
+    d.st = 0;
+    d.cnt = 0;
+    d.lo = 0;
+    d.hi = 0;
+    for (uint32_t t = 0; t < T; t++) {
+      const uint32_t src = (ri * T + t) & 63u;
+      const uint32_t lo_t = __shfl(bflat, (int)src, 64);
+      const uint32_t c_t = __shfl(dcnt, (int)src, 64);
+      const uint32_t m = rv ? (c_t + 63u) >> 6 : 0u;
+      const bool mine = j >= run && j < run + m;
+      const uint32_t kin = (j - run) * 64u;  // postings of the list before this slot
+      const uint64_t base = (((uint64_t)rl(my_off_hi, t) << 32) | rl(my_off_lo, t)) + lo_t + kin;
+      const uint32_t left = c_t - kin;
+      d.st = mine ? t : d.st;
+      d.cnt = mine ? (left < 64u ? left : 64u) : d.cnt;
+      d.lo = mine ? (uint32_t)base : d.lo;
+      d.hi = mine ? (uint32_t)(base >> 32) : d.hi;
+      run += m;
+    }
+    d.nsl = run;
+  };
+
+  // ---- descriptors for per-list ranges [lo, lo+cnt) held in lane t (chunks of an over-full
+  //      round); lane j = slot j ----
+  auto describe_chunk = [&](Desc &d, const uint32_t lo, const uint32_t cnt) {
     const uint32_t m = (cnt + 63u) >> 6;  // slots of my list
     uint32_t ss = 0, run = 0;             // ss: first slot of my list
     for (uint32_t t = 0; t < T; t++) {
       ss = lane == t ? run : ss;
       run += rl(m, t);
     }
-    r.nslots = run;
+    d.nsl = run;
     // lane j: which list owns slot j = the last list whose first slot is <= j
     uint32_t tj = 0;
     for (uint32_t t = 1; t < T; t++) tj = lane >= rl(ss, t) ? t : tj;
     const uint32_t l_ss = __shfl(ss, (int)tj, 64), l_cnt = __shfl(cnt, (int)tj, 64);
-    const uint64_t l_abs = (((uint64_t)__shfl((uint32_t)(my_off >> 32), (int)tj, 64) << 32) |
-                            __shfl((uint32_t)my_off, (int)tj, 64)) +
+    const uint64_t l_abs = (((uint64_t)__shfl(my_off_hi, (int)tj, 64) << 32) |
+                            __shfl(my_off_lo, (int)tj, 64)) +
                            __shfl(lo, (int)tj, 64);
-    const uint32_t kin = (lane - l_ss) * 64u;  // postings of the list before this slot
+    const uint32_t kin = (lane - l_ss) * 64u;
     const bool used = lane < run && lane < (uint32_t)NS;
     const uint32_t left = used && l_cnt > kin ? l_cnt - kin : 0u;
-    r.st = tj;
-    r.scnt = left < 64u ? left : 64u;
+    d.st = tj;
+    d.cnt = left < 64u ? left : 64u;
     const uint64_t base = l_abs + kin;
-    r.sb_lo = (uint32_t)base;
-    r.sb_hi = (uint32_t)(base >> 32);
+    d.lo = (uint32_t)base;
+    d.hi = (uint32_t)(base >> 32);
   };
 
-  // ---- issue the loads of a described round ----
-  auto issue = [&](URound &r) {
+  // ---- issue the loads of the round described by lanes dbase .. dbase+7 of d ----
+  auto issue = [&](URound &r, const Desc &d, const uint32_t dbase) {
+    r.st = d.st;
+    r.dbase = dbase;
 #pragma unroll
     for (int jj = 0; jj < NS; jj++) {
-      const uint32_t c = rl(r.scnt, jj);
-      const uint64_t base = ((uint64_t)rl(r.sb_hi, jj) << 32) | rl(r.sb_lo, jj);
+      const uint32_t c = rl(d.cnt, dbase + jj);
+      const uint64_t base = ((uint64_t)rl(d.hi, dbase + jj) << 32) | rl(d.lo, dbase + jj);
       r.doc[jj] = kDocEnd;  // idle lanes: never inside any doc window
       r.imp[jj] = 0.0f;
       if (lane < c) {
@@ -200,7 +240,7 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
       }
 #pragma unroll
       for (int jj = 0; jj < NS; jj++) {
-        const float w = __int_as_float((int)rl((uint32_t)__float_as_int(my_w), rl(e.st, jj)));
+        const float w = __int_as_float((int)rl((uint32_t)__float_as_int(my_w), rl(e.st, e.dbase + jj)));
         slot[jj] = (pf[jj] + __popc(wd[jj] & (bit[jj] - 1u))) & (kUniCap - 1);
         if (bit[jj] != 0u) e.imp[jj] = e.imp[jj] * w;  // each posting is valid in one window
         const bool own = (ownmask >> jj) & 1u;
@@ -305,23 +345,28 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
   //      a round that needs more than NS slots is streamed in chunks cut at a common doc id.
   //      Both paths and all doc windows share ONE accumulate site (code size / I-cache). ----
   URound ew, en;
-  uint32_t lo_n, hi_n;
-  cuts(0, lo_n, hi_n);
-  describe(en, lo_n, hi_n - lo_n);
-  if (en.nslots <= (uint32_t)NS) issue(en);
+  Desc G, C;  // descriptors of the current group of 8 planned rounds / of the current chunk
+  describe_group(G, 0);
+  en.nslots = rl(G.nsl, 0);
+  en.st = G.st;
+  en.dbase = 0;
+  if (en.nslots <= (uint32_t)NS) issue(en, G, 0);
   for (uint32_t rr = 0; rr < n_r; rr++) {
     const bool big = en.nslots > (uint32_t)NS;
-    uint32_t ocur = lo_n;
-    const uint32_t oend = hi_n;
+    uint32_t ocur = 0, oend = 0;
+    if (big) cuts(rr, ocur, oend);
     if (!big) ew = en;
 #ifdef SLG_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     SLG_STAMP(6);
     if (rr + 1 < n_r) {  // prefetch the next round
-      cuts(rr + 1, lo_n, hi_n);
-      describe(en, lo_n, hi_n - lo_n);
-      if (en.nslots <= (uint32_t)NS) issue(en);
+      const uint32_t nx = rr + 1, db = (nx & 7u) * 8u;
+      if (db == 0) describe_group(G, nx);
+      en.nslots = rl(G.nsl, db);
+      en.st = G.st;
+      en.dbase = db;
+      if (en.nslots <= (uint32_t)NS) issue(en, G, db);
     }
     uint32_t dlo = rl(dflat, rr), dhi = rl(dflat, rr + 1);
     SLG_STAMP(0);
@@ -347,8 +392,9 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
         uint32_t lastdoc = kDocEnd, firstdoc = kDocEnd;
         if (chunk < rem) lastdoc = gdocs[my_off + ocur + chunk - 1];
         if (rem > 0) firstdoc = gdocs[my_off + ocur];
-        describe(ew, ocur, chunk);
-        issue(ew);
+        describe_chunk(C, ocur, chunk);
+        ew.nslots = C.nsl;
+        issue(ew, C, 0);
         uint32_t bound = kDocEnd;
         dlo = kDocEnd;
         for (uint32_t t = 0; t < T; t++) {
@@ -362,7 +408,7 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
 #pragma unroll
         for (int jj = 0; jj < NS; jj++) {
           const uint32_t cnt = (uint32_t)__popcll(__ballot(ew.doc[jj] < dhi));
-          consumed += lane == rl(ew.st, jj) ? cnt : 0u;
+          consumed += lane == rl(ew.st, jj) ? cnt : 0u;  // chunk descriptors: dbase 0
           ew.doc[jj] = ew.doc[jj] < dhi ? ew.doc[jj] : kDocEnd;  // the rest: next chunk
         }
         ocur += consumed;
