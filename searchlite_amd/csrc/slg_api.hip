@@ -276,8 +276,12 @@ void stage_segment(slg_index *ix, SegHost &sh, const slg_segment_desc &d) {
   const uint64_t P = sh.term_offsets[d.n_terms];
   sh.n_postings = P;
 
-  sh.d_docs.alloc(P * 4);
-  sh.d_imps.alloc(P * 4);
+  // + 64 entries: the scoring kernels load whole 64-lane slots (lanes past a slot's count are
+  // masked after the load), so a slot that starts near the end of the arrays reads past P
+  sh.d_docs.alloc((P + 64) * 4);
+  sh.d_imps.alloc((P + 64) * 4);
+  SLG_HIP(hipMemsetAsync(static_cast<char *>(sh.d_docs.p) + P * 4, 0xFF, 64 * 4, st));
+  SLG_HIP(hipMemsetAsync(static_cast<char *>(sh.d_imps.p) + P * 4, 0, 64 * 4, st));
   ix->device_bytes += sh.d_docs.bytes + sh.d_imps.bytes;
   if (d.deleted) {
     const size_t words = ((size_t)d.n_docs + 31) / 32;

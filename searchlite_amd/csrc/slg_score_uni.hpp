@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
   struct URound {
     uint32_t doc[NS];
     float imp[NS];
-    uint32_t st;      // copy of the Desc's list ids (the Desc may be rebuilt while this round waits)
+    uint32_t st, cnt;  // copies of the Desc's list ids / counts (it may be rebuilt meanwhile)
     uint32_t dbase;   // uniform: first descriptor lane of this round
     uint32_t nslots;  // uniform
   };
@@ -171,20 +171,31 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
     d.hi = (uint32_t)(base >> 32);
   };
 
-  // ---- issue the loads of the round described by lanes dbase .. dbase+7 of d ----
+  // ---- issue the loads of the round described by lanes dbase .. dbase+7 of d: whole 64-lane
+  //      slots, scalar base + lane (no per-lane predicate; the arrays are padded by 64 entries).
+  //      Lanes past the slot's count hold other postings until settle() masks them. ----
   auto issue = [&](URound &r, const Desc &d, const uint32_t dbase) {
     r.st = d.st;
+    r.cnt = d.cnt;
     r.dbase = dbase;
 #pragma unroll
     for (int jj = 0; jj < NS; jj++) {
-      const uint32_t c = rl(d.cnt, dbase + jj);
       const uint64_t base = ((uint64_t)rl(d.hi, dbase + jj) << 32) | rl(d.lo, dbase + jj);
-      r.doc[jj] = kDocEnd;  // idle lanes: never inside any doc window
-      r.imp[jj] = 0.0f;
-      if (lane < c) {
-        r.doc[jj] = gdocs[base + lane];
-        r.imp[jj] = gimps[base + lane];
-      }
+      r.doc[jj] = gdocs[base + lane];
+      r.imp[jj] = gimps[base + lane];
+    }
+  };
+  // ---- dst = the loaded round src with the lanes beyond each slot's count turned into idle
+  //      lanes (kDocEnd is never inside a doc window) ----
+  auto settle = [&](URound &dst, const URound &src) {
+    dst.st = src.st;
+    dst.cnt = src.cnt;
+    dst.dbase = src.dbase;
+    dst.nslots = src.nslots;
+#pragma unroll
+    for (int jj = 0; jj < NS; jj++) {
+      dst.doc[jj] = lane < rl(src.cnt, src.dbase + jj) ? src.doc[jj] : kDocEnd;
+      dst.imp[jj] = src.imp[jj];
     }
   };
 
@@ -355,7 +366,7 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
     const bool big = en.nslots > (uint32_t)NS;
     uint32_t ocur = 0, oend = 0;
     if (big) cuts(rr, ocur, oend);
-    if (!big) ew = en;
+    if (!big) settle(ew, en);
 #ifdef SLG_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -395,6 +406,7 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
         describe_chunk(C, ocur, chunk);
         ew.nslots = C.nsl;
         issue(ew, C, 0);
+        settle(ew, ew);
         uint32_t bound = kDocEnd;
         dlo = kDocEnd;
         for (uint32_t t = 0; t < T; t++) {
