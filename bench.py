@@ -43,6 +43,9 @@ def parse_args():
     ap.add_argument("--terms", type=int, default=0)
     ap.add_argument("--limit", type=int, default=0)
     ap.add_argument("--strategy", default="wand", choices=["bm25", "wand", "bmw"])
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="prepared batches in flight, each on its own HIP stream (steps go "
+                         "round-robin over them; every step still does the whole batch's work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=0, help="queries in the CPU sample")
     ap.add_argument("--check", type=int, default=64, help="queries parity-checked vs the oracle")
@@ -118,7 +121,16 @@ def main():
     index = searcher.GpuIndex([seg], device=local_rank)
     stream = torch.cuda.current_stream()
     index.set_stream(stream.cuda_stream)
-    batch = index.prepare(offs, terms, w, k, strategy)
+    # several batches in flight (separate work buffers, separate HIP streams): the partition /
+    # merge kernels of one batch overlap the scoring kernel of another.  Not combined with the
+    # rerank stage or the cross-shard merge, which run on the index stream.
+    inflight = max(1, args.inflight) if not (rerank or shard_mode) else 1
+    batches = [index.prepare(offs, terms, w, k, strategy) for _ in range(inflight)]
+    streams = [torch.cuda.Stream() for _ in range(inflight)] if inflight > 1 else [stream]
+    if inflight > 1:
+        for b_, s_ in zip(batches, streams):
+            b_.set_stream(s_.cuda_stream)
+    batch = batches[0]
     info = batch.info()
     d_doc, d_seg, d_score, d_count = batch.device_results()
     t_doc = torch.as_tensor(_DevArray(d_doc, (nq, k), "<i4"), device="cuda")
@@ -126,9 +138,12 @@ def main():
     t_score = torch.as_tensor(_DevArray(d_score, (nq, k), "<f4"), device="cuda")
     t_count = torch.as_tensor(_DevArray(d_count, (nq,), "<i4"), device="cuda")
     if use_dist:
-        blk_ptr, blk_bytes = batch.device_result_block()
-        t_block = torch.as_tensor(_DevArray(blk_ptr, (blk_bytes // 4,), "<i4"), device="cuda")
-        g_block = torch.empty((world * (blk_bytes // 4),), dtype=torch.int32, device="cuda")
+        t_blocks, g_blocks = [], []
+        for b_ in batches:
+            blk_ptr, blk_bytes = b_.device_result_block()
+            t_blocks.append(torch.as_tensor(_DevArray(blk_ptr, (blk_bytes // 4,), "<i4"), device="cuda"))
+            g_blocks.append(torch.empty((world * (blk_bytes // 4),), dtype=torch.int32, device="cuda"))
+        t_block, g_block = t_blocks[0], g_blocks[0]
         m_doc = torch.empty((nq, k), dtype=torch.int32, device="cuda")
         m_seg = torch.empty_like(m_doc)
         m_score = torch.empty((nq, k), dtype=torch.float32, device="cuda")
@@ -147,8 +162,17 @@ def main():
         ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
         ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     step_no = [0]
+    turn = [0]
 
     def step():
+        if inflight > 1:
+            i = turn[0] % inflight
+            turn[0] += 1
+            batches[i].run()
+            if use_dist:  # replica mode: one all-gather of this batch's block, on its stream
+                with torch.cuda.stream(streams[i]):
+                    dist.all_gather_into_tensor(g_blocks[i], t_blocks[i])
+            return
         batch.run()
         if rerank:  # candidates = the BM25 pass's device results (no host round trip)
             timed = step_no[0] >= args.warmup
@@ -184,13 +208,22 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    index.profile(True)
-    index.profile_read()
+    if inflight == 1:
+        index.profile(True)
+        index.profile_read()
     t1 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t1
+    if inflight > 1:
+        # scoring-kernel duration (HIP events on the kernel's stream): measured on one batch
+        # running alone, after the timed region, so overlap with other batches does not blur it
+        index.profile(True)
+        index.profile_read()
+        for _ in range(max(5, min(args.steps, 20))):
+            batch.run()
+        fence()
     n_launch, kern_ms = index.profile_read()
     index.profile(False)
     if use_dist:
@@ -230,7 +263,7 @@ def main():
                                    f"top-{limit} (k={k}), strategy={args.strategy}, "
                                    f"{'index-sharded' if shard_mode else 'query-sharded replicas'}",
                        "postings_per_batch": int(info["n_postings"]),
-                       "slices": int(info["n_slices"]),
+                       "slices": int(info["n_slices"]), "batches_in_flight": inflight,
                        "all_ranks_postings": int(total_postings),
                        "corpus_build_s": round(t_corpus, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -254,6 +287,11 @@ def main():
     if rank == 0:
         from oracle import oracle as O
         got = batch.fetch()
+        for b_ in batches[1:]:  # every in-flight batch computed the same results
+            other = b_.fetch()
+            if not all(np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32))
+                       for x, y in zip(got[:4], other[:4])):
+                raise SystemExit("bench.py: in-flight batches disagree")
         nchk = min(args.check, nq)
         if nchk:
             want = O.search_batch([seg], offs[:nchk + 1], terms[:nchk * T], w[:nchk * T], k,
@@ -312,7 +350,8 @@ def main():
                 "gpu_over_cpu": round(value / strict, 1)}
         print(json.dumps(out), flush=True)
 
-    batch.close()
+    for b_ in batches:
+        b_.close()
     index.close()
     if use_dist:
         dist.barrier()

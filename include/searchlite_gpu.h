@@ -155,8 +155,13 @@ int slg_search_batch(slg_index *index, const slg_query *queries, uint32_t nq, ui
 slg_batch *slg_batch_prepare(slg_index *index, uint32_t nq, const uint32_t *q_offsets,
                              const uint32_t *q_term_ids, const float *q_weights, uint32_t k,
                              int strategy);
-/* Enqueue the partition / score / merge kernels on the index stream (asynchronous). */
+/* Enqueue the partition / score / merge kernels on the batch's stream (asynchronous). */
 int slg_batch_run(slg_batch *batch);
+/* Run this batch on its own HIP stream instead of the index stream, so several prepared
+ * batches can be in flight at once (their partition / merge kernels then overlap the other
+ * batches' scoring).  A batch owns all its work buffers; batches never share state.
+ * SLG_OWN_STREAM returns the batch to the index stream. */
+int slg_batch_set_stream(slg_batch *batch, void *hip_stream);
 /* Wait for everything enqueued for this batch. */
 int slg_batch_sync(slg_batch *batch);
 /* Copy results to host arrays (nq*k, nq); waits for completion. */

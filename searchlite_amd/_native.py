@@ -88,6 +88,7 @@ def load():
         "slg_search_batch": (i32, [vp, vp, u32, u32, i32, vp, vp, vp, vp, vp]),
         "slg_batch_prepare": (vp, [vp, u32, vp, vp, vp, u32, i32]),
         "slg_batch_run": (i32, [vp]),
+        "slg_batch_set_stream": (i32, [vp, vp]),
         "slg_batch_sync": (i32, [vp]),
         "slg_batch_fetch": (i32, [vp, vp, vp, vp, vp, vp]),
         "slg_batch_device_results": (i32, [vp, vp, vp, vp, vp]),

@@ -137,6 +137,8 @@ struct slg_batch {
   bool uniform = false;  // every sub-query fits the one-list-per-slot kernel
   uint64_t n_postings = 0, n_postings_essential = 0, n_rounds = 0;
   std::vector<uint64_t> q_postings;  // per query (stats.postings_advanced)
+  bool own_stream_set = false;       // slg_batch_set_stream: run on `stream` instead of the index's
+  hipStream_t stream = nullptr;
   DevBuf d_desc;                     // packed descriptors
   const slg::RoundQuery *d_sq = nullptr;
   const slg::TermRef *d_terms = nullptr;
@@ -266,6 +268,10 @@ void validate_segment(const slg_segment_desc &d, uint32_t si) {
         SLG_REQUIRE(d.vec_offsets[i] == SLG_NO_VECTOR || d.vec_offsets[i] < d.vec_rows,
                     pfx + "vec_offsets out of range");
   }
+}
+
+static inline hipStream_t batch_stream(const slg_batch *b) {
+  return b->own_stream_set ? b->stream : b->idx->stream;
 }
 
 void stage_segment(slg_index *ix, SegHost &sh, const slg_segment_desc &d) {
@@ -792,7 +798,7 @@ int slg_batch_run(slg_batch *b) {
     slg_index *ix = b->idx;
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
-    hipStream_t st = ix->stream;
+    hipStream_t st = batch_stream(b);
     if (b->nq == 0) return;
     if (b->n_slices == 0) SLG_HIP(hipMemsetAsync(b->d_q_scored.p, 0, (size_t)b->nq * 4, st));
     if (b->n_slices > 0) {
@@ -867,7 +873,7 @@ int slg_batch_sync(slg_batch *b) {
   return guarded([&] {
     SLG_REQUIRE(b != nullptr, "batch is NULL");
     DeviceGuard g(b->idx->device);
-    SLG_HIP(hipStreamSynchronize(b->idx->stream));
+    SLG_HIP(hipStreamSynchronize(batch_stream(b)));
   });
 }
 
@@ -880,7 +886,7 @@ int slg_batch_fetch(slg_batch *b, uint32_t *out_doc, uint32_t *out_seg, float *o
     slg_index *ix = b->idx;
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
-    hipStream_t st = ix->stream;
+    hipStream_t st = batch_stream(b);
     const size_t n = (size_t)b->nq * b->k;
     if (n) {
       SLG_HIP(hipMemcpyAsync(out_doc, b->d_out_doc, n * 4, hipMemcpyDeviceToHost, st));
@@ -939,18 +945,30 @@ int slg_batch_info(const slg_batch *b, uint64_t *n_postings, uint32_t *n_slices,
 #ifdef SLG_STAMPS
 int slg_debug_read_stamps(slg_batch *b, unsigned long long *out, uint32_t n_slices) {
   return guarded([&] {
-    SLG_HIP(hipStreamSynchronize(b->idx->stream));
+    SLG_HIP(hipStreamSynchronize(batch_stream(b)));
     SLG_HIP(hipMemcpy(out, b->d_stamps.p, (size_t)n_slices * 64, hipMemcpyDeviceToHost));
   });
 }
 #endif
+
+int slg_batch_set_stream(slg_batch *b, void *hip_stream) {
+  return guarded([&] {
+    SLG_REQUIRE(b != nullptr, "batch is NULL");
+    slg_index *ix = b->idx;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    SLG_HIP(hipStreamSynchronize(batch_stream(b)));  // work already queued finishes first
+    b->own_stream_set = hip_stream != SLG_OWN_STREAM;
+    b->stream = b->own_stream_set ? (hipStream_t)hip_stream : nullptr;
+  });
+}
 
 void slg_batch_destroy(slg_batch *b) {
   if (!b) return;
   int prev = -1;
   (void)hipGetDevice(&prev);
   (void)hipSetDevice(b->idx->device);
-  (void)hipStreamSynchronize(b->idx->stream);
+  (void)hipStreamSynchronize(batch_stream(b));
   delete b;
   if (prev >= 0) (void)hipSetDevice(prev);
 }

@@ -218,6 +218,12 @@ class PreparedBatch:
     def run(self) -> None:
         N.check(self._lib.slg_batch_run(self._h))
 
+    def set_stream(self, hip_stream) -> None:
+        """Run this batch on its own hipStream_t so several batches can be in flight at once
+        (None: back to the index stream)."""
+        h = C.c_void_p(-1) if hip_stream is None else C.c_void_p(int(hip_stream) or None)
+        N.check(self._lib.slg_batch_set_stream(self._h, h))
+
     def sync(self) -> None:
         N.check(self._lib.slg_batch_sync(self._h))
 

@@ -136,6 +136,30 @@ def test_deleted_winners_do_not_seed_the_threshold(gpu, oracle):
                          0.0, "dead winners, k=101")
 
 
+def test_batches_in_flight_on_their_own_streams(gpu, oracle):
+    """slg_batch_set_stream: prepared batches own their buffers, so several can run at once."""
+    import torch
+    rng = np.random.default_rng(21)
+    seg = random_segment(rng, 6000, 60, 25)
+    qs = [random_queries(rng, 32, 3, 60) for _ in range(3)]
+    wants = [_oracle_batch(oracle, [seg], o, t, w, 11) for o, t, w in qs]
+    with gpu.GpuIndex([seg]) as ix:
+        streams = [torch.cuda.Stream() for _ in qs]
+        batches = [ix.prepare(o, t, w, 11) for o, t, w in qs]
+        for b, s in zip(batches, streams):
+            b.set_stream(s.cuda_stream)
+        for _ in range(4):
+            for b in batches:
+                b.run()
+        for b, want in zip(batches, wants):
+            assert_same_hits(b.fetch(), want, 0.0, "in flight")
+        batches[0].set_stream(None)  # back on the index stream
+        batches[0].run()
+        assert_same_hits(batches[0].fetch(), wants[0], 0.0, "index stream again")
+        for b in batches:
+            b.close()
+
+
 def test_ragged_and_empty_inputs(gpu, oracle):
     rng = np.random.default_rng(3)
     seg = random_segment(rng, 300, 12, 10)
