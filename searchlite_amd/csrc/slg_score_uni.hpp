@@ -185,8 +185,9 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
       r.imp[jj] = gimps[base + lane];
     }
   };
-  // ---- dst = the loaded round src with the lanes beyond each slot's count turned into idle
-  //      lanes (kDocEnd is never inside a doc window) ----
+  // ---- dst = the loaded round src, ready to accumulate: lanes beyond each slot's count become
+  //      idle lanes (kDocEnd is never inside a doc window) and the impacts are multiplied by
+  //      the slot's list weight (score_tf, query/wand.rs:285: one scalar per slot) ----
   auto settle = [&](URound &dst, const URound &src) {
     dst.st = src.st;
     dst.cnt = src.cnt;
@@ -194,8 +195,9 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
     dst.nslots = src.nslots;
 #pragma unroll
     for (int jj = 0; jj < NS; jj++) {
+      const float w = __int_as_float((int)rl((uint32_t)__float_as_int(my_w), rl(src.st, src.dbase + jj)));
       dst.doc[jj] = lane < rl(src.cnt, src.dbase + jj) ? src.doc[jj] : kDocEnd;
-      dst.imp[jj] = src.imp[jj];
+      dst.imp[jj] = src.imp[jj] * w;
     }
   };
 
@@ -209,7 +211,8 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
     // P1: one bit per posting (transposed bitmap: doc d -> word d mod 512, bit d / 512); the
     // returned old word tells which posting of a doc came first = the owner.  Slots are in
     // list order and a slot holds one list, so the owner is the first list in term order.
-    uint32_t wi[NS], bit[NS], ownmask = 0;
+    uint32_t wi[NS], bit[NS];
+    bool own[NS];
     {
       uint32_t oldw[NS];
 #pragma unroll
@@ -220,8 +223,7 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
         oldw[jj] = atomicOr(&bm[wi[jj]], bit[jj]);
       }
 #pragma unroll
-      for (int jj = 0; jj < NS; jj++)
-        ownmask |= (bit[jj] & ~oldw[jj]) != 0u ? (1u << jj) : 0u;
+      for (int jj = 0; jj < NS; jj++) own[jj] = (bit[jj] & ~oldw[jj]) != 0u;
     }
     wave_fence();
     SLG_STAMP(2);
@@ -239,8 +241,9 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
     }
     wave_fence();
     SLG_STAMP(3);
-    // P3a: rank(doc) = accumulator slot; x = impact * weight (score_tf, query/wand.rs:285, the
-    // slot's list weight is a scalar); owners store 0.0 + x (`or_insert(0.0) += score`, :539)
+    // P3a: rank(doc) = accumulator slot (< kUniCap: a round holds <= kUniCap postings; idle
+    // lanes index at most kUniCap + 31, inside the dump words); x = impact * weight (settle());
+    // owners store 0.0 + x (`or_insert(0.0) += score`, query/wand.rs:539)
     uint32_t slot[NS];
     {
       uint32_t wd[NS], pf[NS];
@@ -251,11 +254,8 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
       }
 #pragma unroll
       for (int jj = 0; jj < NS; jj++) {
-        const float w = __int_as_float((int)rl((uint32_t)__float_as_int(my_w), rl(e.st, e.dbase + jj)));
-        slot[jj] = (pf[jj] + __popc(wd[jj] & (bit[jj] - 1u))) & (kUniCap - 1);
-        if (bit[jj] != 0u) e.imp[jj] = e.imp[jj] * w;  // each posting is valid in one window
-        const bool own = (ownmask >> jj) & 1u;
-        vals[own ? slot[jj] : kUniCap + lane] = __float_as_uint(0.0f + e.imp[jj]);
+        slot[jj] = pf[jj] + __popc(wd[jj] & (bit[jj] - 1u));
+        vals[own[jj] ? slot[jj] : kUniCap + lane] = __float_as_uint(0.0f + e.imp[jj]);
       }
     }
     wave_fence();
@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
     // order and slots are in list order, so the sum is ((0.0 + x_a) + x_b) + ... in term order.
 #pragma unroll
     for (int jj = 1; jj < NS; jj++) {
-      const bool later = bit[jj] != 0u && !((ownmask >> jj) & 1u);
+      const bool later = bit[jj] != 0u && !own[jj];
       if (__ballot(later) != 0ull) {
         const uint32_t old = vals[slot[jj]];
         vals[later ? slot[jj] : kUniCap + lane] = __float_as_uint(__uint_as_float(old) + e.imp[jj]);
@@ -278,35 +278,37 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
 #pragma unroll
     for (int jj = 0; jj < NS; jj++) v[jj] = vals[slot[jj]];
     if constexpr (BUF) {
-      uint32_t okey[NS], passmask = 0;
+      uint32_t okey[NS];
+      bool pass[NS];
+      bool any = false;
 #pragma unroll
       for (int jj = 0; jj < NS; jj++) {
-        const bool own = (ownmask >> jj) & 1u;
         okey[jj] = ordered_score(__uint_as_float(v[jj]));
-        passmask |= (own && btop.passes(okey[jj], ~e.doc[jj])) ? (1u << jj) : 0u;
+        pass[jj] = own[jj] && btop.passes(((uint64_t)okey[jj] << 32) | (uint32_t)~e.doc[jj]);
+        any = any || pass[jj];
       }
-      if (__ballot(passmask != 0u) != 0ull) {
+      if (__ballot(any) != 0ull) {
         uint32_t tot = 0;
 #pragma unroll
-        for (int jj = 0; jj < NS; jj++) tot += (uint32_t)__popcll(__ballot((passmask >> jj) & 1u));
+        for (int jj = 0; jj < NS; jj++) tot += (uint32_t)__popcll(__ballot(pass[jj]));
 #ifdef SLG_STAMPS
         st_ins += tot;
 #endif
         if (btop.count + tot <= btop.kEntries) {  // the common case: everything fits
 #pragma unroll
-          for (int jj = 0; jj < NS; jj++)
-            btop.append((passmask >> jj) & 1u, okey[jj], ~e.doc[jj], lane);
+          for (int jj = 0; jj < NS; jj++) btop.append(pass[jj], okey[jj], ~e.doc[jj], lane);
         } else {  // rank-and-trim between slots; one site, slot registers selected at run time
 #pragma unroll 1
           for (uint32_t it = 0; it < (uint32_t)NS; it++) {
             uint32_t ok = okey[0], dc = e.doc[0];
+            bool ps = pass[0];
 #pragma unroll
             for (int j = 1; j < NS; j++) {
               ok = it == (uint32_t)j ? okey[j] : ok;
               dc = it == (uint32_t)j ? e.doc[j] : dc;
+              ps = it == (uint32_t)j ? pass[j] : ps;
             }
-            btop.append_checked(((passmask >> it) & 1u) && btop.passes(ok, ~dc), ok, ~dc, k, lane,
-                                (const uint32_t *)gdel);
+            btop.append_checked(ps && btop.passes(ok, ~dc), ok, ~dc, k, lane, (const uint32_t *)gdel);
           }
         }
       }
@@ -315,9 +317,8 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
       uint32_t passmask = 0;
 #pragma unroll
       for (int jj = 0; jj < NS; jj++) {
-        const bool own = (ownmask >> jj) & 1u;
-        ctk[jj] = own ? total_key(__uint_as_float(v[jj])) : kSentinelTk;
-        passmask |= (own && top.passes(ctk[jj], 0u, e.doc[jj])) ? (1u << jj) : 0u;
+        ctk[jj] = own[jj] ? total_key(__uint_as_float(v[jj])) : kSentinelTk;
+        passmask |= (own[jj] && top.passes(ctk[jj], 0u, e.doc[jj])) ? (1u << jj) : 0u;
       }
       if (__ballot(passmask != 0u) != 0ull) {
 #pragma unroll

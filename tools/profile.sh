@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --check 0"
+ARGS="$REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --check 0 --inflight 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o c2 -- python3 $ARGS > $OUT/trace.log 2>&1
 echo "trace rc=$?" >> $OUT/trace.log
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM --output-format csv -d $OUT/pmc_a -o c2 -- python3 $ARGS > $OUT/pmc_a.log 2>&1
