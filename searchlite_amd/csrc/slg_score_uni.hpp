@@ -18,6 +18,10 @@
 
 #include "slg_score.hpp"
 
+#ifndef SLG_ABL
+#define SLG_ABL 0  // diagnostic builds only (tools/ablate.py): bit i skips a phase; results are wrong
+#endif
+
 namespace slg {
 
 constexpr int kUniSlots = 8;                 // 64-posting slots per round; also max lists
@@ -204,6 +208,10 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
   // ---- accumulate the postings of `e` whose docs lie in [wbase, wbase + wspan) ----
   auto accumulate = [&](URound &e, const uint32_t wbase, const uint32_t wspan) {
     SLG_STAMP(1);
+    if (SLG_ABL & 32) {
+      n_scored += e.doc[0] & 1u;
+      return;
+    }
     // P0: clear the bitmap
     bm4[lane] = make_uint4(0u, 0u, 0u, 0u);
     bm4[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
@@ -218,9 +226,14 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
 #pragma unroll
       for (int jj = 0; jj < NS; jj++) {
         const uint32_t rel = e.doc[jj] - wbase;
-        wi[jj] = rel & (kSpanWords - 1);
+        wi[jj] = (SLG_ABL & 64) ? ((lane * 8u + jj) & (kSpanWords - 1)) : (rel & (kSpanWords - 1));
         bit[jj] = rel < wspan ? 1u << (rel >> 9) : 0u;  // rel < 16384 => rel >> 9 < 32
-        oldw[jj] = atomicOr(&bm[wi[jj]], bit[jj]);
+        if (SLG_ABL & 4) {
+          oldw[jj] = 0;
+          bm[wi[jj]] = bit[jj];
+        } else {
+          oldw[jj] = atomicOr(&bm[wi[jj]], bit[jj]);
+        }
       }
 #pragma unroll
       for (int jj = 0; jj < NS; jj++) own[jj] = (bit[jj] & ~oldw[jj]) != 0u;
@@ -228,7 +241,7 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
     wave_fence();
     SLG_STAMP(2);
     // P2: exclusive prefix popcount (lane l owns words 4l..4l+3 and 256+4l..256+4l+3)
-    {
+    if (!(SLG_ABL & 16)) {
       const uint4 a = bm4[lane], b = bm4[lane + 64];
       const uint32_t c0 = __popc(a.x), c1 = c0 + __popc(a.y), c2 = c1 + __popc(a.z),
                      c3 = c2 + __popc(a.w), c4 = c3 + __popc(b.x), c5 = c4 + __popc(b.y),
@@ -245,7 +258,10 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
     // lanes index at most kUniCap + 31, inside the dump words); x = impact * weight (settle());
     // owners store 0.0 + x (`or_insert(0.0) += score`, query/wand.rs:539)
     uint32_t slot[NS];
-    {
+    if (SLG_ABL & 8) {
+#pragma unroll
+      for (int jj = 0; jj < NS; jj++) slot[jj] = wi[jj];
+    } else {
       uint32_t wd[NS], pf[NS];
 #pragma unroll
       for (int jj = 0; jj < NS; jj++) {
@@ -265,7 +281,7 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
 #pragma unroll
     for (int jj = 1; jj < NS; jj++) {
       const bool later = bit[jj] != 0u && !own[jj];
-      if (__ballot(later) != 0ull) {
+      if (!(SLG_ABL & 1) && __ballot(later) != 0ull) {
         const uint32_t old = vals[slot[jj]];
         vals[later ? slot[jj] : kUniCap + lane] = __float_as_uint(__uint_as_float(old) + e.imp[jj]);
         wave_fence();
@@ -274,6 +290,10 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
     wave_fence();
     SLG_STAMP(4);
     // P4: owners read the finished sums and offer them to the top-k
+    if (SLG_ABL & 2) {
+      n_scored += slot[0] & 1u;
+      return;
+    }
     uint32_t v[NS];
 #pragma unroll
     for (int jj = 0; jj < NS; jj++) v[jj] = vals[slot[jj]];
