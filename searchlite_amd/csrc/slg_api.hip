@@ -148,6 +148,8 @@ struct slg_batch {
   const uint32_t *d_bnd_sq = nullptr;
   const slg::QueryRef *d_queries = nullptr;
   DevBuf d_bounds, d_rdoc, d_slice_tk, d_slice_doc, d_q_scored;
+  bool cand_mode = false;  // uniform kernel, k > 256: candidates + select_topk_kernel
+  DevBuf d_cand, d_slice_cbeg, d_slice_ccnt;
   DevBuf d_out;  // doc | seg | score | count, contiguous
   uint32_t *d_out_doc = nullptr, *d_out_seg = nullptr, *d_out_count = nullptr;
   float *d_out_score = nullptr;
@@ -701,6 +703,16 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
       slice_seg.insert(slice_seg.end(), (size_t)S, sq.seg);
       bnd_sq.insert(bnd_sq.end(), (size_t)(nr + 1), (uint32_t)i);
     }
+    // large k: per-slice top-k lists would be mostly the slice itself; keep every doc above the
+    // seed threshold instead (one candidate slot per posting) and select per query afterwards
+    b->cand_mode = b->uniform && k > 256 && env_u32("SLG_NO_CAND_MODE", 0) == 0;
+    uint64_t cand_total = 0;
+    if (b->cand_mode)
+      for (size_t i = 0; i < sqs.size(); i++) {
+        sqs[i].cand_lo = (uint32_t)cand_total;
+        sqs[i].cand_hi = (uint32_t)(cand_total >> 32);
+        cand_total += sq_postings_all[i];
+      }
     std::vector<slg::QueryRef> qrefs(nq);
     for (uint32_t q = 0; q < nq; q++) {
       const uint32_t a = q_sq_begin[q], e = q_sq_begin[q + 1];
@@ -773,8 +785,14 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
 
     b->d_bounds.alloc((size_t)n_bounds * 4);
     b->d_rdoc.alloc((size_t)n_bnd * 4);
-    b->d_slice_tk.alloc((size_t)b->n_slices * k * 4);
-    b->d_slice_doc.alloc((size_t)b->n_slices * k * 4);
+    if (b->cand_mode) {
+      b->d_cand.alloc((size_t)(cand_total + 1) * 8);
+      b->d_slice_cbeg.alloc((size_t)b->n_slices * 8);
+      b->d_slice_ccnt.alloc((size_t)b->n_slices * 4);
+    } else {
+      b->d_slice_tk.alloc((size_t)b->n_slices * k * 4);
+      b->d_slice_doc.alloc((size_t)b->n_slices * k * 4);
+    }
     b->d_q_scored.alloc((size_t)nq * 4);
     b->d_out.alloc(((size_t)nq * k * 3 + nq) * 4);
     b->d_out_doc = b->d_out.as<uint32_t>();
@@ -822,6 +840,9 @@ int slg_batch_run(slg_batch *b) {
       sp.terms = b->d_terms;
       sp.slice_sq = b->d_slice_sq;
       sp.slice_order = b->d_slice_order;
+      sp.cand = b->d_cand.as<uint2>();
+      sp.slice_cbeg = b->d_slice_cbeg.as<uint64_t>();
+      sp.slice_ccnt = b->d_slice_ccnt.as<uint32_t>();
       sp.segs = ix->d_segs.as<slg::SegDev>();
       sp.bounds = b->d_bounds.as<uint32_t>();
       sp.rdoc = b->d_rdoc.as<uint32_t>();
@@ -850,7 +871,23 @@ int slg_batch_run(slg_batch *b) {
       launch_score(sp, b->max_terms, b->uniform, st);
       if (ev) SLG_HIP(hipEventRecord(ev->second, st));
     }
-    if (b->k > 0) {
+    if (b->k > 0 && b->cand_mode && b->n_slices > 0) {
+      slg::SelectParams sp{};
+      sp.queries = b->d_queries;
+      sp.slice_seg = b->d_slice_seg;
+      sp.slice_cbeg = b->d_slice_cbeg.as<uint64_t>();
+      sp.slice_ccnt = b->d_slice_ccnt.as<uint32_t>();
+      sp.cand = b->d_cand.as<uint2>();
+      sp.segs = ix->d_segs.as<slg::SegDev>();
+      sp.out_doc = b->d_out_doc;
+      sp.out_seg = b->d_out_seg;
+      sp.out_score = b->d_out_score;
+      sp.out_count = b->d_out_count;
+      sp.nq = b->nq;
+      sp.k = b->k;
+      hipLaunchKernelGGL(slg::select_topk_kernel, dim3(b->nq), dim3(slg::kSelectThreads), 0, st, sp);
+      SLG_HIP(hipGetLastError());
+    } else if (b->k > 0) {
       slg::MergeParams mp{};
       mp.queries = b->d_queries;
       mp.slice_seg = b->d_slice_seg;

@@ -57,7 +57,8 @@ struct RoundQuery {  // sub-query = (query, segment) pair with >= 1 non-empty te
   uint32_t bnd_begin;     // first boundary task of this sub-query (partition kernel)
   uint32_t longest;       // index of the longest ESSENTIAL list (splitter source)
   uint32_t ess_mask;      // bit t: list t is essential (MaxScore); the others are only probed
-  uint32_t pad[3];
+  uint32_t pad;
+  uint32_t cand_lo, cand_hi;  // large-k mode: first candidate slot of this sub-query (u64)
 };
 
 struct QueryRef {
@@ -566,6 +567,265 @@ __global__ void __launch_bounds__(256) merge_shards_kernel(ShardMergeParams p) {
     }
   }
   if (lane == 0) p.out_count[q] = top.count;
+}
+
+
+// ---- large k (k > 256): per-query radix select over the candidates the scoring kernel kept ----
+// The uniform scoring kernel, instead of keeping a per-slice top-k, writes every doc whose score
+// beats the seed threshold to its slice's region of `cand` ({ordered score, doc}; the region of
+// slice s starts at slice_cbeg[s] and holds slice_ccnt[s] entries).  One workgroup per query
+// then finds the k best under (score desc, segment asc, doc asc) = the 96-bit key
+// (ordered score, ~segment, ~doc) descending: byte-wise MSB-first radix select with an LDS
+// histogram (a pass per byte until the bucket that holds the k-th key is exactly used up), a
+// gather of the k winners into LDS and a bitonic sort.  push_top_k / finalize_heap
+// (query/wand.rs:905-926) + the cross-segment sort (api/reader.rs:2776-2778) for large k.
+struct SelectParams {
+  const QueryRef *queries;
+  const uint32_t *slice_seg;
+  const uint64_t *slice_cbeg;
+  const uint32_t *slice_ccnt;
+  uint2 *cand;  // .x ordered score, .y doc (0xFFFFFFFF: dropped, e.g. deleted)
+  const SegDev *segs;
+  uint32_t *out_doc, *out_seg;
+  float *out_score;
+  uint32_t *out_count;
+  uint32_t nq, k;
+};
+
+constexpr uint32_t kSelectMaxK = 1024;     // largest k
+constexpr uint32_t kSelectCap = 2048;      // keys sorted in LDS (>= kSelectMaxK)
+constexpr uint32_t kSelectMaxSlices = 1024;  // slice table in LDS; more: strided slice loops
+constexpr uint32_t kSelectThreads = 512;
+
+static __global__ void __launch_bounds__(kSelectThreads) select_topk_kernel(SelectParams p) {
+  constexpr uint32_t NT = kSelectThreads;
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t w_ok[kSelectCap], w_sg[kSelectCap], w_dc[kSelectCap];
+  __shared__ uint32_t sh_pre[3], sh_need, sh_done, sh_nvalid, sh_nwin, sh_anydel, sh_taken;
+  __shared__ uint32_t t_end[kSelectMaxSlices];   // inclusive prefix of the slice counts
+  __shared__ uint32_t t_nseg[kSelectMaxSlices];  // ~segment of the slice
+  __shared__ uint64_t t_base[kSelectMaxSlices];  // first candidate slot of the slice
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t q = blockIdx.x;
+  if (q >= p.nq) return;
+  const uint32_t k = p.k;
+  const QueryRef qr = p.queries[q];
+  const uint32_t sb = qr.slice_begin, se = qr.slice_end, nsl = se - sb;
+  const bool table = nsl <= kSelectMaxSlices;
+
+  if (tid == 0) {
+    sh_nvalid = 0;
+    sh_nwin = 0;
+    sh_anydel = table ? 0u : 1u;
+    sh_pre[0] = sh_pre[1] = sh_pre[2] = 0;
+    sh_need = k;
+    sh_done = 0;
+    sh_taken = 0;
+  }
+  if (tid < 256) hist[tid] = 0;
+  __syncthreads();
+  // slice table: the query's candidates form one flat index space [0, n)
+  if (table) {
+    for (uint32_t i = tid; i < nsl; i += NT) {
+      const uint32_t sg = p.slice_seg[sb + i];
+      t_end[i] = p.slice_ccnt[sb + i];
+      t_base[i] = p.slice_cbeg[sb + i];
+      t_nseg[i] = ~sg;
+      if (p.segs[sg].deleted) sh_anydel = 1;
+    }
+    __syncthreads();
+    for (uint32_t d = 1; d < nsl; d <<= 1) {  // Hillis-Steele inclusive scan
+      uint32_t add[kSelectMaxSlices / NT];
+      for (uint32_t i = tid, r = 0; i < nsl; i += NT, r++) add[r] = i >= d ? t_end[i - d] : 0u;
+      __syncthreads();
+      for (uint32_t i = tid, r = 0; i < nsl; i += NT, r++) t_end[i] += add[r];
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  const uint32_t n_flat = table && nsl ? t_end[nsl - 1] : 0u;
+  const bool anydel = sh_anydel != 0;
+
+  // visit every live candidate of the query: f(ordered score, ~seg, ~doc, slot); four
+  // independent loads in flight per thread
+  auto for_each = [&](auto &&f) {
+    if (table) {
+      for (uint32_t i0 = tid; i0 < n_flat; i0 += 4 * NT) {
+        uint2 c[4];
+        uint64_t at[4];
+        uint32_t ns[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t i = i0 + u * NT;
+          c[u] = make_uint2(0u, 0xFFFFFFFFu);
+          at[u] = 0;
+          ns[u] = 0;
+          if (i < n_flat) {
+            uint32_t lo = 0, hi = nsl - 1;  // first slice whose inclusive prefix exceeds i
+            while (lo < hi) {
+              const uint32_t mid = (lo + hi) >> 1;
+              if (t_end[mid] > i)
+                hi = mid;
+              else
+                lo = mid + 1;
+            }
+            at[u] = t_base[lo] + (i - (lo ? t_end[lo - 1] : 0u));
+            ns[u] = t_nseg[lo];
+            c[u] = p.cand[at[u]];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (c[u].y != 0xFFFFFFFFu) f(c[u].x, ns[u], ~c[u].y, at[u]);
+      }
+    } else {
+      for (uint32_t s = sb + wave; s < se; s += NT / 64) {
+        const uint64_t base = p.slice_cbeg[s];
+        const uint32_t cnt = p.slice_ccnt[s];
+        const uint32_t nseg = ~p.slice_seg[s];
+        for (uint32_t i = lane; i < cnt; i += 64) {
+          const uint2 c = p.cand[base + i];
+          if (c.y != 0xFFFFFFFFu) f(c.x, nseg, ~c.y, base + i);
+        }
+      }
+    }
+  };
+
+  // ---- sweep 1: accept() (drop deleted docs) + histogram of the top score byte ----
+  for_each([&](uint32_t a, uint32_t nseg, uint32_t ndoc, uint64_t at) {
+    if (anydel) {
+      const uint32_t *del = p.segs[~nseg].deleted;
+      const uint32_t d = ~ndoc;
+      if (del && ((del[d >> 5] >> (d & 31)) & 1u)) {
+        p.cand[at].y = 0xFFFFFFFFu;
+        return;
+      }
+    }
+    atomicAdd(&hist[a >> 24], 1u);
+  });
+  __syncthreads();
+
+  // ---- radix select, one byte per level, until the keys at or above the chosen prefix fit the
+  //      LDS sort buffer (they include the k best) ----
+  uint32_t level = 0;
+  for (;; level++) {
+    const uint32_t wd = level >> 2, shift = 24u - 8u * (level & 3u);
+    if (level > 0) {
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      const uint32_t p0 = sh_pre[0], p1 = sh_pre[1], p2 = sh_pre[2];
+      const uint32_t himask = shift == 24u ? 0u : ~((1u << (shift + 8u)) - 1u);  // bytes above
+      for_each([&](uint32_t a, uint32_t b, uint32_t c, uint64_t) {
+        const uint32_t w = wd == 0 ? a : (wd == 1 ? b : c), pw = wd == 0 ? p0 : (wd == 1 ? p1 : p2);
+        bool m = (w & himask) == (pw & himask);
+        if (wd >= 1) m = m && a == p0;
+        if (wd >= 2) m = m && b == p1;
+        if (m) atomicAdd(&hist[(w >> shift) & 255u], 1u);
+      });
+      __syncthreads();
+    }
+    if (wave == 0) {
+      // lane l owns bins 255-4l .. 252-4l (descending); inclusive prefix of the lane sums
+      const uint32_t b0 = 255u - 4u * lane;
+      const uint32_t h0 = hist[b0], h1 = hist[b0 - 1], h2 = hist[b0 - 2], h3 = hist[b0 - 3];
+      const uint32_t tot = h0 + h1 + h2 + h3;
+      uint32_t incl = tot;
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o, 64);
+        if ((int)lane >= o) incl += v;
+      }
+      const uint32_t matching = __shfl(incl, 63, 64);
+      if (level == 0 && lane == 0) sh_nvalid = matching;
+      const uint32_t need = sh_need, excl = incl - tot;
+      if (matching < need) {
+        // (level 0 only) fewer live candidates than k: everything is kept
+        if (lane == 0) {
+          sh_done = 2;
+          sh_taken = matching;
+        }
+      } else if (excl < need && need <= incl) {  // exactly one lane
+        uint32_t cum = excl, b = b0, h = h0;
+        if (cum + h < need) { cum += h; b = b0 - 1; h = h1; }
+        if (cum + h < need) { cum += h; b = b0 - 2; h = h2; }
+        if (cum + h < need) { cum += h; b = b0 - 3; h = h3; }
+        sh_pre[wd] = sh_pre[wd] | (b << shift);
+        sh_need = need - cum;  // rank of the k-th key inside the bucket
+        const uint32_t taken = (k - (need - cum)) + h;  // keys with prefix >= the chosen one
+        sh_taken = taken;
+        sh_done = (taken <= kSelectCap || level == 11) ? 1u : 0u;
+      }
+    }
+    __syncthreads();
+    if (sh_done) break;
+  }
+  const bool all = sh_done == 2;
+  const uint32_t nvalid = sh_nvalid;
+  const uint32_t nout = nvalid < k ? nvalid : k;
+  uint32_t taken = sh_taken < kSelectCap ? sh_taken : kSelectCap;
+
+  // ---- gather the keys at or above the chosen prefix ----
+  {
+    const uint32_t wd = level >> 2, shift = 24u - 8u * (level & 3u);
+    const uint32_t keep = ~((1u << shift) - 1u);  // decided bytes of word wd
+    const uint32_t p0 = sh_pre[0], p1 = sh_pre[1], p2 = sh_pre[2];
+    for_each([&](uint32_t a, uint32_t b, uint32_t c, uint64_t) {
+      bool win = all;
+      if (!all) {
+        const uint32_t ka = wd == 0 ? (a & keep) : a, kb = wd == 1 ? (b & keep) : b,
+                       kc = wd == 2 ? (c & keep) : c;
+        if (wd == 0)
+          win = ka >= p0;
+        else if (wd == 1)
+          win = ka > p0 || (ka == p0 && kb >= p1);
+        else
+          win = ka > p0 || (ka == p0 && (kb > p1 || (kb == p1 && kc >= p2)));
+      }
+      if (win) {
+        const uint32_t at = atomicAdd(&sh_nwin, 1u);
+        if (at < kSelectCap) {
+          w_ok[at] = a;
+          w_sg[at] = b;
+          w_dc[at] = c;
+        }
+      }
+    });
+  }
+  __syncthreads();
+  // ---- bitonic sort, descending 96-bit key; the first nout are the result ----
+  uint32_t n2 = 1;
+  while (n2 < taken) n2 <<= 1;
+  for (uint32_t i = taken + tid; i < n2; i += NT) {
+    w_ok[i] = 0;
+    w_sg[i] = 0;
+    w_dc[i] = 0;
+  }
+  __syncthreads();
+  for (uint32_t size = 2; size <= n2; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      for (uint32_t t = tid; t < (n2 >> 1); t += NT) {
+        const uint32_t i = 2 * t - (t & (stride - 1));  // lower index of the pair
+        const uint32_t j = i + stride;
+        const bool desc = (i & size) == 0;
+        const uint32_t ai = w_ok[i], bi = w_sg[i], ci = w_dc[i];
+        const uint32_t aj = w_ok[j], bj = w_sg[j], cj = w_dc[j];
+        const bool i_lt_j = ai < aj || (ai == aj && (bi < bj || (bi == bj && ci < cj)));
+        if (i_lt_j == desc) {
+          w_ok[i] = aj; w_sg[i] = bj; w_dc[i] = cj;
+          w_ok[j] = ai; w_sg[j] = bi; w_dc[j] = ci;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (uint32_t i = tid; i < k; i += NT) {
+    const bool real = i < nout;
+    const uint32_t ok = real ? w_ok[i] : 0u;
+    const int32_t tk = (int32_t)(ok ^ 0x80000000u);
+    p.out_doc[(size_t)q * k + i] = real ? ~w_dc[i] : 0u;
+    p.out_seg[(size_t)q * k + i] = real ? ~w_sg[i] : 0u;
+    p.out_score[(size_t)q * k + i] = real ? key_to_float(tk) : 0.0f;
+  }
+  if (tid == 0) p.out_count[q] = nout;
 }
 
 }  // namespace slg

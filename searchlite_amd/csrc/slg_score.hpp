@@ -150,6 +150,10 @@ struct RoundScoreParams {
   int32_t *slice_tk;    // [n_slices * k]
   uint32_t *slice_doc;  // [n_slices * k]
   uint32_t *q_scored;   // [nq] or null
+  // large-k mode of the uniform kernel (k > 256): candidates instead of per-slice top-k lists
+  uint2 *cand;            // {ordered score, doc}; sub-query region + posting offset of the slice
+  uint64_t *slice_cbeg;   // [n_slices] first candidate slot of the slice
+  uint32_t *slice_ccnt;   // [n_slices] candidates written
   uint32_t n_slices;
   uint32_t k;
   uint32_t dbg;

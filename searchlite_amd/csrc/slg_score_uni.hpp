@@ -27,7 +27,8 @@ namespace slg {
 constexpr int kUniSlots = 8;                 // 64-posting slots per round; also max lists
 constexpr int kUniCap = kUniSlots * 64;
 constexpr int kUniWaveLdsBase = kSpanWords * 4 + kSpanWords * 4 + kUniCap * 4 + 64 * 4;
-// k <= 256 (KREGS <= 4): buffered top-k in LDS (BufTopK); larger k: register-sorted WaveTopK
+// k <= 256 (KREGS <= 4): buffered top-k in LDS (BufTopK); larger k: every doc above the seed
+// threshold goes to the slice's candidate region and select_topk_kernel picks the k best
 constexpr bool uni_buffered(int kregs) { return kregs <= 4; }
 constexpr int uni_wave_lds(int kregs) {
   return kUniWaveLdsBase + (uni_buffered(kregs) ? 128 * kregs * 8 : 0);
@@ -80,10 +81,18 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
   // lane i = r*T + t: postings of list t in round r
   const uint32_t dcnt = __shfl(bflat, (lane + T) & 63u, 64) - bflat;
 
-  WaveTopK<BUF ? 1 : KREGS, false> top;  // k > 256
-  BufTopK<BUF ? KREGS : 1> btop;          // k <= 256
-  top.init();
+  BufTopK<BUF ? KREGS : 1> btop;  // k <= 256; for larger k only its threshold is used
   btop.init(reinterpret_cast<uint64_t *>(vals + kUniCap + 64));
+  // k > 256: the slice's candidate region starts at (sub-query base) + (postings of all lists
+  // before the slice's first round) and can hold one entry per posting of the slice
+  uint32_t ccur = 0;
+  uint64_t cbeg = 0;
+  if (!BUF) {
+    uint32_t before = 0;
+    for (uint32_t t = 0; t < T; t++) before += rl(bflat, t);
+    cbeg = (((uint64_t)rfl(s.cand_hi) << 32) | rfl(s.cand_lo)) + before;
+  }
+  uint2 *const creg = BUF ? nullptr : p.cand + cbeg;
   if (sd.champ != nullptr && k <= 1024u) {  // threshold seed (see slg_score.hpp)
     float f = 0.0f;
     if (lane < T && my_w > 0.0f)
@@ -92,12 +101,7 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
     for (uint32_t t = 0; t < T; t++)
       best = fmaxf(best, __int_as_float((int)rl((uint32_t)__float_as_int(f), t)));
     const bool anyneg = __ballot(lane < T && !(my_w >= 0.0f)) != 0ull;
-    if (best > 0.0f && !anyneg) {
-      if (BUF)
-        btop.set_floor(best);
-      else
-        top.set_floor(best);
-    }
+    if (best > 0.0f && !anyneg) btop.set_floor(best);
   }
   uint32_t n_scored = 0;
 #ifdef SLG_STAMPS
@@ -333,26 +337,16 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
         }
       }
     } else {
-      int32_t ctk[NS];
-      uint32_t passmask = 0;
 #pragma unroll
       for (int jj = 0; jj < NS; jj++) {
-        ctk[jj] = own[jj] ? total_key(__uint_as_float(v[jj])) : kSentinelTk;
-        passmask |= (own[jj] && top.passes(ctk[jj], 0u, e.doc[jj])) ? (1u << jj) : 0u;
-      }
-      if (__ballot(passmask != 0u) != 0ull) {
-#pragma unroll
-        for (int jj = 0; jj < NS; jj++) {
-          uint64_t m = __ballot(((passmask >> jj) & 1u) && top.passes(ctk[jj], 0u, e.doc[jj]));
-          while (m) {
-            const uint32_t l = (uint32_t)__builtin_ctzll(m);
-            const int32_t c_tk = (int32_t)rl((uint32_t)ctk[jj], l);
-            const uint32_t c_doc = rl(e.doc[jj], l);
-            if (!(gdel && ((gdel[c_doc >> 5] >> (c_doc & 31)) & 1u)))  // accept()
-              top.insert(c_tk, 0u, c_doc, k, lane);
-            m &= m - 1;
-            m &= __ballot(top.passes(ctk[jj], 0u, e.doc[jj]));
-          }
+        const uint32_t ok = ordered_score(__uint_as_float(v[jj]));
+        const bool ps = own[jj] && btop.passes(((uint64_t)ok << 32) | (uint32_t)~e.doc[jj]);
+        const uint64_t m = __ballot(ps);
+        if (m != 0ull) {
+          const uint32_t at = ccur + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          if (ps) creg[at] = make_uint2(ok, e.doc[jj]);
+          ccur += (uint32_t)__popcll(m);
         }
       }
     }
@@ -463,20 +457,13 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
     } while (big);
   }
 
-  // ---- write this slice's candidates (sorted best-first; sentinel-padded) ----
-  int32_t *otk = p.slice_tk + (size_t)slice * k;
-  uint32_t *odoc = p.slice_doc + (size_t)slice * k;
-  if constexpr (BUF) {
-    btop.write_out(otk, odoc, k, lane, (const uint32_t *)gdel);
-  } else {
-#pragma unroll
-    for (int r = 0; r < KREGS; r++) {
-      const uint32_t pos = lane * KREGS + r;
-      if (pos < k) {
-        otk[pos] = top.tk[r];
-        odoc[pos] = top.doc[r];
-      }
-    }
+  // ---- write this slice's candidates ----
+  if constexpr (BUF) {  // k entries, sentinel-padded, for merge_topk_kernel
+    btop.write_out(p.slice_tk + (size_t)slice * k, p.slice_doc + (size_t)slice * k, k, lane,
+                   (const uint32_t *)gdel);
+  } else if (lane == 0) {  // region already written; deleted docs are dropped by the select
+    p.slice_cbeg[slice] = cbeg;
+    p.slice_ccnt[slice] = ccur;
   }
   if (p.q_scored && lane == 0 && n_scored) atomicAdd(&p.q_scored[s.q], n_scored);
 #ifdef SLG_STAMPS

