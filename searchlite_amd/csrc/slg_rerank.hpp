@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) rerank_kernel(RerankParams p) {
   const uint32_t *cdoc = p.cand_doc + (size_t)q * p.max_cand;
   const uint32_t *cseg = p.cand_seg + (size_t)q * p.max_cand;
   const float *cbm = p.cand_bm25 + (size_t)q * p.max_cand;
-  constexpr int U = 4;
+  constexpr int U = 8;
 
   for (uint32_t c0 = wave * U; c0 < n; c0 += 4 * U) {
     const float *row[U];
