@@ -132,6 +132,24 @@ int slg_index_info(const slg_index *index, uint32_t *n_segs, uint64_t *n_posting
 #define SLG_OWN_STREAM ((void *)(intptr_t)-1)
 int slg_index_set_stream(slg_index *index, void *hip_stream);
 
+/* ---- doc filters ----------------------------------------------------------
+ * The reference's accept() is `!deleted && matcher && filter && cursor`
+ * (api/reader.rs:3009-3036); for a pure disjunction the matcher is implied and a filter
+ * (query/filters.rs: keyword equality / numeric range on fast fields) reduces to a doc bitmap.
+ * A filter is registered once per index and referenced by id from any number of queries.
+ * All return a filter id >= 0, or a negative error code. */
+
+/* seg_bitmaps[s]: bit d of byte d/8 set = doc d of segment s passes; NULL = all pass. */
+int slg_index_add_filter(slg_index *index, const uint8_t *const *seg_bitmaps);
+/* Pre-pass on the device: doc d passes iff lo <= column[d] <= hi (one fast-field column per
+ * segment, n_docs values; a NaN never passes). */
+int slg_index_add_filter_range_i64(slg_index *index, const int64_t *const *seg_columns, int64_t lo,
+                                   int64_t hi);
+int slg_index_add_filter_range_f64(slg_index *index, const double *const *seg_columns, double lo,
+                                   double hi);
+/* Frees the bitmaps; the id is not reused.  No batch prepared with this filter may run after. */
+int slg_index_remove_filter(slg_index *index, int filter_id);
+
 /* ---- one-shot search (what a searchlite `gpu` shim calls) -------------------------- */
 
 /*
@@ -145,6 +163,12 @@ int slg_search_batch(slg_index *index, const slg_query *queries, uint32_t nq, ui
                      int strategy, uint32_t *out_doc, uint32_t *out_seg, float *out_score,
                      uint32_t *out_count, slg_stats *stats_or_null);
 
+/* Same with a doc filter per query (q_filter[q] = filter id, < 0 none; NULL = none at all). */
+int slg_search_batch_filtered(slg_index *index, const slg_query *queries, uint32_t nq,
+                              const int32_t *q_filter, uint32_t k, int strategy, uint32_t *out_doc,
+                              uint32_t *out_seg, float *out_score, uint32_t *out_count,
+                              slg_stats *stats_or_null);
+
 /* ---- prepared batches (device-resident inputs; used for steady-state serving) ------ */
 
 /*
@@ -155,6 +179,11 @@ int slg_search_batch(slg_index *index, const slg_query *queries, uint32_t nq, ui
 slg_batch *slg_batch_prepare(slg_index *index, uint32_t nq, const uint32_t *q_offsets,
                              const uint32_t *q_term_ids, const float *q_weights, uint32_t k,
                              int strategy);
+/* Same, with a doc filter per query: q_filter[q] = filter id, or < 0 for none (q_filter may be
+ * NULL).  Filtered queries get no threshold seed (the filter may reject the champions). */
+slg_batch *slg_batch_prepare_filtered(slg_index *index, uint32_t nq, const uint32_t *q_offsets,
+                                      const uint32_t *q_term_ids, const float *q_weights,
+                                      const int32_t *q_filter, uint32_t k, int strategy);
 /* Enqueue the partition / score / merge kernels on the batch's stream (asynchronous). */
 int slg_batch_run(slg_batch *batch);
 /* Run this batch on its own HIP stream instead of the index stream, so several prepared

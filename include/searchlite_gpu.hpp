@@ -76,6 +76,7 @@ class Index {
       d[i].deleted = s.deleted.empty() ? nullptr : s.deleted.data();
     }
     n_segs_ = (uint32_t)segs.size();
+    for (const SegmentData &sd : segs) n_docs_.push_back(sd.n_docs);
     h_ = slg_index_create(d.data(), n_segs_, device);
     if (!h_) throw Error(SLG_ERR_INVALID, slg_last_error());
   }
@@ -84,10 +85,12 @@ class Index {
   Index &operator=(const Index &) = delete;
   slg_index *handle() const { return h_; }
   uint32_t n_segs() const { return n_segs_; }
+  uint32_t n_docs(uint32_t segment) const { return n_docs_[segment]; }
 
  private:
   slg_index *h_ = nullptr;
   uint32_t n_segs_ = 0;
+  std::vector<uint32_t> n_docs_;
 };
 
 // execute_top_k_with_stats (query/wand.rs:374-395) against one segment of the index.
@@ -122,6 +125,43 @@ inline std::vector<RankedDoc> execute_top_k_with_stats(Index &index, const std::
 inline std::vector<RankedDoc> execute_top_k(Index &index, const std::vector<ScoredTerm> &terms, size_t k,
                                             ExecutionStrategy strategy, uint32_t segment = 0) {
   return execute_top_k_with_stats(index, terms, k, strategy, nullptr, segment);
+}
+
+// The reference's `accept: FnMut(DocId, f32) -> bool` argument (wand.rs:343, called at :512 /
+// :555 / :858) for predicates that depend on the doc only (deleted docs, filters, cursors:
+// api/reader.rs:3009-3036).  A closure cannot cross the C ABI, so it is evaluated once per doc
+// into a bitmap and registered as a doc filter for the duration of the call.
+template <typename Accept>
+inline std::vector<RankedDoc> execute_top_k_with_accept(Index &index, const std::vector<ScoredTerm> &terms,
+                                                        size_t k, ExecutionStrategy strategy, Accept accept,
+                                                        uint32_t segment = 0) {
+  const uint32_t n = index.n_docs(segment);
+  std::vector<uint8_t> bits(((size_t)n + 7) / 8 + 1, 0);
+  for (uint32_t d = 0; d < n; d++)
+    if (accept(d)) bits[d >> 3] |= (uint8_t)(1u << (d & 7));
+  std::vector<const uint8_t *> per_seg(index.n_segs(), nullptr);
+  per_seg[segment] = bits.data();
+  const int fid = slg_index_add_filter(index.handle(), per_seg.data());
+  if (fid < 0) throw Error(fid, slg_last_error());
+  std::vector<uint32_t> ids(terms.size() * index.n_segs(), SLG_NO_TERM);
+  std::vector<float> w(terms.size());
+  for (size_t i = 0; i < terms.size(); i++) {
+    ids[i * index.n_segs() + segment] = terms[i].term_id;
+    w[i] = terms[i].weight;
+  }
+  slg_query q{(uint32_t)terms.size(), ids.data(), w.data()};
+  std::vector<uint32_t> doc(k ? k : 1), seg(k ? k : 1);
+  std::vector<float> score(k ? k : 1);
+  uint32_t count = 0;
+  const int32_t qf = fid;
+  const int rc = slg_search_batch_filtered(index.handle(), &q, 1, &qf, (uint32_t)k, (int)strategy, doc.data(),
+                                           seg.data(), score.data(), &count, nullptr);
+  const std::string msg = rc != SLG_OK ? slg_last_error() : "";
+  slg_index_remove_filter(index.handle(), fid);
+  if (rc != SLG_OK) throw Error(rc, msg);
+  std::vector<RankedDoc> out(count);
+  for (uint32_t i = 0; i < count; i++) out[i] = RankedDoc{doc[i], score[i]};
+  return out;
 }
 
 }  // namespace gpu

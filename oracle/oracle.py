@@ -193,6 +193,45 @@ def search_batch(segments, q_offsets, q_terms, q_weights, k, strategy=WAND, bloc
     return out_doc, out_seg, out_score, out_count
 
 
+def search_batch_filtered(segments, q_offsets, q_terms, q_weights, k, q_filter, filters,
+                          strategy=WAND, **kw):
+    """search_batch with a doc filter per query.  The reference's accept() is
+    `!deleted && filter` for a pure disjunction (api/reader.rs:3009-3018), so a filtered query
+    is the unfiltered scorer run with the tombstones OR-ed with the filter's complement (idf
+    keeps using segment.docs, which is a separate field).  filters[f][s] = boolean pass mask of
+    segment s or None; q_filter[q] = filter id or < 0."""
+    import copy
+    q_offsets = np.ascontiguousarray(q_offsets, dtype=np.uint32)
+    nq = len(q_offsets) - 1
+    q_terms = np.ascontiguousarray(q_terms, dtype=np.uint32).reshape(-1, len(segments))
+    q_weights = np.ascontiguousarray(q_weights, dtype=np.float32)
+    out = None
+    for q in range(nq):
+        f = int(q_filter[q]) if q_filter is not None else -1
+        segs = segments
+        if f >= 0:
+            segs = []
+            for s, seg in enumerate(segments):
+                sg = copy.copy(seg)
+                m = filters[f][s]
+                if m is not None:
+                    dead = np.zeros(seg.n_docs, dtype=bool)
+                    if seg.deleted is not None:
+                        dead |= np.unpackbits(seg.deleted, bitorder="little")[:seg.n_docs].astype(bool)
+                    dead |= ~np.asarray(m, dtype=bool)
+                    sg.deleted = np.packbits(dead, bitorder="little")
+                segs.append(sg)
+        a, b = int(q_offsets[q]), int(q_offsets[q + 1])
+        r = search_batch(segs, np.array([0, b - a], dtype=np.uint32), q_terms[a:b], q_weights[a:b], k,
+                         strategy=strategy, **kw)
+        if out is None:
+            out = [np.zeros((nq,) + x.shape[1:], dtype=x.dtype) for x in r[:4]]
+        for o, x in zip(out, r[:4]):
+            o[q] = x[0]
+    return tuple(out) if out is not None else search_batch(segments, q_offsets, q_terms, q_weights, k,
+                                                           strategy=strategy, **kw)
+
+
 def normalize_in_place(v):
     assert v.dtype == np.float32 and v.flags.c_contiguous
     lib().slo_normalize_in_place(_ptr(v), v.size)

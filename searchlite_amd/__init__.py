@@ -10,11 +10,14 @@ from .segment import (NO_TERM, NO_VECTOR, Segment, SegmentBuilder, default_token
 
 __all__ = ["Segment", "SegmentBuilder", "default_tokenize", "fold_terms", "parse_query_terms",
            "resolve_query", "NO_TERM", "NO_VECTOR", "GpuIndex", "PreparedBatch", "Bm25", "Wand",
-           "Bmw"]
+           "Bmw", "SlgError"]
 
 
 def __getattr__(name):
     if name in ("GpuIndex", "PreparedBatch", "Bm25", "Wand", "Bmw", "device_count"):
         from . import searcher
         return getattr(searcher, name)
+    if name == "SlgError":
+        from ._native import SlgError
+        return SlgError
     raise AttributeError(name)

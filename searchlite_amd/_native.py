@@ -86,7 +86,13 @@ def load():
         "slg_index_info": (i32, [vp, vp, vp, vp]),
         "slg_index_set_stream": (i32, [vp, vp]),
         "slg_search_batch": (i32, [vp, vp, u32, u32, i32, vp, vp, vp, vp, vp]),
+        "slg_index_add_filter": (i32, [vp, vp]),
+        "slg_index_add_filter_range_i64": (i32, [vp, vp, C.c_int64, C.c_int64]),
+        "slg_index_add_filter_range_f64": (i32, [vp, vp, C.c_double, C.c_double]),
+        "slg_index_remove_filter": (i32, [vp, i32]),
+        "slg_search_batch_filtered": (i32, [vp, vp, u32, vp, u32, i32, vp, vp, vp, vp, vp]),
         "slg_batch_prepare": (vp, [vp, u32, vp, vp, vp, u32, i32]),
+        "slg_batch_prepare_filtered": (vp, [vp, u32, vp, vp, vp, vp, u32, i32]),
         "slg_batch_run": (i32, [vp]),
         "slg_batch_set_stream": (i32, [vp, vp]),
         "slg_batch_sync": (i32, [vp]),

@@ -94,6 +94,20 @@ struct DevBuf {
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
+  DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) {
+    o.p = nullptr;
+    o.bytes = 0;
+  }
+  DevBuf &operator=(DevBuf &&o) noexcept {
+    if (this != &o) {
+      release();
+      p = o.p;
+      bytes = o.bytes;
+      o.p = nullptr;
+      o.bytes = 0;
+    }
+    return *this;
+  }
   template <typename T>
   T *as() const {
     return static_cast<T *>(p);
@@ -123,6 +137,10 @@ struct slg_index {
   DevBuf d_vsegs; // slg::VecSegDev[n_segs]
   uint64_t device_bytes = 0;
   std::mutex mu;
+  // doc filters (slg_index_add_filter*): per filter and segment a reject bitmap (deleted | ~filter)
+  std::vector<std::vector<DevBuf>> filters;  // [filter][seg]; a removed filter keeps empty bufs
+  std::vector<const uint32_t *> reject_host;  // flattened [filter * n_segs + seg] device pointers
+  DevBuf d_reject_table;                      // the same table on the device
   // profiling of the scoring kernel
   bool profile = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -148,6 +166,7 @@ struct slg_batch {
   const uint32_t *d_bnd_sq = nullptr;
   const slg::QueryRef *d_queries = nullptr;
   DevBuf d_bounds, d_rdoc, d_slice_tk, d_slice_doc, d_q_scored;
+  DevBuf d_q_filter;       // [nq] 0 = none, f + 1 (select_topk_kernel); empty when unfiltered
   bool cand_mode = false;  // uniform kernel, k > 256: candidates + select_topk_kernel
   DevBuf d_cand, d_slice_cbeg, d_slice_ccnt;
   DevBuf d_out;  // doc | seg | score | count, contiguous
@@ -510,9 +529,102 @@ int slg_index_set_stream(slg_index *ix, void *hip_stream) {
   });
 }
 
+
+// ---- doc filters -------------------------------------------------------------
+namespace {
+int add_filter_impl(slg_index *ix, const uint8_t *const *seg_bitmaps, const void *const *seg_columns,
+                    int column_kind, long long lo_i, long long hi_i, double lo_f, double hi_f) {
+  int id = -1;
+  int rc = guarded([&] {
+    SLG_REQUIRE(ix != nullptr, "index is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    hipStream_t st = ix->stream;
+    const size_t n_segs = ix->segs.size();
+    std::vector<DevBuf> bufs(n_segs);
+    std::vector<DevBuf> tmp(n_segs);  // uploaded pass bitmaps / columns (freed on return)
+    for (size_t s = 0; s < n_segs; s++) {
+      const SegHost &sh = *ix->segs[s];
+      const size_t words = ((size_t)sh.n_docs + 31) / 32;
+      bufs[s].alloc((words ? words : 1) * 4);
+      slg::FilterBuildParams fp{};
+      fp.deleted = sh.d_deleted.as<uint32_t>();
+      fp.n_docs = sh.n_docs;
+      fp.reject = bufs[s].as<uint32_t>();
+      fp.column_kind = 0;
+      if (column_kind) {
+        SLG_REQUIRE(seg_columns && seg_columns[s], "filter column of a segment is NULL");
+        tmp[s].alloc((size_t)std::max<uint32_t>(sh.n_docs, 1) * 8);
+        SLG_HIP(hipMemcpyAsync(tmp[s].p, seg_columns[s], (size_t)sh.n_docs * 8, hipMemcpyHostToDevice, st));
+        fp.column = tmp[s].p;
+        fp.column_kind = column_kind;
+        fp.lo_i = lo_i;
+        fp.hi_i = hi_i;
+        fp.lo_f = lo_f;
+        fp.hi_f = hi_f;
+      } else if (seg_bitmaps && seg_bitmaps[s]) {
+        std::vector<uint32_t> w(words ? words : 1, 0u);
+        std::memcpy(w.data(), seg_bitmaps[s], ((size_t)sh.n_docs + 7) / 8);
+        tmp[s].alloc(w.size() * 4);
+        SLG_HIP(hipMemcpy(tmp[s].p, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+        fp.pass = tmp[s].as<uint32_t>();
+      }
+      if (sh.n_docs) {
+        hipLaunchKernelGGL(slg::filter_build_kernel, dim3((sh.n_docs + 255) / 256), dim3(256), 0, st, fp);
+        SLG_HIP(hipGetLastError());
+      }
+    }
+    SLG_HIP(hipStreamSynchronize(st));
+    for (size_t s = 0; s < n_segs; s++) ix->device_bytes += bufs[s].bytes;
+    id = (int)ix->filters.size();
+    ix->filters.push_back(std::move(bufs));
+    // rebuild the device pointer table (batches read it at run time; ids are stable)
+    ix->reject_host.assign(ix->filters.size() * n_segs, nullptr);
+    for (size_t f = 0; f < ix->filters.size(); f++)
+      for (size_t s = 0; s < ix->filters[f].size(); s++)
+        ix->reject_host[f * n_segs + s] = ix->filters[f][s].as<uint32_t>();
+    DevBuf nt;
+    nt.alloc(std::max<size_t>(ix->reject_host.size(), 1) * sizeof(void *));
+    SLG_HIP(hipMemcpy(nt.p, ix->reject_host.data(), ix->reject_host.size() * sizeof(void *),
+                      hipMemcpyHostToDevice));
+    SLG_HIP(hipDeviceSynchronize());  // no kernel may still read the old table
+    ix->d_reject_table = std::move(nt);
+  });
+  return rc == SLG_OK ? id : rc;
+}
+}  // namespace
+
+int slg_index_add_filter(slg_index *ix, const uint8_t *const *seg_bitmaps) {
+  return add_filter_impl(ix, seg_bitmaps, nullptr, 0, 0, 0, 0.0, 0.0);
+}
+int slg_index_add_filter_range_i64(slg_index *ix, const int64_t *const *seg_columns, int64_t lo, int64_t hi) {
+  return add_filter_impl(ix, nullptr, reinterpret_cast<const void *const *>(seg_columns), 1, lo, hi, 0.0, 0.0);
+}
+int slg_index_add_filter_range_f64(slg_index *ix, const double *const *seg_columns, double lo, double hi) {
+  return add_filter_impl(ix, nullptr, reinterpret_cast<const void *const *>(seg_columns), 2, 0, 0, lo, hi);
+}
+int slg_index_remove_filter(slg_index *ix, int filter_id) {
+  return guarded([&] {
+    SLG_REQUIRE(ix != nullptr, "index is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    SLG_REQUIRE(filter_id >= 0 && (size_t)filter_id < ix->filters.size() && !ix->filters[filter_id].empty(),
+                "unknown filter id");
+    SLG_HIP(hipDeviceSynchronize());
+    for (auto &bf : ix->filters[filter_id]) ix->device_bytes -= bf.bytes;
+    ix->filters[filter_id].clear();  // the id is never reused
+  });
+}
+
 slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offsets,
                              const uint32_t *q_term_ids, const float *q_weights, uint32_t k,
                              int strategy) {
+  return slg_batch_prepare_filtered(ix, nq, q_offsets, q_term_ids, q_weights, nullptr, k, strategy);
+}
+
+slg_batch *slg_batch_prepare_filtered(slg_index *ix, uint32_t nq, const uint32_t *q_offsets,
+                                      const uint32_t *q_term_ids, const float *q_weights,
+                                      const int32_t *q_filter, uint32_t k, int strategy) {
   slg_batch *b = nullptr;
   int rc = guarded([&] {
     SLG_REQUIRE(ix != nullptr, "index is NULL");
@@ -540,6 +652,7 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
     std::vector<slg::TermRef> terms;
     std::vector<uint64_t> sq_postings, sq_postings_all;
     std::vector<uint32_t> q_sq_begin(nq + 1, 0);
+    bool any_filter = false;
     for (uint32_t q = 0; q < nq; q++) {
       q_sq_begin[q] = (uint32_t)sqs.size();
       SLG_REQUIRE(q_offsets[q + 1] >= q_offsets[q], "q_offsets not monotone");
@@ -547,12 +660,20 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
       if (nt > SLG_MAX_QUERY_TERMS)
         throw SlgError(SLG_ERR_UNSUPPORTED, "query " + std::to_string(q) + " has more than " +
                                                 std::to_string(SLG_MAX_QUERY_TERMS) + " terms");
+      uint32_t fq = 0;  // doc filter of the query (0 none, id + 1)
+      if (q_filter && q_filter[q] >= 0) {
+        SLG_REQUIRE((size_t)q_filter[q] < ix->filters.size() && !ix->filters[q_filter[q]].empty(),
+                    "unknown filter id in query " + std::to_string(q));
+        fq = (uint32_t)q_filter[q] + 1u;
+        any_filter = true;
+      }
       if (k == 0) continue;  // wand.rs:413-416: k == 0 and no collector => no work
       for (uint32_t s = 0; s < n_segs; s++) {
         const SegHost &sh = *ix->segs[s];
         slg::RoundQuery sq{};
         sq.q = q;
         sq.seg = s;
+        sq.filter = fq;
         sq.term_begin = (uint32_t)terms.size();
         uint64_t P = 0;
         uint32_t longest = 0, longest_df = 0;
@@ -582,7 +703,7 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
         // their maximum contribution ub_t = w_t * champ[t][0] are non-essential while the running
         // sum of ub stays below theta0: a doc found only in them totals < theta0.
         uint32_t ess_mask = sq.n_terms >= 32 ? 0xFFFFFFFFu : ((1u << sq.n_terms) - 1u);
-        if (strategy != SLG_STRATEGY_BM25 && !sh.champ.empty() && k >= 1 && k <= 1024u &&
+        if (strategy != SLG_STRATEGY_BM25 && !sh.champ.empty() && k >= 1 && k <= 1024u && fq == 0 &&
             sq.n_terms > 1 && env_u32("SLG_MAXSCORE", 0) != 0) {
           bool ok = true;
           float theta0 = 0.0f;
@@ -642,7 +763,7 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
     std::vector<uint32_t> slice_sq, slice_seg, bnd_sq;
     uint64_t n_bounds = 0, n_bnd = 0;
     // one-list-per-slot kernel (slg_score_uni.hpp): few terms, no non-essential lists
-    const uint32_t uni_max_terms = std::min<uint32_t>(env_u32("SLG_UNIFORM_MAX_TERMS", 5), slg::kUniSlots);
+    const uint32_t uni_max_terms = std::min<uint32_t>(env_u32("SLG_UNIFORM_MAX_TERMS", 6), slg::kUniSlots);
     b->uniform = env_u32("SLG_NO_UNIFORM", 0) == 0 && b->max_terms <= uni_max_terms;
     for (size_t i = 0; i < sqs.size() && b->uniform; i++) {
       const uint32_t full = sqs[i].n_terms >= 32 ? 0xFFFFFFFFu : ((1u << sqs[i].n_terms) - 1u);
@@ -794,6 +915,14 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
       b->d_slice_doc.alloc((size_t)b->n_slices * k * 4);
     }
     b->d_q_scored.alloc((size_t)nq * 4);
+    if (any_filter) {
+      std::vector<uint32_t> qf(nq, 0u);
+      for (uint32_t q = 0; q < nq; q++)
+        if (q_filter[q] >= 0) qf[q] = (uint32_t)q_filter[q] + 1u;
+      b->d_q_filter.alloc((size_t)nq * 4);
+      SLG_HIP(hipMemcpyAsync(b->d_q_filter.p, qf.data(), (size_t)nq * 4, hipMemcpyHostToDevice, ix->stream));
+      SLG_HIP(hipStreamSynchronize(ix->stream));
+    }
     b->d_out.alloc(((size_t)nq * k * 3 + nq) * 4);
     b->d_out_doc = b->d_out.as<uint32_t>();
     b->d_out_seg = b->d_out_doc + (size_t)nq * k;
@@ -840,6 +969,8 @@ int slg_batch_run(slg_batch *b) {
       sp.terms = b->d_terms;
       sp.slice_sq = b->d_slice_sq;
       sp.slice_order = b->d_slice_order;
+      sp.reject_table = ix->d_reject_table.as<const uint32_t *>();
+      sp.n_segs = (uint32_t)ix->segs.size();
       sp.cand = b->d_cand.as<uint2>();
       sp.slice_cbeg = b->d_slice_cbeg.as<uint64_t>();
       sp.slice_ccnt = b->d_slice_ccnt.as<uint32_t>();
@@ -879,6 +1010,9 @@ int slg_batch_run(slg_batch *b) {
       sp.slice_ccnt = b->d_slice_ccnt.as<uint32_t>();
       sp.cand = b->d_cand.as<uint2>();
       sp.segs = ix->d_segs.as<slg::SegDev>();
+      sp.q_filter = b->d_q_filter.as<uint32_t>();
+      sp.reject_table = ix->d_reject_table.as<const uint32_t *>();
+      sp.n_segs = (uint32_t)ix->segs.size();
       sp.out_doc = b->d_out_doc;
       sp.out_seg = b->d_out_seg;
       sp.out_score = b->d_out_score;
@@ -1013,6 +1147,14 @@ void slg_batch_destroy(slg_batch *b) {
 int slg_search_batch(slg_index *ix, const slg_query *queries, uint32_t nq, uint32_t k,
                      int strategy, uint32_t *out_doc, uint32_t *out_seg, float *out_score,
                      uint32_t *out_count, slg_stats *stats) {
+  return slg_search_batch_filtered(ix, queries, nq, nullptr, k, strategy, out_doc, out_seg, out_score,
+                                   out_count, stats);
+}
+
+int slg_search_batch_filtered(slg_index *ix, const slg_query *queries, uint32_t nq,
+                              const int32_t *q_filter, uint32_t k, int strategy, uint32_t *out_doc,
+                              uint32_t *out_seg, float *out_score, uint32_t *out_count,
+                              slg_stats *stats) {
   slg_batch *b = nullptr;
   int rc = guarded([&] {
     SLG_REQUIRE(ix != nullptr, "index is NULL");
@@ -1032,7 +1174,7 @@ int slg_search_batch(slg_index *ix, const slg_query *queries, uint32_t nq, uint3
     }
   });
   if (rc != SLG_OK) return rc;
-  b = slg_batch_prepare(ix, nq, offs.data(), tids.data(), ws.data(), k, strategy);
+  b = slg_batch_prepare_filtered(ix, nq, offs.data(), tids.data(), ws.data(), q_filter, k, strategy);
   if (!b) {
     // slg_batch_prepare already set the thread-local error; map it back to a code
     return g_last_error.find("SLG_MAX") != std::string::npos ||

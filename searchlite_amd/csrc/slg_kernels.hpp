@@ -57,7 +57,7 @@ struct RoundQuery {  // sub-query = (query, segment) pair with >= 1 non-empty te
   uint32_t bnd_begin;     // first boundary task of this sub-query (partition kernel)
   uint32_t longest;       // index of the longest ESSENTIAL list (splitter source)
   uint32_t ess_mask;      // bit t: list t is essential (MaxScore); the others are only probed
-  uint32_t pad;
+  uint32_t filter;        // 0: none; f + 1: docs must also pass filter f (reject table row f)
   uint32_t cand_lo, cand_hi;  // large-k mode: first candidate slot of this sub-query (u64)
 };
 
@@ -570,6 +570,42 @@ __global__ void __launch_bounds__(256) merge_shards_kernel(ShardMergeParams p) {
 }
 
 
+// ---- doc filters (accept = !deleted && filter, api/reader.rs:3009-3018) -----------
+// A filter is kept per segment as a REJECT bitmap (deleted | ~filter, bit d of word d/32) so the
+// scoring kernels use it exactly like the tombstone bitmap.
+struct FilterBuildParams {
+  const uint32_t *deleted;  // or nullptr
+  const uint32_t *pass;     // uploaded pass bitmap (words), or nullptr when built from a column
+  const void *column;       // i64 / f64 column [n_docs], or nullptr
+  double lo_f, hi_f;
+  long long lo_i, hi_i;
+  int column_kind;  // 0 none, 1 i64, 2 f64
+  uint32_t n_docs;
+  uint32_t *reject;  // out [ceil(n_docs/32)]
+};
+
+static __global__ void __launch_bounds__(256) filter_build_kernel(FilterBuildParams p) {
+  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;  // one doc per lane
+  const uint32_t lane = threadIdx.x & 63;
+  bool pass = false;
+  if (d < p.n_docs) {
+    if (p.column_kind == 1) {
+      const long long v = static_cast<const long long *>(p.column)[d];
+      pass = v >= p.lo_i && v <= p.hi_i;
+    } else if (p.column_kind == 2) {
+      const double v = static_cast<const double *>(p.column)[d];
+      pass = v >= p.lo_f && v <= p.hi_f;  // NaN never passes (query/filters.rs numeric range)
+    } else {
+      pass = p.pass == nullptr || ((p.pass[d >> 5] >> (d & 31)) & 1u);
+    }
+    if (p.deleted && ((p.deleted[d >> 5] >> (d & 31)) & 1u)) pass = false;
+  }
+  const uint64_t rej = ~__ballot(pass);  // docs past n_docs are rejected too
+  const uint32_t w = d >> 5;
+  if ((lane & 31u) == 0 && (d < p.n_docs))
+    p.reject[w] = lane == 0 ? (uint32_t)rej : (uint32_t)(rej >> 32);
+}
+
 // ---- large k (k > 256): per-query radix select over the candidates the scoring kernel kept ----
 // The uniform scoring kernel, instead of keeping a per-slice top-k, writes every doc whose score
 // beats the seed threshold to its slice's region of `cand` ({ordered score, doc}; the region of
@@ -586,6 +622,9 @@ struct SelectParams {
   const uint32_t *slice_ccnt;
   uint2 *cand;  // .x ordered score, .y doc (0xFFFFFFFF: dropped, e.g. deleted)
   const SegDev *segs;
+  const uint32_t *q_filter;             // [nq] 0 = none, f + 1
+  const uint32_t *const *reject_table;  // [n_filters * n_segs] reject bitmaps
+  uint32_t n_segs;
   uint32_t *out_doc, *out_seg;
   float *out_score;
   uint32_t *out_count;
@@ -612,6 +651,7 @@ static __global__ void __launch_bounds__(kSelectThreads) select_topk_kernel(Sele
   const QueryRef qr = p.queries[q];
   const uint32_t sb = qr.slice_begin, se = qr.slice_end, nsl = se - sb;
   const bool table = nsl <= kSelectMaxSlices;
+  const uint32_t flt = p.q_filter ? p.q_filter[q] : 0u;
 
   if (tid == 0) {
     sh_nvalid = 0;
@@ -631,7 +671,7 @@ static __global__ void __launch_bounds__(kSelectThreads) select_topk_kernel(Sele
       t_end[i] = p.slice_ccnt[sb + i];
       t_base[i] = p.slice_cbeg[sb + i];
       t_nseg[i] = ~sg;
-      if (p.segs[sg].deleted) sh_anydel = 1;
+      if (p.segs[sg].deleted || flt) sh_anydel = 1;
     }
     __syncthreads();
     for (uint32_t d = 1; d < nsl; d <<= 1) {  // Hillis-Steele inclusive scan
@@ -694,7 +734,7 @@ static __global__ void __launch_bounds__(kSelectThreads) select_topk_kernel(Sele
   // ---- sweep 1: accept() (drop deleted docs) + histogram of the top score byte ----
   for_each([&](uint32_t a, uint32_t nseg, uint32_t ndoc, uint64_t at) {
     if (anydel) {
-      const uint32_t *del = p.segs[~nseg].deleted;
+      const uint32_t *del = flt ? p.reject_table[(size_t)(flt - 1) * p.n_segs + ~nseg] : p.segs[~nseg].deleted;
       const uint32_t d = ~ndoc;
       if (del && ((del[d >> 5] >> (d & 31)) & 1u)) {
         p.cand[at].y = 0xFFFFFFFFu;

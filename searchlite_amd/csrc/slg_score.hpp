@@ -150,6 +150,8 @@ struct RoundScoreParams {
   int32_t *slice_tk;    // [n_slices * k]
   uint32_t *slice_doc;  // [n_slices * k]
   uint32_t *q_scored;   // [nq] or null
+  const uint32_t *const *reject_table;  // [n_filters * n_segs] reject bitmaps (doc filters)
+  uint32_t n_segs;
   // large-k mode of the uniform kernel (k > 256): candidates instead of per-slice top-k lists
   uint2 *cand;            // {ordered score, doc}; sub-query region + posting offset of the slice
   uint64_t *slice_cbeg;   // [n_slices] first candidate slot of the slice
@@ -237,7 +239,9 @@ __global__ void __launch_bounds__(256) score_rounds_kernel(RoundScoreParams p) {
   // serialize against the LDS traffic)
   const gu32_t gdocs = (gu32_t)sd.docs;
   const gf32_t gimps = (gf32_t)sd.imps;
-  const gu32_t gdel = (gu32_t)sd.deleted;
+  // accept(): tombstones, or the reject bitmap (deleted | ~filter) of the query's doc filter
+  const uint32_t fid = rfl(s.filter);
+  const gu32_t gdel = (gu32_t)(fid ? p.reject_table[(size_t)(fid - 1) * p.n_segs + s.seg] : sd.deleted);
   const uint32_t k = p.k;
   const uint32_t ess_mask = rfl(s.ess_mask);
 
@@ -259,7 +263,7 @@ __global__ void __launch_bounds__(256) score_rounds_kernel(RoundScoreParams p) {
 
   WaveTopK<KREGS, false> top;
   top.init();
-  if (sd.champ != nullptr && k <= 1024u) {
+  if (sd.champ != nullptr && k <= 1024u && fid == 0) {  // (a filter may reject the champions)
     // threshold seed: >= k postings of term t have impact >= champ[t][k-1], and a doc's total
     // is >= any single (non-negative) contribution, so >= k docs score >= w_t * champ[t][k-1]
     float f = 0.0f;

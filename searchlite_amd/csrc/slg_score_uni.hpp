@@ -61,7 +61,9 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
   const SegDev sd = p.segs[s.seg];
   const gu32_t gdocs = (gu32_t)sd.docs;
   const gf32_t gimps = (gf32_t)sd.imps;
-  const gu32_t gdel = (gu32_t)sd.deleted;
+  // accept(): tombstones, or the reject bitmap (deleted | ~filter) of the query's doc filter
+  const uint32_t fid = rfl(s.filter);
+  const gu32_t gdel = (gu32_t)(fid ? p.reject_table[(size_t)(fid - 1) * p.n_segs + s.seg] : sd.deleted);
   const uint32_t k = p.k;
 
   // lane t < T: list t's posting offset, weight, term id
@@ -93,7 +95,7 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
     cbeg = (((uint64_t)rfl(s.cand_hi) << 32) | rfl(s.cand_lo)) + before;
   }
   uint2 *const creg = BUF ? nullptr : p.cand + cbeg;
-  if (sd.champ != nullptr && k <= 1024u) {  // threshold seed (see slg_score.hpp)
+  if (sd.champ != nullptr && k <= 1024u && fid == 0) {  // (a filter may reject the champions)  // threshold seed (see slg_score.hpp)
     float f = 0.0f;
     if (lane < T && my_w > 0.0f)
       f = my_w * ((const gf32_t)sd.champ)[(size_t)my_term * kChampions + champ_index(k)];

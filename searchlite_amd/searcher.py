@@ -95,14 +95,47 @@ class GpuIndex:
         N.check(self._lib.slg_profile_read(self._h, C.addressof(n), C.addressof(ms)))
         return n.value, ms.value
 
+    # -- doc filters (accept = !deleted && filter, api/reader.rs:3009-3018) ---------
+    def add_filter(self, seg_masks) -> int:
+        """Register a filter: seg_masks[s] = boolean array over the docs of segment s (True =
+        passes) or None (all pass).  Returns the filter id queries refer to."""
+        assert len(seg_masks) == self.n_segs
+        packed = [None if m is None else np.packbits(np.asarray(m, dtype=bool), bitorder="little")
+                  for m in seg_masks]
+        ptrs = (C.c_void_p * self.n_segs)(*[None if b is None else b.ctypes.data for b in packed])
+        rc = self._lib.slg_index_add_filter(self._h, ptrs)
+        if rc < 0:
+            N.check(rc)
+        return rc
+
+    def add_filter_range(self, seg_columns, lo, hi) -> int:
+        """Filter built on the device from one numeric fast-field column per segment (int64 or
+        float64 arrays of n_docs values): doc passes iff lo <= value <= hi."""
+        assert len(seg_columns) == self.n_segs
+        cols = [np.ascontiguousarray(c) for c in seg_columns]
+        ptrs = (C.c_void_p * self.n_segs)(*[c.ctypes.data for c in cols])
+        if all(c.dtype == np.int64 for c in cols):
+            rc = self._lib.slg_index_add_filter_range_i64(self._h, ptrs, int(lo), int(hi))
+        elif all(c.dtype == np.float64 for c in cols):
+            rc = self._lib.slg_index_add_filter_range_f64(self._h, ptrs, float(lo), float(hi))
+        else:
+            raise TypeError("filter columns must all be int64 or all float64")
+        if rc < 0:
+            N.check(rc)
+        return rc
+
+    def remove_filter(self, filter_id: int) -> None:
+        N.check(self._lib.slg_index_remove_filter(self._h, filter_id))
+
     # -- search ----------------------------------------------------------------------
-    def prepare(self, q_offsets, q_terms, q_weights, k: int, strategy: int = Wand
-                ) -> "PreparedBatch":
-        return PreparedBatch(self, q_offsets, q_terms, q_weights, k, strategy)
+    def prepare(self, q_offsets, q_terms, q_weights, k: int, strategy: int = Wand,
+                q_filter=None) -> "PreparedBatch":
+        return PreparedBatch(self, q_offsets, q_terms, q_weights, k, strategy, q_filter)
 
     def search_batch(self, q_offsets, q_terms, q_weights, k: int, strategy: int = Wand,
-                     want_stats: bool = False):
-        """One-shot slg_search_batch over CSR queries -> (doc, seg, score, count[, stats])."""
+                     want_stats: bool = False, q_filter=None):
+        """One-shot slg_search_batch over CSR queries -> (doc, seg, score, count[, stats]).
+        q_filter: optional int array, one filter id per query (< 0: none)."""
         q_offsets = np.ascontiguousarray(q_offsets, dtype=np.uint32)
         nq = len(q_offsets) - 1
         q_terms = np.ascontiguousarray(q_terms, dtype=np.uint32).reshape(-1, self.n_segs)
@@ -117,9 +150,12 @@ class GpuIndex:
         out_score = np.zeros((nq, k), dtype=np.float32)
         out_count = np.zeros(nq, dtype=np.uint32)
         stats = (N.Stats * max(nq, 1))() if want_stats else None
-        N.check(self._lib.slg_search_batch(self._h, qs, nq, k, strategy, _ptr(out_doc),
-                                           _ptr(out_seg), _ptr(out_score), _ptr(out_count),
-                                           None if stats is None else C.addressof(stats)))
+        qf = None if q_filter is None else np.ascontiguousarray(q_filter, dtype=np.int32)
+        assert qf is None or len(qf) == nq
+        N.check(self._lib.slg_search_batch_filtered(
+            self._h, qs, nq, None if qf is None else _ptr(qf), k, strategy, _ptr(out_doc),
+            _ptr(out_seg), _ptr(out_score), _ptr(out_count),
+            None if stats is None else C.addressof(stats)))
         if want_stats:
             return out_doc, out_seg, out_score, out_count, stats
         return out_doc, out_seg, out_score, out_count
@@ -189,7 +225,8 @@ class GpuIndex:
 class PreparedBatch:
     """A planned query batch with device-resident descriptors and work buffers."""
 
-    def __init__(self, index: GpuIndex, q_offsets, q_terms, q_weights, k: int, strategy: int):
+    def __init__(self, index: GpuIndex, q_offsets, q_terms, q_weights, k: int, strategy: int,
+                 q_filter=None):
         self.index = index
         self._lib = index._lib
         q_offsets = np.ascontiguousarray(q_offsets, dtype=np.uint32)
@@ -197,8 +234,11 @@ class PreparedBatch:
         q_weights = np.ascontiguousarray(q_weights, dtype=np.float32)
         self.nq = len(q_offsets) - 1
         self.k = k
-        self._h = self._lib.slg_batch_prepare(index._h, self.nq, _ptr(q_offsets), _ptr(q_terms),
-                                              _ptr(q_weights), k, strategy)
+        qf = None if q_filter is None else np.ascontiguousarray(q_filter, dtype=np.int32)
+        assert qf is None or len(qf) == self.nq
+        self._h = self._lib.slg_batch_prepare_filtered(
+            index._h, self.nq, _ptr(q_offsets), _ptr(q_terms), _ptr(q_weights),
+            None if qf is None else _ptr(qf), k, strategy)
         if not self._h:
             msg = N.last_error()
             code = N.ERR_UNSUPPORTED if ("SLG_MAX" in msg or "more than" in msg) else N.ERR_INVALID

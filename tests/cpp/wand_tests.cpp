@@ -82,11 +82,25 @@ static void errors_do_not_unwind_across_the_abi() {
   CHECK(threw);
 }
 
+static void accept_predicate_filters_hits() {  // wand.rs:512/:555/:858 accept(doc, score)
+  Index ix({two_term_segment()});
+  auto only3 = execute_top_k_with_accept(ix, {{0, 1.0f}, {1, 1.0f}}, 2, ExecutionStrategy::Wand,
+                                         [](uint32_t d) { return d != 1; });
+  CHECK(only3.size() == 1 && only3[0].doc_id == 3 && std::fabs(only3[0].score - 6.6957893f) < 1e-5f);
+  auto none = execute_top_k_with_accept(ix, {{0, 1.0f}, {1, 1.0f}}, 2, ExecutionStrategy::Bm25,
+                                        [](uint32_t) { return false; });
+  CHECK(none.empty());
+  auto all = execute_top_k_with_accept(ix, {{0, 1.0f}, {1, 1.0f}}, 2, ExecutionStrategy::Bm25,
+                                       [](uint32_t) { return true; });
+  CHECK(all.size() == 2 && all[0].doc_id == 3 && all[1].doc_id == 1);
+}
+
 int main() {
   ranked_doc_ordering_prefers_smaller_id_on_tie();
   brute_force_matches_wand_results();
   stats_and_k_zero();
   errors_do_not_unwind_across_the_abi();
+  accept_predicate_filters_hits();
   std::puts("wand_tests: all passed");
   return 0;
 }

@@ -51,6 +51,10 @@ def test_null_arguments_fail_cleanly(lib):
     assert lib.slg_batch_fetch(None, None, None, None, None, None) == N.ERR_INVALID
     assert lib.slg_search_batch(None, None, 0, 11, 1, None, None, None, None, None) == N.ERR_INVALID
     assert lib.slg_index_info(None, None, None, None) == N.ERR_INVALID
+    assert lib.slg_index_add_filter(None, None) == N.ERR_INVALID
+    assert lib.slg_index_remove_filter(None, 0) == N.ERR_INVALID
+    assert lib.slg_batch_prepare_filtered(None, 0, None, None, None, None, 11, 1) is None
+    assert lib.slg_batch_set_stream(None, None) == N.ERR_INVALID
     lib.slg_index_destroy(None)
     lib.slg_batch_destroy(None)
 

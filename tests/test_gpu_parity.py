@@ -178,6 +178,47 @@ def test_large_k_select_multi_segment_deleted_ties(gpu, oracle, k):
         assert_same_hits(ix.search_batch(offs, terms, w, k, gpu.Bm25), want, 0.0, f"select bm25 k={k}")
 
 
+@pytest.mark.parametrize("k,T", [(11, 3), (101, 3), (300, 3), (11, 7)])
+def test_doc_filters_match_accept_semantics(gpu, oracle, k, T):
+    """accept = !deleted && filter (api/reader.rs:3009-3018).  Two segments with
+    tombstones; one bitmap filter, one numeric-range filter built on the device, unfiltered
+    queries mixed into the same batch; k = 11 (buffered top-k), 101, 300 (select kernel)."""
+    rng = np.random.default_rng(600 + k)
+    segs = [random_segment(rng, 3000 + 500 * i, 25, 14) for i in range(2)]
+    for i, sg in enumerate(segs):
+        sg.set_deleted(list(range(3 + i, sg.n_docs, 17)))
+    offs, terms, w = random_queries(rng, 30, T, 25, n_segs=2, weights=True)  # T = 7: packed kernel
+    masks = [rng.random(sg.n_docs) < 0.3 for sg in segs]
+    masks[1][:] = rng.random(segs[1].n_docs) < 0.05       # sparse in segment 1
+    cols = [rng.integers(0, 1000, sg.n_docs).astype(np.int64) for sg in segs]
+    fcols = [c.astype(np.float64) / 7.0 for c in cols]
+    fcols[0][::50] = np.nan
+    with gpu.GpuIndex(segs) as ix:
+        f_mask = ix.add_filter(masks)
+        f_none = ix.add_filter([None, masks[1]])
+        f_int = ix.add_filter_range(cols, 200, 450)
+        f_flt = ix.add_filter_range(fcols, 10.0, 90.0)
+        filters = {f_mask: masks, f_none: [None, masks[1]],
+                   f_int: [(c >= 200) & (c <= 450) for c in cols],
+                   f_flt: [(c >= 10.0) & (c <= 90.0) for c in fcols]}
+        ids = [f_mask, -1, f_int, f_flt, f_none]
+        q_filter = np.array([ids[q % 5] for q in range(30)], dtype=np.int32)
+        flist = [filters[i] for i in range(max(filters) + 1)]
+        want = oracle.search_batch_filtered(segs, offs, terms, w, k, q_filter, flist, strategy=oracle.BM25)
+        for strat in (gpu.Bm25, gpu.Wand):
+            got = ix.search_batch(offs, terms, w, k, strat, q_filter=q_filter)
+            assert_same_hits(got, want, 0.0, f"filtered k={k}")
+        b = ix.prepare(offs, terms, w, k, q_filter=q_filter)
+        b.run()
+        assert_same_hits(b.fetch(), want, 0.0, "filtered, prepared")
+        b.close()
+        ix.remove_filter(f_none)
+        with pytest.raises(gpu.SlgError):
+            ix.search_batch(offs, terms, w, k, q_filter=np.full(30, f_none, dtype=np.int32))
+        with pytest.raises(gpu.SlgError):
+            ix.search_batch(offs, terms, w, k, q_filter=np.full(30, 99, dtype=np.int32))
+
+
 def test_ragged_and_empty_inputs(gpu, oracle):
     rng = np.random.default_rng(3)
     seg = random_segment(rng, 300, 12, 10)

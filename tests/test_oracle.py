@@ -302,3 +302,27 @@ def test_builder_merges_tf_and_orders_docs():
     d, tf = seg.postings(seg.term_id("body:rust"))
     assert list(d) == [0, 1] and list(tf) == [2, 2]
     assert list(seg.field_doc_len[0]) == [3.0, 3.0] and seg.field_avgdl[0] == 3.0
+
+
+def test_filtered_search_is_the_scorer_with_the_filter_folded_into_accept(oracle):
+    O = oracle
+    """oracle.search_batch_filtered (SURVEY N3): accept = !deleted && filter.  Cross-checked by
+    brute force in numpy: score every doc, drop rejected ones, sort (score desc, doc asc)."""
+    rng = np.random.default_rng(91)
+    seg = random_segment(rng, 400, 10, 8)
+    seg.set_deleted(range(0, 400, 13))
+    offs, terms, w = random_queries(rng, 6, 2, 10)
+    mask = rng.random(400) < 0.4
+    q_filter = np.array([0, -1, 0, -1, 0, 0], dtype=np.int32)
+    got = O.search_batch_filtered([seg], offs, terms, w, 7, q_filter, [[mask]], strategy=O.BM25)
+    plain = O.search_batch([seg], offs, terms, w, 400, strategy=O.BM25)
+    dead = np.unpackbits(seg.deleted, bitorder="little")[:400].astype(bool)
+    for q in range(6):
+        n = int(plain[3][q])
+        docs, scores = plain[0][q, :n], plain[2][q, :n]
+        keep = ~dead[docs] if q_filter[q] < 0 else (~dead[docs] & mask[docs])
+        want_docs, want_scores = docs[keep][:7], scores[keep][:7]
+        m = int(got[3][q])
+        assert m == len(want_docs)
+        assert np.array_equal(got[0][q, :m], want_docs)
+        assert np.array_equal(got[2][q, :m].view(np.uint32), want_scores.view(np.uint32))
