@@ -25,6 +25,7 @@
 #include "slg_rerank.hpp"
 #include "slg_score.hpp"
 #include "slg_score_uni.hpp"
+#include "slg_score_multi.hpp"
 
 namespace {
 
@@ -153,6 +154,7 @@ struct slg_batch {
   int strategy = 0;
   uint32_t n_sq = 0, n_slices = 0, n_terms = 0, n_boundaries = 0, max_terms = 0;
   bool uniform = false;  // every sub-query fits the one-list-per-slot kernel
+  bool multi = false;    // many-term form of it (slg_score_multi.hpp); else the packed kernel
   uint64_t n_postings = 0, n_postings_essential = 0, n_rounds = 0;
   std::vector<uint64_t> q_postings;  // per query (stats.postings_advanced)
   bool own_stream_set = false;       // slg_batch_set_stream: run on `stream` instead of the index's
@@ -200,28 +202,29 @@ int kregs_for(uint32_t k) {
 namespace slg {
 // defined in slg_score_inst.hip, one translation unit per KREGS
 template <int KREGS>
-void launch_score_kregs(const RoundScoreParams &sp, uint32_t max_terms, bool uniform, hipStream_t st);
-template <> void launch_score_kregs<1>(const RoundScoreParams &, uint32_t, bool, hipStream_t);
-template <> void launch_score_kregs<2>(const RoundScoreParams &, uint32_t, bool, hipStream_t);
-template <> void launch_score_kregs<4>(const RoundScoreParams &, uint32_t, bool, hipStream_t);
-template <> void launch_score_kregs<8>(const RoundScoreParams &, uint32_t, bool, hipStream_t);
-template <> void launch_score_kregs<16>(const RoundScoreParams &, uint32_t, bool, hipStream_t);
+void launch_score_kregs(const RoundScoreParams &sp, uint32_t max_terms, int kind, hipStream_t st);
+template <> void launch_score_kregs<1>(const RoundScoreParams &, uint32_t, int, hipStream_t);
+template <> void launch_score_kregs<2>(const RoundScoreParams &, uint32_t, int, hipStream_t);
+template <> void launch_score_kregs<4>(const RoundScoreParams &, uint32_t, int, hipStream_t);
+template <> void launch_score_kregs<8>(const RoundScoreParams &, uint32_t, int, hipStream_t);
+template <> void launch_score_kregs<16>(const RoundScoreParams &, uint32_t, int, hipStream_t);
 }  // namespace slg
 namespace {
 
-void launch_score(const slg::RoundScoreParams &sp, uint32_t max_terms, bool uniform, hipStream_t st) {
+// kind: 0 packed (slg_score.hpp), 1 uniform (slg_score_uni.hpp), 2 multi (slg_score_multi.hpp)
+void launch_score(const slg::RoundScoreParams &sp, uint32_t max_terms, int kind, hipStream_t st) {
 #ifdef SLG_STAMPS  // diagnostic build: only the k <= 64 variant is compiled
   if (kregs_for(sp.k) != 1) throw SlgError(SLG_ERR_UNSUPPORTED, "stamps build supports k <= 64 only");
-  slg::launch_score_kregs<1>(sp, max_terms, uniform, st);
+  slg::launch_score_kregs<1>(sp, max_terms, kind, st);
   SLG_HIP(hipGetLastError());
   return;
 #else
   switch (kregs_for(sp.k)) {
-    case 1: slg::launch_score_kregs<1>(sp, max_terms, uniform, st); break;
-    case 2: slg::launch_score_kregs<2>(sp, max_terms, uniform, st); break;
-    case 4: slg::launch_score_kregs<4>(sp, max_terms, uniform, st); break;
-    case 8: slg::launch_score_kregs<8>(sp, max_terms, uniform, st); break;
-    default: slg::launch_score_kregs<16>(sp, max_terms, uniform, st); break;
+    case 1: slg::launch_score_kregs<1>(sp, max_terms, kind, st); break;
+    case 2: slg::launch_score_kregs<2>(sp, max_terms, kind, st); break;
+    case 4: slg::launch_score_kregs<4>(sp, max_terms, kind, st); break;
+    case 8: slg::launch_score_kregs<8>(sp, max_terms, kind, st); break;
+    default: slg::launch_score_kregs<16>(sp, max_terms, kind, st); break;
   }
   SLG_HIP(hipGetLastError());
 #endif
@@ -763,11 +766,17 @@ slg_batch *slg_batch_prepare_filtered(slg_index *ix, uint32_t nq, const uint32_t
     std::vector<uint32_t> slice_sq, slice_seg, bnd_sq;
     uint64_t n_bounds = 0, n_bnd = 0;
     // one-list-per-slot kernel (slg_score_uni.hpp): few terms, no non-essential lists
-    const uint32_t uni_max_terms = std::min<uint32_t>(env_u32("SLG_UNIFORM_MAX_TERMS", 6), slg::kUniSlots);
+    const uint32_t uni_max_terms = std::min<uint32_t>(env_u32("SLG_UNIFORM_MAX_TERMS", 5), slg::kUniSlots);
     b->uniform = env_u32("SLG_NO_UNIFORM", 0) == 0 && b->max_terms <= uni_max_terms;
     for (size_t i = 0; i < sqs.size() && b->uniform; i++) {
       const uint32_t full = sqs[i].n_terms >= 32 ? 0xFFFFFFFFu : ((1u << sqs[i].n_terms) - 1u);
       if (sqs[i].ess_mask != full) b->uniform = false;
+    }
+    // more terms (the multi-field shape): the same slots-of-one-list design, 8 slots at a time
+    b->multi = !b->uniform && env_u32("SLG_NO_MULTI", 0) == 0 && env_u32("SLG_NO_UNIFORM", 0) == 0;
+    for (size_t i = 0; i < sqs.size() && b->multi; i++) {
+      const uint32_t full = sqs[i].n_terms >= 32 ? 0xFFFFFFFFu : ((1u << sqs[i].n_terms) - 1u);
+      if (sqs[i].ess_mask != full) b->multi = false;
     }
     // rounds per slice: short slices pack the tail of the launch better (one wave per slice,
     // ~5 generations of waves per SIMD on config 2).  The uniform kernel's slices are cheap to
@@ -792,6 +801,9 @@ slg_batch *slg_batch_prepare_filtered(slg_index *ix, uint32_t nq, const uint32_t
         const uint32_t dflt = 64u * (slg::kUniSlots > t ? slg::kUniSlots - t : 0u) + 64u;
         round_target = std::max<uint32_t>(48, std::min<uint32_t>(
             env_u32("SLG_UNIFORM_ROUND_TARGET", dflt), slg::kUniCap));
+      } else if (b->multi) {
+        round_target = std::max<uint32_t>(64, std::min<uint32_t>(
+            env_u32("SLG_MULTI_ROUND_TARGET", slg::kMultiTarget), slg::kMultiCap));
       }
       // a round holds <= ~round_target postings of the essential lists (register slots) and
       // <= ~probe_target postings overall (non-essential lists are streamed per round), so
@@ -804,7 +816,9 @@ slg_batch *slg_batch_prepare_filtered(slg_index *ix, uint32_t nq, const uint32_t
       uint32_t want_rps = max_rps;
       if (!rps_pinned) want_rps = (uint32_t)std::min<uint64_t>(
           std::max<uint64_t>(max_rps, (nr + slices_per_sq - 1) / slices_per_sq), rps_cap);
-      const uint32_t rps = std::max<uint32_t>(1, std::min<uint32_t>(want_rps, 64 / sq.n_terms - 1));
+      // (the uniform / packed kernels keep a slice's cut points in one register: (rps+1)*T <= 64)
+      const uint32_t rps = b->multi ? std::max<uint32_t>(1, want_rps)
+                                    : std::max<uint32_t>(1, std::min<uint32_t>(want_rps, 64 / sq.n_terms - 1));
       const uint64_t S = (nr + rps - 1) / rps;
       SLG_REQUIRE(nr < 0x7FFFFFFFull && slice_sq.size() + S < 0x7FFFFFFFull &&
                       (slice_sq.size() + S) * (uint64_t)std::max<uint32_t>(k, 1) < 0xFFFFFFFFull,
@@ -826,7 +840,7 @@ slg_batch *slg_batch_prepare_filtered(slg_index *ix, uint32_t nq, const uint32_t
     }
     // large k: per-slice top-k lists would be mostly the slice itself; keep every doc above the
     // seed threshold instead (one candidate slot per posting) and select per query afterwards
-    b->cand_mode = b->uniform && k > 256 && env_u32("SLG_NO_CAND_MODE", 0) == 0;
+    b->cand_mode = (b->uniform || b->multi) && k > 256 && env_u32("SLG_NO_CAND_MODE", 0) == 0;
     uint64_t cand_total = 0;
     if (b->cand_mode)
       for (size_t i = 0; i < sqs.size(); i++) {
@@ -999,7 +1013,7 @@ int slg_batch_run(slg_batch *b) {
         ev = &ix->prof_events[ix->prof_used++];
         SLG_HIP(hipEventRecord(ev->first, st));
       }
-      launch_score(sp, b->max_terms, b->uniform, st);
+      launch_score(sp, b->max_terms, b->uniform ? 1 : (b->multi ? 2 : 0), st);
       if (ev) SLG_HIP(hipEventRecord(ev->second, st));
     }
     if (b->k > 0 && b->cand_mode && b->n_slices > 0) {

@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(256) score_rounds_kernel(RoundScoreParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wib = threadIdx.x >> 6;
-  const uint32_t widx = rfl(blockIdx.x * kWavesPerBlock + wib);
+  const uint32_t widx = rfl(blockIdx.x * (blockDim.x >> 6) + wib);
   if (widx >= p.n_slices) return;  // waves are independent: no workgroup barrier anywhere
   const uint32_t slice = rfl(p.slice_order[widx]);
 
@@ -445,13 +445,20 @@ __global__ void __launch_bounds__(256) score_rounds_kernel(RoundScoreParams p) {
 #pragma unroll
           for (int jj = 0; jj < kNSlot; jj++) am |= (((lmask >> jj) & 1u) && e.t(jj) == tc) ? 1u : 0u;
           if (__ballot(am != 0u) == 0ull) continue;
+          // only the slots that hold postings of list tc (uniform test): with many short lists
+          // that is one or two slots, not all eight
           uint32_t old[kNSlot];
 #pragma unroll
-          for (int jj = 0; jj < kNSlot; jj++) old[jj] = vals[slot[jj]];
+          for (int jj = 0; jj < kNSlot; jj++) {
+            old[jj] = 0;
+            if (tc >= tlo[jj] && tc <= thi[jj]) old[jj] = vals[slot[jj]];
+          }
 #pragma unroll
           for (int jj = 0; jj < kNSlot; jj++) {
-            const bool act = ((lmask >> jj) & 1u) && e.t(jj) == tc;
-            vals[act ? slot[jj] : kCap + lane] = __float_as_uint(__uint_as_float(old[jj]) + e.imp[jj]);
+            if (tc >= tlo[jj] && tc <= thi[jj]) {
+              const bool act = ((lmask >> jj) & 1u) && e.t(jj) == tc;
+              vals[act ? slot[jj] : kCap + lane] = __float_as_uint(__uint_as_float(old[jj]) + e.imp[jj]);
+            }
           }
           wave_fence();
         }

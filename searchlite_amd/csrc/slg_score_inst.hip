@@ -6,6 +6,7 @@
 
 #include "slg_score.hpp"
 #include "slg_score_uni.hpp"
+#include "slg_score_multi.hpp"
 
 #ifndef SLG_INST_KREGS
 #error "compile with -DSLG_INST_KREGS={1,2,4,8,16}"
@@ -15,18 +16,29 @@ namespace slg {
 
 template <int KREGS, int TT>
 static void launch_tt(const RoundScoreParams &sp, hipStream_t st) {
-  const uint32_t blocks = (sp.n_slices + kWavesPerBlock - 1) / kWavesPerBlock;
-  const size_t lds = (size_t)kWavesPerBlock * kScoreWaveLds;
-  hipLaunchKernelGGL((score_rounds_kernel<KREGS, TT>), dim3(blocks), dim3(256), lds, st, sp);
+  // waves are independent (no workgroup barrier): one-wave workgroups, as for the uniform kernel
+  static const uint32_t wpb = [] {
+    const char *e = getenv("SLG_PACKED_WAVES_PER_BLOCK");
+    const uint32_t v = e ? (uint32_t)atoi(e) : 1u;
+    return v >= 1 && v <= 4 ? v : 1u;
+  }();
+  const uint32_t blocks = (sp.n_slices + wpb - 1) / wpb;
+  const size_t lds = (size_t)wpb * kScoreWaveLds;
+  hipLaunchKernelGGL((score_rounds_kernel<KREGS, TT>), dim3(blocks), dim3(64 * wpb), lds, st, sp);
 }
 
 template <int KREGS>
-void launch_score_kregs(const RoundScoreParams &sp, uint32_t max_terms, bool uniform, hipStream_t st);
+void launch_score_kregs(const RoundScoreParams &sp, uint32_t max_terms, int kind, hipStream_t st);
 
 template <>
 void launch_score_kregs<SLG_INST_KREGS>(const RoundScoreParams &sp, uint32_t max_terms,
-                                        bool uniform, hipStream_t st) {
-  if (uniform) {  // one list per register slot (slg_score_uni.hpp); waves are independent, so
+                                        int kind, hipStream_t st) {
+  if (kind == 2) {  // many lists: slots of one list each, 8 at a time (slg_score_multi.hpp)
+    hipLaunchKernelGGL((score_multi_kernel<SLG_INST_KREGS>), dim3(sp.n_slices), dim3(64),
+                       (size_t)multi_wave_lds(SLG_INST_KREGS), st, sp);
+    return;
+  }
+  if (kind == 1) {  // one list per register slot (slg_score_uni.hpp); waves are independent, so
                   // one-wave workgroups: a finished wave frees its slot and LDS at once
     static const uint32_t wpb = [] {
       const char *e = getenv("SLG_UNI_WAVES_PER_BLOCK");

@@ -1,0 +1,293 @@
+// slg_score_multi.hpp — scoring kernel for queries with many terms (7..32 lists), the shape a
+// multi-field query string produces (one scored term per field and word, api/reader.rs:2971-3005).
+//
+// Same algorithm as slg_score_uni.hpp — exact pre-planned rounds, LDS bitmap + prefix popcount =
+// dense accumulator slot per doc, f32 sums in term order (query/wand.rs:459-566, planner.rs:122-135),
+// buffered top-k — and the same register shape: a 64-lane slot holds postings of ONE list, so a
+// slot's list, weight, count and address are wave-uniform scalars.  What differs: a round's lists
+// need up to 8 + T slots, more than the 8 a wave keeps in registers, so a round is processed in
+// two sweeps over batches of 8 consecutive slots:
+//   sweep A  load each batch, set one bitmap bit per posting (ds_or, no return value);
+//   P2       prefix popcount over the bitmap -> rank(doc) = accumulator slot;
+//   sweep C  load each batch again (L2 hits), rank every posting, add weight*impact into
+//            vals[rank] slot by slot = in list order; vals starts at +0.0, so a doc's sum is
+//            ((0.0 + x_a) + x_b) + ... exactly as the reference forms it; docid[rank] = doc;
+//   P4       walk the ranks in order (conflict-free LDS reads): finished sum + doc -> top-k.
+// No posting "owns" a doc, so P1 needs no returning atomics and P4 no per-posting reads.
+// A round whose postings exceed the 512 accumulators, or whose docs span more than the 16 384
+// doc window, is cut at a common doc id and finished in further chunks.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "slg_score_uni.hpp"
+
+namespace slg {
+
+constexpr int kMultiCap = 512;       // accumulators (= distinct docs) per chunk
+constexpr int kMultiTarget = 384;    // planned postings per round (host)
+constexpr int kMultiFill = 448;      // postings taken when a round has to be cut
+constexpr int multi_wave_lds(int kregs) {
+  return kSpanWords * 4 + kSpanWords * 4 + (kMultiCap + 64) * 4 + kMultiCap * 4 +
+         (uni_buffered(kregs) ? 128 * kregs * 8 : 0);
+}
+
+template <int KREGS>
+__global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) {
+  constexpr int NS = kUniSlots;
+  constexpr bool BUF = uni_buffered(KREGS);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t widx = blockIdx.x;
+  if (widx >= p.n_slices) return;
+  const uint32_t slice = rfl(p.slice_order[widx]);
+
+  uint32_t *bm = reinterpret_cast<uint32_t *>(smem);
+  uint32_t *pre = bm + kSpanWords;
+  uint32_t *vals = pre + kSpanWords;          // [kMultiCap] + 64 dump words
+  uint32_t *docid = vals + kMultiCap + 64;    // [kMultiCap]
+  uint4 *bm4 = reinterpret_cast<uint4 *>(bm);
+  uint4 *pre4 = reinterpret_cast<uint4 *>(pre);
+  uint4 *vals4 = reinterpret_cast<uint4 *>(vals);
+
+  const uint32_t sqi = rfl(p.slice_sq[slice]);
+  const RoundQuery s = p.sq[sqi];
+  const uint32_t T = rfl(s.n_terms);
+  const uint32_t rps = rfl(s.rounds_per_slice);
+  const uint32_t r0 = (slice - rfl(s.slice_begin)) * rps;
+  const uint32_t r_end = rfl(s.n_rounds) < r0 + rps ? rfl(s.n_rounds) : r0 + rps;
+  const uint32_t n_r = r_end - r0;
+  const SegDev sd = p.segs[s.seg];
+  const gu32_t gdocs = (gu32_t)sd.docs;
+  const gf32_t gimps = (gf32_t)sd.imps;
+  const uint32_t fid = rfl(s.filter);
+  const gu32_t gdel = (gu32_t)(fid ? p.reject_table[(size_t)(fid - 1) * p.n_segs + s.seg] : sd.deleted);
+  const uint32_t k = p.k;
+
+  // lane t < T: list t's posting offset, weight, term id
+  uint64_t my_off = 0;
+  float my_w = 0.0f;
+  uint32_t my_term = 0;
+  if (lane < T) {
+    const TermRef tr = p.terms[s.term_begin + lane];
+    my_off = tr.off;
+    my_w = tr.weight;
+    my_term = tr.term;
+  }
+  const uint32_t my_off_lo = (uint32_t)my_off, my_off_hi = (uint32_t)(my_off >> 32);
+  const gu32_t gbounds = (gu32_t)p.bounds + s.bounds_begin + (size_t)r0 * T;
+  const gu32_t grdoc = (gu32_t)p.rdoc + s.rdoc_begin + r0;
+
+  BufTopK<BUF ? KREGS : 1> btop;
+  btop.init(reinterpret_cast<uint64_t *>(docid + kMultiCap));
+  uint32_t ccur = 0;
+  uint64_t cbeg = 0;
+  if (!BUF) {  // k > 256: candidate region (see slg_score_uni.hpp)
+    const uint32_t b0 = lane < T ? gbounds[lane] : 0u;
+    cbeg = (((uint64_t)rfl(s.cand_hi) << 32) | rfl(s.cand_lo)) + wave_sum(b0);
+  }
+  uint2 *const creg = BUF ? nullptr : p.cand + cbeg;
+  if (sd.champ != nullptr && k <= 1024u && fid == 0) {  // threshold seed (see slg_score.hpp)
+    float f = 0.0f;
+    if (lane < T && my_w > 0.0f)
+      f = my_w * ((const gf32_t)sd.champ)[(size_t)my_term * kChampions + champ_index(k)];
+    float best = 0.0f;
+    for (uint32_t t = 0; t < T; t++)
+      best = fmaxf(best, __int_as_float((int)rl((uint32_t)__float_as_int(f), t)));
+    const bool anyneg = __ballot(lane < T && !(my_w >= 0.0f)) != 0ull;
+    if (best > 0.0f && !anyneg) btop.set_floor(best);
+  }
+  uint32_t n_scored = 0;
+
+  // slot descriptors of the current chunk: lane G = global slot G (list, count, 64-bit index)
+  uint32_t d_st = 0, d_cnt = 0, d_lo = 0, d_hi = 0;
+
+  // registers of one batch of 8 slots
+  uint32_t doc[NS];
+  float imp[NS];
+  auto load_batch = [&](const uint32_t b, const uint32_t dhi) {
+#pragma unroll
+    for (int jj = 0; jj < NS; jj++) {
+      const uint64_t base = ((uint64_t)rl(d_hi, b * 8u + jj) << 32) | rl(d_lo, b * 8u + jj);
+      doc[jj] = gdocs[base + lane];
+      imp[jj] = gimps[base + lane];
+    }
+#pragma unroll
+    for (int jj = 0; jj < NS; jj++) {  // lanes past the slot's count / docs past the cut: idle
+      const bool live = lane < rl(d_cnt, b * 8u + jj) && doc[jj] < dhi;
+      doc[jj] = live ? doc[jj] : kDocEnd;
+    }
+  };
+
+  for (uint32_t rr = 0; rr < n_r; rr++) {
+    // lane t: this round's range [cur, end) of list t; the round's doc range [dlo, rdhi)
+    uint32_t cur = 0, end = 0;
+    if (lane < T) {
+      cur = gbounds[rr * T + lane];
+      end = gbounds[(rr + 1) * T + lane];
+    }
+    uint32_t dlo = rfl(grdoc[rr]);
+    const uint32_t rdhi = rfl(grdoc[rr + 1]);
+    if (p.dbg & 4u) continue;
+
+    for (uint32_t guard = 0; guard < (1u << 22); guard++) {  // chunks of the round (usually one)
+      const uint32_t rem = end - cur;
+      const uint32_t R = wave_sum(rem);
+      if (R == 0) break;
+      uint32_t chunk = rem, dhi = rdhi;
+      bool cut = false;
+      if (R > (uint32_t)kMultiCap) {
+        // too many postings for the accumulators: take a proportional part of every list and
+        // cut at the smallest "last loaded doc" of the lists that were not taken whole
+        const float share = (float)kMultiFill / (float)R;
+        uint32_t c = (uint32_t)((float)rem * share);
+        c = c < 1u ? 1u : c;
+        chunk = rem < c ? rem : c;
+        uint32_t lastdoc = kDocEnd;
+        if (chunk < rem) lastdoc = gdocs[my_off + cur + chunk - 1];
+        const uint32_t bound = wave_min(lastdoc);
+        dhi = bound == kDocEnd ? rdhi : bound + 1u;
+        cut = true;
+      }
+      const uint32_t wbase = dlo & ~31u;
+      if (dhi - wbase > kSpan) {  // docs span more than one bitmap window
+        dhi = wbase + kSpan;
+        cut = true;
+      }
+      // ---- slots: list t takes ceil(chunk/64) consecutive global slots ----
+      const uint32_t m = (chunk + 63u) >> 6;
+      const uint32_t gs_incl = wave_incl_scan(m);
+      const uint32_t gs = gs_incl - m;            // first global slot of my list
+      const uint32_t S = rl(gs_incl, 63);          // slots in use (<= 8 + T <= 40)
+      {
+        // lane G: the list that owns slot G = number of lists that end at or before G
+        uint32_t tG = 0;
+        for (uint32_t t = 0; t < T; t++) tG += (rl(gs_incl, t) <= lane) ? 1u : 0u;
+        tG = tG < T ? tG : T - 1;
+        const uint32_t l_gs = __shfl(gs, (int)tG, 64), l_chunk = __shfl(chunk, (int)tG, 64);
+        const uint64_t l_abs = (((uint64_t)__shfl(my_off_hi, (int)tG, 64) << 32) |
+                                __shfl(my_off_lo, (int)tG, 64)) +
+                               __shfl(cur, (int)tG, 64);
+        const uint32_t kin = (lane - l_gs) * 64u;
+        const bool used = lane < S;
+        const uint32_t left = used && l_chunk > kin ? l_chunk - kin : 0u;
+        const uint64_t base = used ? l_abs + kin : 0ull;
+        d_st = tG;
+        d_cnt = left < 64u ? left : 64u;
+        d_lo = (uint32_t)base;
+        d_hi = (uint32_t)(base >> 32);
+      }
+      const uint32_t nb = (S + 7u) >> 3;
+      const uint32_t wspan = dhi - wbase;
+
+      // ---- P0: clear bitmap and accumulators ----
+      bm4[lane] = make_uint4(0u, 0u, 0u, 0u);
+      bm4[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
+      vals4[lane] = make_uint4(0u, 0u, 0u, 0u);
+      vals4[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
+      wave_fence();
+      // ---- sweep A: one bit per posting; what every list consumes (docs below the cut) ----
+      uint32_t consumed = 0;
+      for (uint32_t b = 0; b < nb; b++) {
+        load_batch(b, dhi);
+#pragma unroll
+        for (int jj = 0; jj < NS; jj++) {
+          const uint32_t rel = doc[jj] - wbase;
+          const bool in = rel < wspan;
+          if (in) atomicOr(&bm[rel & (kSpanWords - 1)], 1u << (rel >> 9));
+          const uint32_t cnt = (uint32_t)__popcll(__ballot(in));
+          consumed += lane == rl(d_st, b * 8u + jj) ? cnt : 0u;
+        }
+      }
+      wave_fence();
+      // ---- P2: exclusive prefix popcount (lane l owns words 4l..4l+3 and 256+4l..256+4l+3) ----
+      uint32_t ndocs;
+      {
+        const uint4 a = bm4[lane], bb = bm4[lane + 64];
+        const uint32_t c0 = __popc(a.x), c1 = c0 + __popc(a.y), c2 = c1 + __popc(a.z),
+                       c3 = c2 + __popc(a.w), c4 = c3 + __popc(bb.x), c5 = c4 + __popc(bb.y),
+                       c6 = c5 + __popc(bb.z), c7 = c6 + __popc(bb.w);
+        const uint32_t incl = wave_incl_scan(c7);
+        const uint32_t ex = incl - c7;
+        pre4[lane] = make_uint4(ex, ex + c0, ex + c1, ex + c2);
+        pre4[lane + 64] = make_uint4(ex + c3, ex + c4, ex + c5, ex + c6);
+        ndocs = rl(incl, 63);
+        n_scored += ndocs;
+      }
+      wave_fence();
+      // ---- sweep C: rank every posting, accumulate slot by slot (= in list order) ----
+      for (uint32_t b = 0; b < nb; b++) {
+        load_batch(b, dhi);
+        uint32_t rank[NS];
+        bool in[NS];
+        {
+          uint32_t wd[NS], pf[NS], bit[NS];
+#pragma unroll
+          for (int jj = 0; jj < NS; jj++) {
+            const uint32_t rel = doc[jj] - wbase;
+            const uint32_t wi = rel & (kSpanWords - 1);
+            in[jj] = rel < wspan;
+            bit[jj] = 1u << ((rel >> 9) & 31u);
+            wd[jj] = bm[wi];
+            pf[jj] = pre[wi];
+          }
+#pragma unroll
+          for (int jj = 0; jj < NS; jj++) rank[jj] = pf[jj] + __popc(wd[jj] & (bit[jj] - 1u));
+        }
+#pragma unroll
+        for (int jj = 0; jj < NS; jj++) {
+          if (__ballot(in[jj]) == 0ull) continue;  // unused slot
+          // score_tf: impact * weight (query/wand.rs:285); the slot's list weight is a scalar
+          const float w = __int_as_float((int)rl((uint32_t)__float_as_int(my_w), rl(d_st, b * 8u + jj)));
+          const uint32_t at = in[jj] ? rank[jj] : (uint32_t)kMultiCap + lane;
+          const uint32_t old = vals[at];
+          vals[at] = __float_as_uint(__uint_as_float(old) + imp[jj] * w);
+          if (in[jj]) docid[rank[jj]] = doc[jj];
+          wave_fence();
+        }
+      }
+      wave_fence();
+      // ---- P4: the docs of the chunk in rank order -> top-k ----
+      for (uint32_t base = 0; base < ndocs; base += 64) {
+        const uint32_t r = base + lane;
+        const bool have = r < ndocs;
+        const uint32_t v = vals[have ? r : 0u];
+        const uint32_t d = docid[have ? r : 0u];
+        const uint32_t ok = ordered_score(__uint_as_float(v));
+        const bool ps = have && btop.passes(((uint64_t)ok << 32) | (uint32_t)~d);
+        if constexpr (BUF) {
+          btop.append_checked(ps, ok, ~d, k, lane, (const uint32_t *)gdel);
+        } else {
+          const uint64_t mm = __ballot(ps);
+          if (mm != 0ull) {
+            const uint32_t at = ccur + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32),
+                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+            if (ps) creg[at] = make_uint2(ok, d);
+            ccur += (uint32_t)__popcll(mm);
+          }
+        }
+      }
+      wave_fence();
+      // ---- advance ----
+      if (!cut) break;  // the whole rest of the round was in this chunk
+      cur += consumed;
+      uint32_t firstdoc = kDocEnd;  // next chunk starts at the smallest doc not yet scored
+      if (cur < end) firstdoc = gdocs[my_off + cur];
+      dlo = wave_min(firstdoc);
+      if (dlo == kDocEnd) break;
+    }
+  }
+
+  // ---- write this slice's candidates ----
+  if constexpr (BUF) {
+    btop.write_out(p.slice_tk + (size_t)slice * k, p.slice_doc + (size_t)slice * k, k, lane,
+                   (const uint32_t *)gdel);
+  } else if (lane == 0) {
+    p.slice_cbeg[slice] = cbeg;
+    p.slice_ccnt[slice] = ccur;
+  }
+  if (p.q_scored && lane == 0 && n_scored) atomicAdd(&p.q_scored[s.q], n_scored);
+}
+
+}  // namespace slg
