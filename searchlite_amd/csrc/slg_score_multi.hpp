@@ -26,7 +26,7 @@
 namespace slg {
 
 constexpr int kMultiCap = 512;       // accumulators (= distinct docs) per chunk
-constexpr int kMultiTarget = 384;    // planned postings per round (host)
+constexpr int kMultiTarget = 448;    // planned postings per round (host; measured optimum 448-480)
 constexpr int kMultiFill = 448;      // postings taken when a round has to be cut
 constexpr int multi_wave_lds(int kregs) {
   return kSpanWords * 4 + kSpanWords * 4 + (kMultiCap + 64) * 4 + kMultiCap * 4 +
@@ -103,20 +103,23 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
   // slot descriptors of the current chunk: lane G = global slot G (list, count, 64-bit index)
   uint32_t d_st = 0, d_cnt = 0, d_lo = 0, d_hi = 0;
 
-  // registers of one batch of 8 slots
-  uint32_t doc[NS];
-  float imp[NS];
-  auto load_batch = [&](const uint32_t b, const uint32_t dhi) {
+  // registers of one batch of 8 slots, and of the next one (in flight while this one is used)
+  uint32_t doc[NS], ndoc[NS];
+  float imp[NS], nimp[NS];
+  auto issue_batch = [&](const uint32_t b) {
 #pragma unroll
     for (int jj = 0; jj < NS; jj++) {
       const uint64_t base = ((uint64_t)rl(d_hi, b * 8u + jj) << 32) | rl(d_lo, b * 8u + jj);
-      doc[jj] = gdocs[base + lane];
-      imp[jj] = gimps[base + lane];
+      ndoc[jj] = gdocs[base + lane];
+      nimp[jj] = gimps[base + lane];
     }
+  };
+  auto take_batch = [&](const uint32_t b, const uint32_t dhi) {
 #pragma unroll
     for (int jj = 0; jj < NS; jj++) {  // lanes past the slot's count / docs past the cut: idle
-      const bool live = lane < rl(d_cnt, b * 8u + jj) && doc[jj] < dhi;
-      doc[jj] = live ? doc[jj] : kDocEnd;
+      const bool live = lane < rl(d_cnt, b * 8u + jj) && ndoc[jj] < dhi;
+      doc[jj] = live ? ndoc[jj] : kDocEnd;
+      imp[jj] = nimp[jj];
     }
   };
 
@@ -189,8 +192,10 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
       wave_fence();
       // ---- sweep A: one bit per posting; what every list consumes (docs below the cut) ----
       uint32_t consumed = 0;
+      issue_batch(0);
       for (uint32_t b = 0; b < nb; b++) {
-        load_batch(b, dhi);
+        take_batch(b, dhi);
+        issue_batch(b + 1 < nb ? b + 1 : 0);  // (after the last batch: sweep C's first)
 #pragma unroll
         for (int jj = 0; jj < NS; jj++) {
           const uint32_t rel = doc[jj] - wbase;
@@ -218,7 +223,8 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
       wave_fence();
       // ---- sweep C: rank every posting, accumulate slot by slot (= in list order) ----
       for (uint32_t b = 0; b < nb; b++) {
-        load_batch(b, dhi);
+        take_batch(b, dhi);
+        if (b + 1 < nb) issue_batch(b + 1);
         uint32_t rank[NS];
         bool in[NS];
         {
