@@ -766,7 +766,7 @@ slg_batch *slg_batch_prepare_filtered(slg_index *ix, uint32_t nq, const uint32_t
     std::vector<uint32_t> slice_sq, slice_seg, bnd_sq;
     uint64_t n_bounds = 0, n_bnd = 0;
     // one-list-per-slot kernel (slg_score_uni.hpp): few terms, no non-essential lists
-    const uint32_t uni_max_terms = std::min<uint32_t>(env_u32("SLG_UNIFORM_MAX_TERMS", 5), slg::kUniSlots);
+    const uint32_t uni_max_terms = std::min<uint32_t>(env_u32("SLG_UNIFORM_MAX_TERMS", 4), slg::kUniSlots);
     b->uniform = env_u32("SLG_NO_UNIFORM", 0) == 0 && b->max_terms <= uni_max_terms;
     for (size_t i = 0; i < sqs.size() && b->uniform; i++) {
       const uint32_t full = sqs[i].n_terms >= 32 ? 0xFFFFFFFFu : ((1u << sqs[i].n_terms) - 1u);
