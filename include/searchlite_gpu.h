@@ -184,6 +184,25 @@ slg_batch *slg_batch_prepare(slg_index *index, uint32_t nq, const uint32_t *q_of
 slg_batch *slg_batch_prepare_filtered(slg_index *index, uint32_t nq, const uint32_t *q_offsets,
                                       const uint32_t *q_term_ids, const float *q_weights,
                                       const int32_t *q_filter, uint32_t k, int strategy);
+/* Same with a score plan per query (query/planner.rs:113-153).  The reference adds
+ * every scored term's contribution to a ScorePlan leaf (wand.rs:488-497 `buf[term.leaf] +=`) and
+ * combines the leaves: a multi-field query string maps all fields of a word to one leaf and sums
+ * the leaves; multi_match best_fields / dis_max take DisMax over the leaves.
+ *   q_leaf[i]   leaf of query term i (same indexing as q_weights); NULL: term i of a query is
+ *               leaf i (the plain disjunction)
+ *   q_plan[q]   SLG_PLAN_SUM or SLG_PLAN_DISMAX over the leaves; NULL: SUM
+ *   q_tie[q]    DisMax tie breaker (max + tie * (sum - max)); NULL: 0
+ *   q_nleaves[q] leaves of the plan (>= max leaf + 1; leaves without a term count as 0.0 in a
+ *               DisMax); NULL: max leaf + 1
+ * Results are bit-identical to the reference's exhaustive scorer (per-leaf sums in term order,
+ * leaves combined in leaf order). */
+#define SLG_PLAN_SUM 0
+#define SLG_PLAN_DISMAX 1
+slg_batch *slg_batch_prepare_plan(slg_index *index, uint32_t nq, const uint32_t *q_offsets,
+                                  const uint32_t *q_term_ids, const float *q_weights,
+                                  const uint32_t *q_leaf, const int32_t *q_plan, const float *q_tie,
+                                  const uint32_t *q_nleaves, const int32_t *q_filter, uint32_t k,
+                                  int strategy);
 /* Enqueue the partition / score / merge kernels on the batch's stream (asynchronous). */
 int slg_batch_run(slg_batch *batch);
 /* Run this batch on its own HIP stream instead of the index stream, so several prepared

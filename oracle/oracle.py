@@ -82,6 +82,11 @@ def lib():
                                        C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_int,
                                        C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]
+        L.slo_search_batch_plan.restype = C.c_int
+        L.slo_search_batch_plan.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.slo_normalize_in_place.restype = None
         L.slo_normalize_in_place.argtypes = [C.c_void_p, C.c_uint32]
         L.slo_metric_similarity.restype = f32
@@ -165,11 +170,18 @@ def _pack_segments(segments):
     return arr, keep
 
 
+PLAN_SUM, PLAN_DISMAX = 0, 1
+
+
 def search_batch(segments, q_offsets, q_terms, q_weights, k, strategy=WAND, block_size=None,
-                 n_threads=1, cache_min_len=False, want_stats=False):
+                 n_threads=1, cache_min_len=False, want_stats=False, q_leaf=None, q_plan=None,
+                 q_tie=None, q_nleaves=None):
     """api/reader.rs search() over segments for a batch of pure-disjunction queries.
 
     q_terms has shape [total_query_terms, n_segs] (per-segment term ids, NO_TERM if absent).
+    Score plans (query/planner.rs:113-153): q_leaf[i] = leaf of query term i (default: term i of
+    a query is leaf i), q_plan[q] = PLAN_SUM | PLAN_DISMAX over the leaves, q_tie[q] = DisMax
+    tie breaker, q_nleaves[q] = leaves of the plan.
     Returns (doc[nq,k], seg[nq,k], score[nq,k], count[nq]).
     """
     segs, keep = _pack_segments(segments)
@@ -182,10 +194,15 @@ def search_batch(segments, q_offsets, q_terms, q_weights, k, strategy=WAND, bloc
     out_score = np.zeros((nq, k), dtype=np.float32)
     out_count = np.zeros(nq, dtype=np.uint32)
     stats = (Stats * max(nq, 1))() if want_stats else None
-    rc = lib().slo_search_batch(segs, len(segments), nq, _ptr(q_offsets), _ptr(q_terms),
-                                _ptr(q_weights), k, strategy, block_size or 0, n_threads,
-                                int(cache_min_len), _ptr(out_doc), _ptr(out_seg), _ptr(out_score),
-                                _ptr(out_count), None if stats is None else C.addressof(stats))
+    ql = None if q_leaf is None else np.ascontiguousarray(q_leaf, dtype=np.uint32)
+    qp = None if q_plan is None else np.ascontiguousarray(q_plan, dtype=np.int32)
+    qt = None if q_tie is None else np.ascontiguousarray(q_tie, dtype=np.float32)
+    qn = None if q_nleaves is None else np.ascontiguousarray(q_nleaves, dtype=np.uint32)
+    rc = lib().slo_search_batch_plan(segs, len(segments), nq, _ptr(q_offsets), _ptr(q_terms),
+                                     _ptr(q_weights), _ptr(ql), _ptr(qp), _ptr(qt), _ptr(qn), k,
+                                     strategy, block_size or 0, n_threads, int(cache_min_len),
+                                     _ptr(out_doc), _ptr(out_seg), _ptr(out_score), _ptr(out_count),
+                                     None if stats is None else C.addressof(stats))
     if rc != 0:
         raise RuntimeError(f"slo_search_batch failed: {rc}")
     if want_stats:

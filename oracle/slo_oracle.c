@@ -234,11 +234,31 @@ static int finalize_heap(bheap *heap, uint32_t *out_doc, float *out_score) {
   return (int)heap->len;
 }
 
-/* query/planner.rs:122-135: Sum([Leaf(0..n)]) => iterator .sum::<f32>(); since Rust 1.83
- * the f32 Sum identity is -0.0 (toolchain pin is 1.92, rust-toolchain.toml:2). */
-static inline float plan_evaluate(const float *leaves, uint32_t leaf_count) {
+/* ScorePlan root over the leaves (query/planner.rs:113-153).
+ * SLO_PLAN_SUM: Sum([Leaf(0..n)]) => iterator .sum::<f32>() (:126); since Rust 1.83 the f32 Sum
+ * identity is -0.0 (toolchain pin is 1.92, rust-toolchain.toml:2).
+ * SLO_PLAN_DISMAX: DisMax{children: leaves, tie_breaker} (:127-151): empty => 0.0; max starts
+ * at -inf, sum at 0.0; every child counts (a leaf without contributions evaluates to 0.0);
+ * result max + tie * (sum - max). */
+typedef struct {
+  int kind;
+  float tie;
+  uint32_t leaf_count;
+} plan_t;
+
+static inline float plan_evaluate(const plan_t *p, const float *leaves) {
+  if (p->kind == SLO_PLAN_DISMAX) {
+    if (p->leaf_count == 0) return 0.0f;
+    float mx = -INFINITY, sum = 0.0f;
+    for (uint32_t i = 0; i < p->leaf_count; i++) {
+      float sc = leaves[i];
+      mx = fmaxf(mx, sc);
+      sum += sc;
+    }
+    return mx + p->tie * (sum - mx);
+  }
   float s = -0.0f;
-  for (uint32_t i = 0; i < leaf_count; i++) s += leaves[i];
+  for (uint32_t i = 0; i < p->leaf_count; i++) s += leaves[i];
   return s;
 }
 
@@ -278,16 +298,14 @@ static inline uint32_t docmap_slot(docmap *m, uint32_t doc, int *is_new) {
   }
 }
 
-static int brute_force(const slo_term *terms, uint32_t n_terms, uint32_t k, int use_plan,
+static int brute_force(const slo_term *terms, uint32_t n_terms, uint32_t k, const plan_t *plan,
                        const uint8_t *deleted, uint32_t *out_doc, float *out_score,
                        slo_stats *stats) {
+  const int use_plan = plan != NULL;
   uint64_t total = 0;
-  uint32_t leaf_count = 0;
-  for (uint32_t t = 0; t < n_terms; t++) {
-    total += terms[t].len;
-    if (terms[t].leaf + 1 > leaf_count) leaf_count = terms[t].leaf + 1;
-  }
-  uint32_t width = use_plan ? leaf_count : 1;
+  for (uint32_t t = 0; t < n_terms; t++) total += terms[t].len;
+  const uint32_t leaf_count = use_plan ? plan->leaf_count : 0;
+  uint32_t width = use_plan ? (leaf_count ? leaf_count : 1) : 1;
   docmap map;
   docmap_init(&map, total);
   float *vals = (float *)calloc((size_t)(map.mask + 1) * width, sizeof(float));
@@ -314,7 +332,7 @@ static int brute_force(const slo_term *terms, uint32_t n_terms, uint32_t k, int 
   for (uint32_t s = 0; s <= map.mask; s++) {
     uint32_t doc = map.keys[s];
     if (doc == SLO_DOCID_END) continue;
-    float score = use_plan ? plan_evaluate(&vals[(size_t)s * width], leaf_count) : vals[s];
+    float score = use_plan ? plan_evaluate(plan, &vals[(size_t)s * width]) : vals[s];
     if (is_deleted(deleted, doc)) continue; /* accept */
     if (k > 0) push_top_k(&heap, rd_pack(doc, score), k);
   }
@@ -473,8 +491,10 @@ static int termq_cmp(const void *ctx, uint64_t a, uint64_t b) {
 /* wand_loop  query/wand.rs:659-903 (no collector, no score_adjust)                      */
 /* ------------------------------------------------------------------------------------ */
 static int wand_loop(term_state *st, uint32_t n_states, uint32_t k, int use_block_bounds,
-                     int use_plan, uint32_t leaf_count, const uint8_t *deleted,
+                     const plan_t *plan, const uint8_t *deleted,
                      uint32_t *out_doc, float *out_score, slo_stats *stats) {
+  const int use_plan = plan != NULL;
+  const uint32_t leaf_count = use_plan ? plan->leaf_count : 0;
   int rank_hits = k > 0;
   bheap heap;
   bheap_init(&heap, ranked_rev_cmp, NULL, (size_t)k + 1);
@@ -554,7 +574,7 @@ static int wand_loop(term_state *st, uint32_t n_states, uint32_t k, int use_bloc
         stats->scored_docs += 1;
       }
       float score = score_sum;
-      if (use_plan) score = plan_evaluate(leaf_scores, leaf_count); /* :834-839 */
+      if (use_plan) score = plan_evaluate(plan, leaf_scores); /* :834-839 */
       for (uint32_t i = 0; i < n_touched; i++) {                   /* :848-852 */
         leaf_scores[touched[i]] = 0.0f;
         touched_flags[touched[i]] = 0;
@@ -590,28 +610,48 @@ static int wand_loop(term_state *st, uint32_t n_states, uint32_t k, int use_bloc
 }
 
 /* query/wand.rs:398-456 */
-int slo_execute_top_k(const slo_term *terms, uint32_t n_terms, uint32_t k, int strategy,
-                      uint32_t block_size, int use_plan, const uint8_t *deleted,
-                      const float *min_len_cache, uint32_t *out_doc, float *out_score,
-                      slo_stats *stats) {
+static int execute_with_plan(const slo_term *terms, uint32_t n_terms, uint32_t k, int strategy,
+                             uint32_t block_size, const plan_t *plan, const uint8_t *deleted,
+                             const float *min_len_cache, uint32_t *out_doc, float *out_score,
+                             slo_stats *stats) {
   if (n_terms == 0 || k == 0) return 0; /* :413-416 (no collector) */
   if (strategy == SLO_BM25)
-    return brute_force(terms, n_terms, k, use_plan, deleted, out_doc, out_score, stats);
+    return brute_force(terms, n_terms, k, plan, deleted, out_doc, out_score, stats);
   uint32_t bsize = block_size ? block_size : SLO_DEFAULT_BLOCK_SIZE;
   if (bsize < 1) bsize = 1;
   term_state *st = (term_state *)malloc((n_terms ? n_terms : 1) * sizeof(term_state));
-  uint32_t ns = 0, leaf_count = 0;
+  uint32_t ns = 0;
   for (uint32_t t = 0; t < n_terms; t++) {
-    if (terms[t].leaf + 1 > leaf_count) leaf_count = terms[t].leaf + 1;
     if (terms[t].len == 0) continue; /* :439-441 filter(postings.len() > 0) */
     term_state_new(&st[ns], &terms[t], bsize, min_len_cache ? &min_len_cache[t] : NULL);
     ns++;
   }
-  int n = wand_loop(st, ns, k, strategy == SLO_BMW, use_plan, leaf_count, deleted, out_doc,
-                    out_score, stats);
+  int n = wand_loop(st, ns, k, strategy == SLO_BMW, plan, deleted, out_doc, out_score, stats);
   for (uint32_t i = 0; i < ns; i++) term_state_free(&st[i]);
   free(st);
   return n;
+}
+
+int slo_execute_top_k(const slo_term *terms, uint32_t n_terms, uint32_t k, int strategy,
+                      uint32_t block_size, int use_plan, const uint8_t *deleted,
+                      const float *min_len_cache, uint32_t *out_doc, float *out_score,
+                      slo_stats *stats) {
+  plan_t plan = {SLO_PLAN_SUM, 0.0f, 0};
+  for (uint32_t t = 0; t < n_terms; t++)
+    if (terms[t].leaf + 1 > plan.leaf_count) plan.leaf_count = terms[t].leaf + 1;
+  return execute_with_plan(terms, n_terms, k, strategy, block_size, use_plan ? &plan : NULL, deleted,
+                           min_len_cache, out_doc, out_score, stats);
+}
+
+int slo_execute_top_k_plan(const slo_term *terms, uint32_t n_terms, uint32_t k, int strategy,
+                           uint32_t block_size, int plan_kind, float tie_breaker,
+                           uint32_t leaf_count, const uint8_t *deleted, const float *min_len_cache,
+                           uint32_t *out_doc, float *out_score, slo_stats *stats) {
+  plan_t plan = {plan_kind, tie_breaker, leaf_count};
+  for (uint32_t t = 0; t < n_terms; t++)
+    if (terms[t].leaf + 1 > plan.leaf_count) plan.leaf_count = terms[t].leaf + 1;
+  return execute_with_plan(terms, n_terms, k, strategy, block_size, &plan, deleted, min_len_cache,
+                           out_doc, out_score, stats);
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -646,12 +686,21 @@ typedef struct {
   uint32_t *out_count;
   slo_stats *stats; /* per query or NULL */
   int tid, n_threads;
+  const uint32_t *q_leaf;    /* per query term, or NULL: term i of a query is leaf i */
+  const int32_t *q_plan;     /* per query SLO_PLAN_*, or NULL: SUM */
+  const float *q_tie;        /* per query, or NULL */
+  const uint32_t *q_nleaves; /* per query (leaves of the plan), or NULL: max leaf + 1 */
 } batch_ctx;
 
 static void run_query(const batch_ctx *c, uint32_t q, slo_term *terms, float *mins, uint32_t *tmp_doc,
                       float *tmp_score, seg_hit *hits) {
   uint32_t t0 = c->q_offsets[q], nt = c->q_offsets[q + 1] - t0;
   uint32_t n_hits = 0;
+  uint32_t n_leaves = c->q_nleaves ? c->q_nleaves[q] : 0;
+  for (uint32_t i = 0; i < nt; i++) {
+    uint32_t lf = c->q_leaf ? c->q_leaf[t0 + i] : i;
+    if (lf + 1 > n_leaves) n_leaves = lf + 1;
+  }
   for (uint32_t s = 0; s < c->n_segs; s++) {
     const slo_segment *seg = &c->segs[s];
     uint32_t n = 0;
@@ -670,7 +719,7 @@ static void run_query(const batch_ctx *c, uint32_t q, slo_term *terms, float *mi
       t->docs = seg->docs;
       t->k1 = seg->k1;
       t->b = seg->b;
-      t->leaf = i;
+      t->leaf = c->q_leaf ? c->q_leaf[t0 + i] : i;
       /* field_lengths_for (api/reader.rs:3604-3621) always yields Some(vec of len doc_count) */
       t->doc_lengths = seg->field_doc_len[field];
       t->n_doc_lengths = seg->field_doc_len[field] ? seg->n_docs : 0;
@@ -678,9 +727,11 @@ static void run_query(const batch_ctx *c, uint32_t q, slo_term *terms, float *mi
       n++;
     }
     if (n == 0) continue; /* api/reader.rs:3003-3005 */
-    int got = slo_execute_top_k(terms, n, c->k, c->strategy, c->block_size, 1, seg->deleted,
-                                c->min_len ? mins : NULL, tmp_doc, tmp_score,
-                                c->stats ? &c->stats[q] : NULL);
+    int got = slo_execute_top_k_plan(terms, n, c->k, c->strategy, c->block_size,
+                                     c->q_plan ? c->q_plan[q] : SLO_PLAN_SUM,
+                                     c->q_tie ? c->q_tie[q] : 0.0f, n_leaves, seg->deleted,
+                                     c->min_len ? mins : NULL, tmp_doc, tmp_score,
+                                     c->stats ? &c->stats[q] : NULL);
     for (int i = 0; i < got; i++) {
       hits[n_hits].score = tmp_score[i];
       hits[n_hits].seg = s;
@@ -725,6 +776,17 @@ int slo_search_batch(const slo_segment *segs, uint32_t n_segs, uint32_t nq,
                      uint32_t k, int strategy, uint32_t block_size, int n_threads,
                      int cache_min_len, uint32_t *out_doc, uint32_t *out_seg, float *out_score,
                      uint32_t *out_count, slo_stats *stats_or_null) {
+  return slo_search_batch_plan(segs, n_segs, nq, q_offsets, q_terms, q_weights, NULL, NULL, NULL, NULL,
+                               k, strategy, block_size, n_threads, cache_min_len, out_doc, out_seg,
+                               out_score, out_count, stats_or_null);
+}
+
+int slo_search_batch_plan(const slo_segment *segs, uint32_t n_segs, uint32_t nq,
+                          const uint32_t *q_offsets, const uint32_t *q_terms, const float *q_weights,
+                          const uint32_t *q_leaf, const int32_t *q_plan, const float *q_tie,
+                          const uint32_t *q_nleaves, uint32_t k, int strategy, uint32_t block_size,
+                          int n_threads, int cache_min_len, uint32_t *out_doc, uint32_t *out_seg,
+                          float *out_score, uint32_t *out_count, slo_stats *stats_or_null) {
   if (!segs || !q_offsets || !out_doc || !out_seg || !out_score || !out_count) return -1;
   if (n_threads < 1) n_threads = 1;
   if (nq == 0) return 0;
@@ -751,7 +813,7 @@ int slo_search_batch(const slo_segment *segs, uint32_t n_segs, uint32_t nq,
   for (int t = 0; t < n_threads; t++) {
     batch_ctx c = {segs,      n_segs,   nq,        q_offsets, q_terms,   q_weights, k,
                    strategy,  block_size, min_len, max_fields, out_doc,  out_seg,   out_score,
-                   out_count, stats_or_null, t,    n_threads};
+                   out_count, stats_or_null, t,    n_threads, q_leaf, q_plan, q_tie, q_nleaves};
     ctxs[t] = c;
   }
   if (n_threads == 1) {

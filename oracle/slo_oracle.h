@@ -30,6 +30,7 @@ extern "C" {
 
 enum { SLO_BM25 = 0, SLO_WAND = 1, SLO_BMW = 2 }; /* api/types.rs:6-13 ExecutionStrategy */
 enum { SLO_COSINE = 0, SLO_L2 = 1 };              /* VectorMetric */
+enum { SLO_PLAN_SUM = 0, SLO_PLAN_DISMAX = 1 };   /* ScoreExpr root over the leaves (planner.rs:113-153) */
 
 /* query/wand.rs:65-75 ScoredTerm (postings held as SoA doc_ids/tfs instead of
  * Vec<PostingEntry>; positions are never read on this path). */
@@ -78,6 +79,15 @@ int slo_execute_top_k(const slo_term *terms, uint32_t n_terms, uint32_t k, int s
                       const float *min_len_cache, uint32_t *out_doc, float *out_score,
                       slo_stats *stats);
 
+/* Same with an explicit ScorePlan root over the leaves: SLO_PLAN_SUM (Sum of leaves) or
+ * SLO_PLAN_DISMAX (DisMax of leaves with tie_breaker), query/planner.rs:113-153.  A leaf's value
+ * is the sum of the scores of the terms mapped to it (wand.rs:488-497 / :820-826); leaf_count =
+ * leaves of the plan (>= max(term.leaf)+1; leaves without terms evaluate to 0.0). */
+int slo_execute_top_k_plan(const slo_term *terms, uint32_t n_terms, uint32_t k, int strategy,
+                           uint32_t block_size, int plan_kind, float tie_breaker,
+                           uint32_t leaf_count, const uint8_t *deleted, const float *min_len_cache,
+                           uint32_t *out_doc, float *out_score, slo_stats *stats);
+
 /* One index segment in the layout the scorer consumes (api/reader.rs:2985-3000). */
 typedef struct {
   uint32_t n_docs;
@@ -111,6 +121,16 @@ int slo_search_batch(const slo_segment *segs, uint32_t n_segs, uint32_t nq,
                      uint32_t k, int strategy, uint32_t block_size, int n_threads,
                      int cache_min_len, uint32_t *out_doc, uint32_t *out_seg, float *out_score,
                      uint32_t *out_count, slo_stats *stats_or_null);
+
+/* slo_search_batch with score plans: q_leaf[i] = leaf of query term i (NULL: term
+ * i of a query is leaf i), q_plan[q] = SLO_PLAN_* (NULL: SUM), q_tie[q] = DisMax tie breaker,
+ * q_nleaves[q] = leaves of the plan (NULL: max leaf + 1). */
+int slo_search_batch_plan(const slo_segment *segs, uint32_t n_segs, uint32_t nq,
+                          const uint32_t *q_offsets, const uint32_t *q_terms, const float *q_weights,
+                          const uint32_t *q_leaf, const int32_t *q_plan, const float *q_tie,
+                          const uint32_t *q_nleaves, uint32_t k, int strategy, uint32_t block_size,
+                          int n_threads, int cache_min_len, uint32_t *out_doc, uint32_t *out_seg,
+                          float *out_score, uint32_t *out_count, slo_stats *stats_or_null);
 
 /* vectors/mod.rs:74-81 */
 void slo_normalize_in_place(float *v, uint32_t dim);

@@ -18,6 +18,7 @@ MAX_K = 1024
 OK, ERR_INVALID, ERR_DEVICE, ERR_OOM, ERR_UNSUPPORTED, ERR_INTERNAL = 0, -1, -2, -3, -4, -5
 STRATEGY_BM25, STRATEGY_WAND, STRATEGY_BMW = 0, 1, 2
 METRIC_COSINE, METRIC_L2 = 0, 1
+PLAN_SUM, PLAN_DISMAX = 0, 1
 
 
 class SlgError(RuntimeError):
@@ -93,6 +94,7 @@ def load():
         "slg_search_batch_filtered": (i32, [vp, vp, u32, vp, u32, i32, vp, vp, vp, vp, vp]),
         "slg_batch_prepare": (vp, [vp, u32, vp, vp, vp, u32, i32]),
         "slg_batch_prepare_filtered": (vp, [vp, u32, vp, vp, vp, vp, u32, i32]),
+        "slg_batch_prepare_plan": (vp, [vp, u32, vp, vp, vp, vp, vp, vp, vp, vp, u32, i32]),
         "slg_batch_run": (i32, [vp]),
         "slg_batch_set_stream": (i32, [vp, vp]),
         "slg_batch_sync": (i32, [vp]),

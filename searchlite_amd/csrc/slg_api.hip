@@ -154,6 +154,7 @@ struct slg_batch {
   int strategy = 0;
   uint32_t n_sq = 0, n_slices = 0, n_terms = 0, n_boundaries = 0, max_terms = 0;
   bool uniform = false;  // every sub-query fits the one-list-per-slot kernel
+  bool plan_batch = false;  // some sub-query has a score plan (multi kernel only)
   bool multi = false;    // many-term form of it (slg_score_multi.hpp); else the packed kernel
   uint64_t n_postings = 0, n_postings_essential = 0, n_rounds = 0;
   std::vector<uint64_t> q_postings;  // per query (stats.postings_advanced)
@@ -628,6 +629,15 @@ slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offse
 slg_batch *slg_batch_prepare_filtered(slg_index *ix, uint32_t nq, const uint32_t *q_offsets,
                                       const uint32_t *q_term_ids, const float *q_weights,
                                       const int32_t *q_filter, uint32_t k, int strategy) {
+  return slg_batch_prepare_plan(ix, nq, q_offsets, q_term_ids, q_weights, nullptr, nullptr, nullptr,
+                                nullptr, q_filter, k, strategy);
+}
+
+slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_offsets,
+                                  const uint32_t *q_term_ids, const float *q_weights,
+                                  const uint32_t *q_leaf, const int32_t *q_plan, const float *q_tie,
+                                  const uint32_t *q_nleaves, const int32_t *q_filter, uint32_t k,
+                                  int strategy) {
   slg_batch *b = nullptr;
   int rc = guarded([&] {
     SLG_REQUIRE(ix != nullptr, "index is NULL");
@@ -655,7 +665,7 @@ slg_batch *slg_batch_prepare_filtered(slg_index *ix, uint32_t nq, const uint32_t
     std::vector<slg::TermRef> terms;
     std::vector<uint64_t> sq_postings, sq_postings_all;
     std::vector<uint32_t> q_sq_begin(nq + 1, 0);
-    bool any_filter = false;
+    bool any_filter = false, any_plan = false;
     for (uint32_t q = 0; q < nq; q++) {
       q_sq_begin[q] = (uint32_t)sqs.size();
       SLG_REQUIRE(q_offsets[q + 1] >= q_offsets[q], "q_offsets not monotone");
@@ -670,6 +680,14 @@ slg_batch *slg_batch_prepare_filtered(slg_index *ix, uint32_t nq, const uint32_t
         fq = (uint32_t)q_filter[q] + 1u;
         any_filter = true;
       }
+      // score plan of the query (query/planner.rs:113-153)
+      const int plan_kind = q_plan ? q_plan[q] : SLG_PLAN_SUM;
+      SLG_REQUIRE(plan_kind == SLG_PLAN_SUM || plan_kind == SLG_PLAN_DISMAX,
+                  "unknown score plan in query " + std::to_string(q));
+      const float tie = q_tie ? q_tie[q] : 0.0f;
+      SLG_REQUIRE(std::isfinite(tie), "non-finite tie breaker in query " + std::to_string(q));
+      uint32_t n_leaves = q_nleaves ? q_nleaves[q] : 0;
+      for (uint32_t i = 0; i < nt; i++) n_leaves = std::max(n_leaves, (q_leaf ? q_leaf[t0 + i] : i) + 1u);
       if (k == 0) continue;  // wand.rs:413-416: k == 0 and no collector => no work
       for (uint32_t s = 0; s < n_segs; s++) {
         const SegHost &sh = *ix->segs[s];
@@ -694,11 +712,30 @@ slg_batch *slg_batch_prepare_filtered(slg_index *ix, uint32_t nq, const uint32_t
             longest_df = df;
             longest = local;
           }
-          terms.push_back(slg::TermRef{off, df, w, tid, 0u});
+          terms.push_back(slg::TermRef{off, df, w, tid, q_leaf ? q_leaf[t0 + i] : i});
           P += df;
         }
         sq.n_terms = (uint32_t)terms.size() - sq.term_begin;
         if (sq.n_terms == 0) continue;
+        {
+          // Lists go to the device sorted by leaf (stable: a leaf's terms keep the term order in
+          // which the reference adds them, wand.rs:488-497).  plan 0 = the flat term-order sum,
+          // which is what Sum gives when no leaf holds two terms.
+          auto first = terms.begin() + sq.term_begin;
+          std::stable_sort(first, terms.end(),
+                           [](const slg::TermRef &a, const slg::TermRef &c) { return a.leaf < c.leaf; });
+          bool shared = false;
+          uint32_t present = 0;
+          for (uint32_t i = 0; i < sq.n_terms; i++) {
+            const bool fresh = i == 0 || first[i].leaf != first[i - 1].leaf;
+            present += fresh ? 1u : 0u;
+            shared = shared || !fresh;
+          }
+          sq.plan = plan_kind == SLG_PLAN_DISMAX ? 2u : (shared ? 1u : 0u);
+          sq.tie = tie;
+          sq.max_init = present < n_leaves ? 0.0f : -INFINITY;
+          if (sq.plan) any_plan = true;
+        }
         // ---- MaxScore classification (opt-in with SLG_MAXSCORE=1 for strategies Wand / Bmw:
         // exact, but in round 1 not yet faster than exhaustive scoring — DESIGN.md section 4) ----
         // theta0 = max_t w_t * champ[t][k-1] is a lower bound of the final k-th score
@@ -706,7 +743,7 @@ slg_batch *slg_batch_prepare_filtered(slg_index *ix, uint32_t nq, const uint32_t
         // their maximum contribution ub_t = w_t * champ[t][0] are non-essential while the running
         // sum of ub stays below theta0: a doc found only in them totals < theta0.
         uint32_t ess_mask = sq.n_terms >= 32 ? 0xFFFFFFFFu : ((1u << sq.n_terms) - 1u);
-        if (strategy != SLG_STRATEGY_BM25 && !sh.champ.empty() && k >= 1 && k <= 1024u && fq == 0 &&
+        if (strategy != SLG_STRATEGY_BM25 && !sh.champ.empty() && k >= 1 && k <= 1024u && fq == 0 && sq.plan == 0 &&
             sq.n_terms > 1 && env_u32("SLG_MAXSCORE", 0) != 0) {
           bool ok = true;
           float theta0 = 0.0f;
@@ -767,13 +804,14 @@ slg_batch *slg_batch_prepare_filtered(slg_index *ix, uint32_t nq, const uint32_t
     uint64_t n_bounds = 0, n_bnd = 0;
     // one-list-per-slot kernel (slg_score_uni.hpp): few terms, no non-essential lists
     const uint32_t uni_max_terms = std::min<uint32_t>(env_u32("SLG_UNIFORM_MAX_TERMS", 4), slg::kUniSlots);
-    b->uniform = env_u32("SLG_NO_UNIFORM", 0) == 0 && b->max_terms <= uni_max_terms;
+    b->uniform = env_u32("SLG_NO_UNIFORM", 0) == 0 && b->max_terms <= uni_max_terms && !any_plan;
     for (size_t i = 0; i < sqs.size() && b->uniform; i++) {
       const uint32_t full = sqs[i].n_terms >= 32 ? 0xFFFFFFFFu : ((1u << sqs[i].n_terms) - 1u);
       if (sqs[i].ess_mask != full) b->uniform = false;
     }
     // more terms (the multi-field shape): the same slots-of-one-list design, 8 slots at a time
-    b->multi = !b->uniform && env_u32("SLG_NO_MULTI", 0) == 0 && env_u32("SLG_NO_UNIFORM", 0) == 0;
+    b->multi = !b->uniform && ((env_u32("SLG_NO_MULTI", 0) == 0 && env_u32("SLG_NO_UNIFORM", 0) == 0) || any_plan);
+    b->plan_batch = any_plan;
     for (size_t i = 0; i < sqs.size() && b->multi; i++) {
       const uint32_t full = sqs[i].n_terms >= 32 ? 0xFFFFFFFFu : ((1u << sqs[i].n_terms) - 1u);
       if (sqs[i].ess_mask != full) b->multi = false;
@@ -985,6 +1023,7 @@ int slg_batch_run(slg_batch *b) {
       sp.slice_order = b->d_slice_order;
       sp.reject_table = ix->d_reject_table.as<const uint32_t *>();
       sp.n_segs = (uint32_t)ix->segs.size();
+      sp.plan_batch = b->plan_batch ? 1u : 0u;
       sp.cand = b->d_cand.as<uint2>();
       sp.slice_cbeg = b->d_slice_cbeg.as<uint64_t>();
       sp.slice_ccnt = b->d_slice_ccnt.as<uint32_t>();

@@ -43,7 +43,7 @@ struct TermRef {  // one scored term of one sub-query
   uint32_t df;    // list length
   float weight;
   uint32_t term;  // term id inside the segment (champion table row)
-  uint32_t pad;
+  uint32_t leaf;  // ScorePlan leaf the term's scores add to (non-decreasing inside a sub-query)
 };
 
 struct RoundQuery {  // sub-query = (query, segment) pair with >= 1 non-empty term
@@ -59,6 +59,12 @@ struct RoundQuery {  // sub-query = (query, segment) pair with >= 1 non-empty te
   uint32_t ess_mask;      // bit t: list t is essential (MaxScore); the others are only probed
   uint32_t filter;        // 0: none; f + 1: docs must also pass filter f (reject table row f)
   uint32_t cand_lo, cand_hi;  // large-k mode: first candidate slot of this sub-query (u64)
+  // score plan (query/planner.rs:113-153): 0 = every term its own leaf, summed (the flat sum in
+  // term order); 1 = Sum of leaves that group several terms; 2 = DisMax of leaves
+  uint32_t plan;
+  float tie;       // DisMax tie breaker
+  float max_init;  // DisMax: 0.0 if some leaf of the plan has no term in this segment, else -inf
+  uint32_t pad2;
 };
 
 struct QueryRef {

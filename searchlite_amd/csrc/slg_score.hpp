@@ -152,6 +152,7 @@ struct RoundScoreParams {
   uint32_t *q_scored;   // [nq] or null
   const uint32_t *const *reject_table;  // [n_filters * n_segs] reject bitmaps (doc filters)
   uint32_t n_segs;
+  uint32_t plan_batch;  // multi kernel: some sub-query has a score plan (extra LDS is allocated)
   // large-k mode of the uniform kernel (k > 256): candidates instead of per-slice top-k lists
   uint2 *cand;            // {ordered score, doc}; sub-query region + posting offset of the slice
   uint64_t *slice_cbeg;   // [n_slices] first candidate slot of the slice

@@ -35,7 +35,7 @@ void launch_score_kregs<SLG_INST_KREGS>(const RoundScoreParams &sp, uint32_t max
                                         int kind, hipStream_t st) {
   if (kind == 2) {  // many lists: slots of one list each, 8 at a time (slg_score_multi.hpp)
     hipLaunchKernelGGL((score_multi_kernel<SLG_INST_KREGS>), dim3(sp.n_slices), dim3(64),
-                       (size_t)multi_wave_lds(SLG_INST_KREGS), st, sp);
+                       (size_t)multi_wave_lds(SLG_INST_KREGS) + (sp.plan_batch ? kMultiPlanLds : 0), st, sp);
     return;
   }
   if (kind == 1) {  // one list per register slot (slg_score_uni.hpp); waves are independent, so

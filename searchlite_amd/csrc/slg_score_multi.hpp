@@ -16,6 +16,14 @@
 // No posting "owns" a doc, so P1 needs no returning atomics and P4 no per-posting reads.
 // A round whose postings exceed the 512 accumulators, or whose docs span more than the 16 384
 // doc window, is cut at a common doc id and finished in further chunks.
+//
+// Score plans (query/planner.rs:113-153): when several terms share a ScorePlan leaf
+// (multi-field query strings) or the root is a DisMax, the lists arrive sorted by leaf; vals[]
+// then holds the CURRENT leaf's partial sums, and at every leaf change all accumulators are
+// closed in bulk: Sum: acc += leaf (acc starts at -0.0, the f32 Sum identity); DisMax:
+// max = max(max, leaf), sum += leaf (every leaf counts, absent ones as 0.0), final
+// max + tie * (sum - max).  Adding an untouched leaf's +0.0 is exact, so the bulk close gives
+// bit for bit what the reference computes per doc.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -32,6 +40,7 @@ constexpr int multi_wave_lds(int kregs) {
   return kSpanWords * 4 + kSpanWords * 4 + (kMultiCap + 64) * 4 + kMultiCap * 4 +
          (uni_buffered(kregs) ? 128 * kregs * 8 : 0);
 }
+constexpr int kMultiPlanLds = 2 * kMultiCap * 4;  // acc[] and max[] of the leaf close
 
 template <int KREGS>
 __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) {
@@ -68,14 +77,21 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
   // lane t < T: list t's posting offset, weight, term id
   uint64_t my_off = 0;
   float my_w = 0.0f;
-  uint32_t my_term = 0;
+  uint32_t my_term = 0, my_leaf = 0;
   if (lane < T) {
     const TermRef tr = p.terms[s.term_begin + lane];
     my_off = tr.off;
     my_w = tr.weight;
     my_term = tr.term;
+    my_leaf = tr.leaf;
   }
   const uint32_t my_off_lo = (uint32_t)my_off, my_off_hi = (uint32_t)(my_off >> 32);
+  // score plan: 0 flat sum, 1 Sum of multi-term leaves, 2 DisMax of leaves
+  const uint32_t plan = p.plan_batch ? rfl(s.plan) : 0u;
+  const float tie = __uint_as_float(rfl(__float_as_uint(s.tie)));
+  const uint32_t max_init = rfl(__float_as_uint(s.max_init));
+  float *acc = reinterpret_cast<float *>(smem + multi_wave_lds(KREGS));  // only if plan_batch
+  float *mxv = acc + kMultiCap;
   const gu32_t gbounds = (gu32_t)p.bounds + s.bounds_begin + (size_t)r0 * T;
   const gu32_t grdoc = (gu32_t)p.rdoc + s.rdoc_begin + r0;
 
@@ -189,6 +205,14 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
       bm4[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
       vals4[lane] = make_uint4(0u, 0u, 0u, 0u);
       vals4[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
+      if (plan) {
+        const uint32_t a0 = plan == 2u ? 0u : 0x80000000u;  // DisMax sum starts at 0.0, Sum at -0.0
+        uint4 *acc4 = reinterpret_cast<uint4 *>(acc), *mx4 = reinterpret_cast<uint4 *>(mxv);
+        acc4[lane] = make_uint4(a0, a0, a0, a0);
+        acc4[lane + 64] = make_uint4(a0, a0, a0, a0);
+        mx4[lane] = make_uint4(max_init, max_init, max_init, max_init);
+        mx4[lane + 64] = make_uint4(max_init, max_init, max_init, max_init);
+      }
       wave_fence();
       // ---- sweep A: one bit per posting; what every list consumes (docs below the cut) ----
       uint32_t consumed = 0;
@@ -221,6 +245,23 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
         n_scored += ndocs;
       }
       wave_fence();
+      // leaf close (score plans): fold the current leaf's partial sums into the per-doc totals
+      auto close_leaf = [&](const bool final) {
+        for (uint32_t r = lane; r < ndocs; r += 64) {
+          const float c = __uint_as_float(vals[r]);
+          const float a = acc[r] + c;
+          const float m = fmaxf(mxv[r], c);
+          if (final) {
+            vals[r] = __float_as_uint(plan == 2u ? m + tie * (a - m) : a);
+          } else {
+            acc[r] = a;
+            mxv[r] = m;
+            vals[r] = 0u;
+          }
+        }
+        wave_fence();
+      };
+      uint32_t cur_leaf = 0xFFFFFFFFu;
       // ---- sweep C: rank every posting, accumulate slot by slot (= in list order) ----
       for (uint32_t b = 0; b < nb; b++) {
         take_batch(b, dhi);
@@ -244,8 +285,16 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
 #pragma unroll
         for (int jj = 0; jj < NS; jj++) {
           if (__ballot(in[jj]) == 0ull) continue;  // unused slot
+          const uint32_t lst = rl(d_st, b * 8u + jj);
+          if (plan) {
+            const uint32_t lf = rl(my_leaf, lst);
+            if (lf != cur_leaf) {
+              if (cur_leaf != 0xFFFFFFFFu) close_leaf(false);
+              cur_leaf = lf;
+            }
+          }
           // score_tf: impact * weight (query/wand.rs:285); the slot's list weight is a scalar
-          const float w = __int_as_float((int)rl((uint32_t)__float_as_int(my_w), rl(d_st, b * 8u + jj)));
+          const float w = __int_as_float((int)rl((uint32_t)__float_as_int(my_w), lst));
           const uint32_t at = in[jj] ? rank[jj] : (uint32_t)kMultiCap + lane;
           const uint32_t old = vals[at];
           vals[at] = __float_as_uint(__uint_as_float(old) + imp[jj] * w);
@@ -254,6 +303,7 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
         }
       }
       wave_fence();
+      if (plan) close_leaf(true);
       // ---- P4: the docs of the chunk in rank order -> top-k ----
       for (uint32_t base = 0; base < ndocs; base += 64) {
         const uint32_t r = base + lane;

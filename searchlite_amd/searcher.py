@@ -129,8 +129,21 @@ class GpuIndex:
 
     # -- search ----------------------------------------------------------------------
     def prepare(self, q_offsets, q_terms, q_weights, k: int, strategy: int = Wand,
-                q_filter=None) -> "PreparedBatch":
-        return PreparedBatch(self, q_offsets, q_terms, q_weights, k, strategy, q_filter)
+                q_filter=None, q_leaf=None, q_plan=None, q_tie=None, q_nleaves=None) -> "PreparedBatch":
+        """q_leaf / q_plan / q_tie / q_nleaves: score plans (slg_batch_prepare_plan)."""
+        return PreparedBatch(self, q_offsets, q_terms, q_weights, k, strategy, q_filter,
+                             q_leaf, q_plan, q_tie, q_nleaves)
+
+    def search_plan(self, q_offsets, q_terms, q_weights, k: int, q_leaf=None, q_plan=None,
+                    q_tie=None, q_nleaves=None, strategy: int = Wand, q_filter=None):
+        """Batch search with score plans (multi-field leaves / DisMax) -> (doc, seg, score, count)."""
+        b = self.prepare(q_offsets, q_terms, q_weights, k, strategy, q_filter, q_leaf, q_plan,
+                         q_tie, q_nleaves)
+        try:
+            b.run()
+            return b.fetch()
+        finally:
+            b.close()
 
     def search_batch(self, q_offsets, q_terms, q_weights, k: int, strategy: int = Wand,
                      want_stats: bool = False, q_filter=None):
@@ -226,7 +239,7 @@ class PreparedBatch:
     """A planned query batch with device-resident descriptors and work buffers."""
 
     def __init__(self, index: GpuIndex, q_offsets, q_terms, q_weights, k: int, strategy: int,
-                 q_filter=None):
+                 q_filter=None, q_leaf=None, q_plan=None, q_tie=None, q_nleaves=None):
         self.index = index
         self._lib = index._lib
         q_offsets = np.ascontiguousarray(q_offsets, dtype=np.uint32)
@@ -236,9 +249,16 @@ class PreparedBatch:
         self.k = k
         qf = None if q_filter is None else np.ascontiguousarray(q_filter, dtype=np.int32)
         assert qf is None or len(qf) == self.nq
-        self._h = self._lib.slg_batch_prepare_filtered(
-            index._h, self.nq, _ptr(q_offsets), _ptr(q_terms), _ptr(q_weights),
-            None if qf is None else _ptr(qf), k, strategy)
+        ql = None if q_leaf is None else np.ascontiguousarray(q_leaf, dtype=np.uint32)
+        qp = None if q_plan is None else np.ascontiguousarray(q_plan, dtype=np.int32)
+        qt = None if q_tie is None else np.ascontiguousarray(q_tie, dtype=np.float32)
+        qn = None if q_nleaves is None else np.ascontiguousarray(q_nleaves, dtype=np.uint32)
+        assert ql is None or len(ql) == len(q_weights)
+        assert all(x is None or len(x) == self.nq for x in (qp, qt, qn))
+        opt = lambda a: None if a is None else _ptr(a)
+        self._h = self._lib.slg_batch_prepare_plan(
+            index._h, self.nq, _ptr(q_offsets), _ptr(q_terms), _ptr(q_weights), opt(ql), opt(qp),
+            opt(qt), opt(qn), opt(qf), k, strategy)
         if not self._h:
             msg = N.last_error()
             code = N.ERR_UNSUPPORTED if ("SLG_MAX" in msg or "more than" in msg) else N.ERR_INVALID

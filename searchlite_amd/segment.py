@@ -215,3 +215,50 @@ def resolve_query(segments: Sequence[Segment], folded: Sequence[Tuple[str, float
             ids[i, s] = seg.term_id(key)
     w = np.array([x[1] for x in folded], dtype=np.float32)
     return ids, w
+
+
+# ---- score plans: how the reference's planner maps scored terms to leaves -----------
+PLAN_SUM, PLAN_DISMAX = 0, 1
+
+
+def plan_query_string(words: Sequence[str], fields: Sequence[Tuple[str, float]]):
+    """Multi-field query string / multi_match most_fields-per-word shape (query/planner.rs:
+    300-360): every word is one leaf, all its `field:word` terms add into it, the leaves are
+    summed.  fields = [(field, boost)].  -> (keys_with_weight_and_leaf, plan, n_leaves)"""
+    out = []
+    for li, wd in enumerate(words):
+        for f, boost in fields:
+            out.append((f"{f}:{wd}", float(boost), li))
+    return out, PLAN_SUM, len(words)
+
+
+def plan_best_fields(words: Sequence[str], fields: Sequence[Tuple[str, float]]):
+    """multi_match best_fields (query/planner.rs:376-396): one leaf per FIELD (all words of the
+    query add into their field's leaf), DisMax over the leaves."""
+    out = []
+    for wd in words:
+        for li, (f, boost) in enumerate(fields):
+            out.append((f"{f}:{wd}", float(boost), li))
+    return out, PLAN_DISMAX, len(fields)
+
+
+def plan_most_fields(words: Sequence[str], fields: Sequence[Tuple[str, float]]):
+    """multi_match most_fields / cross_fields scoring (query/planner.rs:397-409): ONE leaf."""
+    out = [(f"{f}:{wd}", float(boost), 0) for wd in words for f, boost in fields]
+    return out, PLAN_SUM, 1
+
+
+def plan_dis_max_terms(terms: Sequence[Tuple[str, str, float]]):
+    """dis_max over term children (query/planner.rs:445-470): one leaf per child."""
+    out = [(f"{f}:{v}", float(boost), i) for i, (f, v, boost) in enumerate(terms)]
+    return out, PLAN_DISMAX, len(terms)
+
+
+def resolve_plan(segments: Sequence[Segment], planned):
+    """planned = [(key, weight, leaf)] -> (term_ids[n, n_segs], weights[n], leaves[n])."""
+    ids = np.full((len(planned), len(segments)), NO_TERM, dtype=np.uint32)
+    for i, (key, _, _) in enumerate(planned):
+        for s, seg in enumerate(segments):
+            ids[i, s] = seg.term_id(key)
+    return ids, np.array([x[1] for x in planned], dtype=np.float32), \
+        np.array([x[2] for x in planned], dtype=np.uint32)

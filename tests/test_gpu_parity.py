@@ -219,6 +219,58 @@ def test_doc_filters_match_accept_semantics(gpu, oracle, k, T):
             ix.search_batch(offs, terms, w, k, q_filter=np.full(30, 99, dtype=np.int32))
 
 
+@pytest.mark.parametrize("k", [11, 300])
+def test_score_plans_multi_field_and_dismax(gpu, oracle, k):
+    """SURVEY N4 (query/planner.rs:113-153): multi-field query strings (one leaf per word, its
+    fields add into it, leaves summed), best_fields (one leaf per field, DisMax + tie breaker),
+    most_fields (one leaf), mixed with plain disjunctions in one batch, two segments, tombstones,
+    a doc filter.  Bit-exact against the oracle's exhaustive scorer."""
+    from tests.util import random_multifield_segment
+    rng = np.random.default_rng(800 + k)
+    vocab, F = 14, 4
+    segs = [random_multifield_segment(rng, 2500 + 700 * i, vocab, F, 12) for i in range(2)]
+    segs[1].set_deleted(list(range(5, segs[1].n_docs, 11)))
+    offs, terms, w, leaf, plan, tie, nl = [0], [], [], [], [], [], []
+    for q in range(24):
+        words = rng.choice(vocab, size=int(rng.integers(1, 4)), replace=False)
+        kind = q % 4
+        for wi, wd in enumerate(words):
+            for f in range(F):
+                if kind == 3 and f > 0:
+                    continue                     # plain single-field disjunction
+                terms.append([f * vocab + int(wd)] * 2)
+                w.append(np.float32(1.0 + 0.5 * f))
+                leaf.append({0: wi, 1: f, 2: 0, 3: wi}[kind])
+        offs.append(len(terms))
+        plan.append(gpu.PLAN_DISMAX if kind == 1 else gpu.PLAN_SUM)
+        tie.append(0.35 if kind == 1 else 0.0)
+        nl.append({0: len(words), 1: F + 1, 2: 1, 3: len(words)}[kind])  # best_fields: one leaf without terms
+    offs = np.array(offs, dtype=np.uint32)
+    terms = np.array(terms, dtype=np.uint32)
+    w = np.array(w, dtype=np.float32)
+    kw = dict(q_leaf=np.array(leaf, dtype=np.uint32), q_plan=np.array(plan, dtype=np.int32),
+              q_tie=np.array(tie, dtype=np.float32), q_nleaves=np.array(nl, dtype=np.uint32))
+    want = oracle.search_batch(segs, offs, terms, w, k, strategy=oracle.BM25, **kw)
+    flat = oracle.search_batch(segs, offs, terms, w, k, strategy=oracle.BM25)
+    assert not np.array_equal(want[2].view(np.uint32), flat[2].view(np.uint32))  # the plans matter
+    with gpu.GpuIndex(segs) as ix:
+        for strat in (gpu.Bm25, gpu.Wand):
+            assert_same_hits(ix.search_plan(offs, terms, w, k, strategy=strat, **kw), want, 0.0, f"plans k={k}")
+        # the same with a doc filter on every other query
+        masks = [rng.random(sg.n_docs) < 0.5 for sg in segs]
+        fid = ix.add_filter(masks)
+        qf = np.array([fid if q % 2 else -1 for q in range(24)], dtype=np.int32)
+        got = ix.search_plan(offs, terms, w, k, q_filter=qf, **kw)
+    for q in range(24):  # oracle per query (filter folded into the tombstones)
+        sl = slice(int(offs[q]), int(offs[q + 1]))
+        one = oracle.search_batch_filtered(
+            segs, np.array([0, sl.stop - sl.start], dtype=np.uint32), terms[sl], w[sl], k,
+            np.array([0 if q % 2 else -1], dtype=np.int32), [masks], strategy=oracle.BM25,
+            q_leaf=kw["q_leaf"][sl], q_plan=kw["q_plan"][q:q + 1], q_tie=kw["q_tie"][q:q + 1],
+            q_nleaves=kw["q_nleaves"][q:q + 1])
+        assert_same_hits(tuple(x[q:q + 1] for x in got), one, 0.0, f"plans + filter q={q}")
+
+
 def test_ragged_and_empty_inputs(gpu, oracle):
     rng = np.random.default_rng(3)
     seg = random_segment(rng, 300, 12, 10)

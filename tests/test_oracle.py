@@ -326,3 +326,94 @@ def test_filtered_search_is_the_scorer_with_the_filter_folded_into_accept(oracle
         assert m == len(want_docs)
         assert np.array_equal(got[0][q, :m], want_docs)
         assert np.array_equal(got[2][q, :m].view(np.uint32), want_scores.view(np.uint32))
+
+
+# ---- score plans: the reference's tests/multi_field.rs on its own 5-doc corpus --------
+def _multi_field_corpus():
+    import searchlite_amd as sa
+    b = sa.SegmentBuilder(["body", "title"], k1=0.9, b=0.4)   # tests/multi_field.rs:23-58
+    for i, (title, body) in enumerate([("rust search", "fast"), ("rust", "search"), ("rust", "rust search"),
+                                       ("boring", "rust"), ("none", "rust fast search")]):
+        b.add_document(f"doc-{i + 1}", {"title": title, "body": body})
+    return b.build()
+
+
+def _run_plan(oracle, seg, planned, plan, n_leaves, tie=0.0, strategy=None, k=11):
+    import searchlite_amd as sa
+    ids, w, leaf = sa.resolve_plan([seg], planned)
+    offs = np.array([0, len(planned)], dtype=np.uint32)
+    d, sg, sc, c = oracle.search_batch([seg], offs, ids, w, k,
+                                       strategy=oracle.WAND if strategy is None else strategy,
+                                       q_leaf=leaf, q_plan=[plan], q_tie=[tie], q_nleaves=[n_leaves])
+    return {seg.ext_ids[int(d[0, i])]: float(sc[0, i]) for i in range(int(c[0]))}, \
+        [seg.ext_ids[int(d[0, i])] for i in range(int(c[0]))]
+
+
+def test_reference_multi_field_properties(oracle):
+    import searchlite_amd as sa
+    seg = _multi_field_corpus()
+    fields = [("title", 1.0), ("body", 1.0)]
+    # multi_match_most_fields_counts_across_fields (tests/multi_field.rs:104-167)
+    best, _ = _run_plan(oracle, seg, *sa.plan_best_fields(["rust", "search"], fields))
+    most, _ = _run_plan(oracle, seg, *sa.plan_most_fields(["rust", "search"], fields))
+    body_only, _ = _run_plan(oracle, seg, *sa.plan_best_fields(["rust", "search"], [("body", 1.0)]))
+    assert "doc-3" in body_only and "doc-2" in best and "doc-2" in most
+    assert most["doc-2"] > best["doc-2"]
+    # dis_max_tie_breaker_prefers_multi_field_hit (:169-195)
+    _, order = _run_plan(oracle, seg, *sa.plan_dis_max_terms([("title", "rust", 1.0), ("body", "rust", 1.0)]),
+                         tie=0.5)
+    assert order[0] == "doc-3"
+    # field_boost_reshapes_best_field_ranking (:197-223)
+    boosted, _ = _run_plan(oracle, seg, *sa.plan_best_fields(["rust"], [("title", 2.0), ("body", 1.0)]))
+    assert "doc-2" in boosted and "doc-4" in boosted and boosted["doc-2"] > boosted["doc-4"]
+    # every strategy gives the same hits (tests/pruning.rs standard), scores within 1e-5
+    for plan in (sa.plan_best_fields(["rust", "search"], fields), sa.plan_query_string(["rust", "search"], fields)):
+        a, oa = _run_plan(oracle, seg, *plan, tie=0.3, strategy=oracle.BM25)
+        for st in (oracle.WAND, oracle.BMW):
+            b_, ob = _run_plan(oracle, seg, *plan, tie=0.3, strategy=st)
+            assert oa == ob and all(abs(a[x] - b_[x]) < 1e-5 for x in a)
+
+
+def test_score_plan_arithmetic_against_numpy(oracle):
+    """Sum of multi-term leaves and DisMax, recomputed per doc in numpy f32 in the reference's
+    operation order (planner.rs:122-152: leaves 0.0 + terms in order; Sum from -0.0; DisMax max
+    from -inf, sum from 0.0, max + tie * (sum - max))."""
+    from tests.util import random_multifield_segment
+    rng = np.random.default_rng(17)
+    vocab, F = 10, 3
+    seg = random_multifield_segment(rng, 250, vocab, F, 9)
+    words = [0, 2, 5]
+    terms = np.array([[f * vocab + w_] for w_ in words for f in range(F)], dtype=np.uint32)
+    w = (rng.random(len(terms)).astype(np.float32) + np.float32(0.5))
+    offs = np.array([0, len(terms)], dtype=np.uint32)
+    for plan, leaf, tie, nl in ((oracle.PLAN_SUM, [i for i in range(3) for _ in range(F)], 0.0, 3),
+                                (oracle.PLAN_DISMAX, [f for _ in range(3) for f in range(F)], 0.25, 4)):
+        got = oracle.search_batch([seg], offs, terms, w, 250, strategy=oracle.BM25, q_leaf=leaf,
+                                  q_plan=[plan], q_tie=[tie], q_nleaves=[nl])
+        leaves = np.zeros((250, nl), dtype=np.float32)
+        seen = np.zeros(250, dtype=bool)
+        for i, t in enumerate(terms[:, 0]):
+            a, b_ = int(seg.term_offsets[t]), int(seg.term_offsets[t + 1])
+            f = int(seg.term_field[t])
+            for d, tf in zip(seg.doc_ids[a:b_], seg.tfs[a:b_]):
+                x = oracle.score_tf(float(tf), float(b_ - a), float(seg.field_doc_len[f][d]),
+                                    float(seg.field_avgdl[f]), seg.docs, seg.k1, seg.b, float(w[i]))
+                leaves[d, leaf[i]] = np.float32(leaves[d, leaf[i]] + np.float32(x))
+                seen[d] = True
+        want = {}
+        for d in np.nonzero(seen)[0]:
+            if plan == oracle.PLAN_SUM:
+                s_ = np.float32(-0.0)
+                for j in range(nl):
+                    s_ = np.float32(s_ + leaves[d, j])
+            else:
+                mx, sm = np.float32(-np.inf), np.float32(0.0)
+                for j in range(nl):
+                    mx = np.float32(max(mx, leaves[d, j]))
+                    sm = np.float32(sm + leaves[d, j])
+                s_ = np.float32(mx + np.float32(np.float32(tie) * np.float32(sm - mx)))
+            want[int(d)] = s_
+        n = int(got[3][0])
+        assert n == len(want)
+        for i in range(n):
+            assert np.float32(got[2][0, i]).view(np.uint32) == np.float32(want[int(got[0][0, i])]).view(np.uint32)

@@ -37,6 +37,41 @@ def random_segment(rng, n_docs, vocab, avg_len, k1=1.2, b=0.75, missing_len_frac
                    field_avgdl=np.array([avg], dtype=np.float32), docs=float(n_docs), k1=k1, b=b)
 
 
+def random_multifield_segment(rng, n_docs, vocab, n_fields, avg_len, k1=0.9, b=0.4):
+    """Random segment with n_fields text fields over the same vocabulary: term id = f*vocab + w
+    (the `field:word` keys of index/postings.rs), per-field doc lengths / avgdl; some docs lack a
+    field (length 0)."""
+    from searchlite_amd.segment import Segment
+    p = 1.0 / np.arange(1, vocab + 1)
+    p /= p.sum()
+    V = vocab * n_fields
+    post = [[] for _ in range(V)]
+    lens = np.zeros((n_fields, n_docs), dtype=np.float32)
+    for f in range(n_fields):
+        fl = max(1, avg_len // (f + 1))
+        for d in range(n_docs):
+            if rng.random() < 0.1:
+                continue  # field missing in this doc
+            n = int(rng.integers(max(1, fl // 2), fl * 2 + 1))
+            toks = rng.choice(vocab, size=n, p=p)
+            t, c = np.unique(toks, return_counts=True)
+            for ti, ci in zip(t, c):
+                post[f * vocab + int(ti)].append((d, int(ci)))
+            lens[f, d] = n
+    offs = np.zeros(V + 1, dtype=np.uint64)
+    docs, tfs = [], []
+    for t in range(V):
+        for d, c in post[t]:
+            docs.append(d)
+            tfs.append(c)
+        offs[t + 1] = len(docs)
+    avg = np.array([np.float32(lens[f].sum()) / np.float32(n_docs) for f in range(n_fields)], dtype=np.float32)
+    tfield = np.repeat(np.arange(n_fields, dtype=np.uint16), vocab)
+    return Segment(n_docs=n_docs, term_offsets=offs, doc_ids=np.array(docs, dtype=np.uint32),
+                   tfs=np.array(tfs, dtype=np.uint32), field_doc_len=[lens[f] for f in range(n_fields)],
+                   field_avgdl=avg, docs=float(n_docs), k1=k1, b=b, term_field=tfield)
+
+
 def random_queries(rng, nq, n_terms, vocab, n_segs=1, lo=0, weights=False):
     offs = (np.arange(nq + 1) * n_terms).astype(np.uint32)
     terms = np.empty((nq * n_terms, n_segs), dtype=np.uint32)
