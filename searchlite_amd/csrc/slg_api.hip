@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <map>
 #include <mutex>
 #include <new>
 #include <stdexcept>
@@ -77,35 +78,82 @@ uint32_t env_u32(const char *name, uint32_t dflt) {
   return (uint32_t)std::strtoul(v, nullptr, 10);
 }
 
+// Freed batch buffers are kept for the next batch: hipMalloc / hipFree cost ~100 us each and
+// hipFree synchronizes the device, which would serialize host threads that serve batches
+// concurrently.  Size classes are powers of two (>= 4 KiB).
+struct BufPool {
+  std::mutex mu;
+  std::multimap<size_t, void *> free_;
+  size_t pooled = 0;
+  static constexpr size_t kMaxPooled = 4ull << 30;
+  static size_t size_class(size_t n) {
+    size_t c = 4096;
+    while (c < n) c <<= 1;
+    return c;
+  }
+  void *get(size_t cls) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = free_.find(cls);
+    if (it == free_.end()) return nullptr;
+    void *p = it->second;
+    free_.erase(it);
+    pooled -= cls;
+    return p;
+  }
+  bool put(void *p, size_t cls) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (pooled + cls > kMaxPooled) return false;
+    free_.emplace(cls, p);
+    pooled += cls;
+    return true;
+  }
+  ~BufPool() {
+    for (auto &kv : free_) (void)hipFree(kv.second);
+  }
+};
+
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
+  BufPool *pool = nullptr;  // set: bytes is a size class and the block goes back to the pool
   void alloc(size_t n) {
     release();
     if (n == 0) n = 16;
     SLG_HIP(hipMalloc(&p, n));
     bytes = n;
   }
+  void alloc_pooled(BufPool *pl, size_t n) {
+    release();
+    const size_t cls = BufPool::size_class(n ? n : 16);
+    p = pl->get(cls);
+    if (!p) SLG_HIP(hipMalloc(&p, cls));
+    bytes = cls;
+    pool = pl;
+  }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && !(pool && pool->put(p, bytes))) (void)hipFree(p);
     p = nullptr;
     bytes = 0;
+    pool = nullptr;
   }
   ~DevBuf() { release(); }
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
-  DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) {
+  DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes), pool(o.pool) {
     o.p = nullptr;
     o.bytes = 0;
+    o.pool = nullptr;
   }
   DevBuf &operator=(DevBuf &&o) noexcept {
     if (this != &o) {
       release();
       p = o.p;
       bytes = o.bytes;
+      pool = o.pool;
       o.p = nullptr;
       o.bytes = 0;
+      o.pool = nullptr;
     }
     return *this;
   }
@@ -130,6 +178,7 @@ struct SegHost {
 }  // namespace
 
 struct slg_index {
+  BufPool pool;  // work buffers of finished batches (declared first: destroyed last)
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
@@ -650,7 +699,15 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     const uint32_t n_segs = (uint32_t)ix->segs.size();
     const uint32_t total_terms = nq ? q_offsets[nq] : 0;
     SLG_REQUIRE(total_terms == 0 || (q_term_ids && q_weights), "q_term_ids/q_weights is NULL");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    // Planning reads only immutable index data (segments are fixed at create), so host threads
+    // may prepare batches for one index concurrently; the index mutex is held just to look at
+    // the filter table.
+    std::vector<char> filter_live;
+    {
+      std::lock_guard<std::mutex> lk(ix->mu);
+      filter_live.resize(ix->filters.size());
+      for (size_t f = 0; f < ix->filters.size(); f++) filter_live[f] = !ix->filters[f].empty();
+    }
     DeviceGuard g(ix->device);
 
     b = new slg_batch();
@@ -675,7 +732,7 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
                                                 std::to_string(SLG_MAX_QUERY_TERMS) + " terms");
       uint32_t fq = 0;  // doc filter of the query (0 none, id + 1)
       if (q_filter && q_filter[q] >= 0) {
-        SLG_REQUIRE((size_t)q_filter[q] < ix->filters.size() && !ix->filters[q_filter[q]].empty(),
+        SLG_REQUIRE((size_t)q_filter[q] < filter_live.size() && filter_live[q_filter[q]],
                     "unknown filter id in query " + std::to_string(q));
         fq = (uint32_t)q_filter[q] + 1u;
         any_filter = true;
@@ -931,12 +988,10 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     const size_t o_sord = place<uint32_t>(cur, slice_order.size());
     const size_t o_q = place<slg::QueryRef>(cur, qrefs.size());
     const size_t total = (cur + 15) & ~(size_t)15;
-    void *hbuf = nullptr;
-    SLG_HIP(hipHostMalloc(&hbuf, total ? total : 16, hipHostMallocDefault));
-    struct HostFree {
-      void *p;
-      ~HostFree() { (void)hipHostFree(p); }
-    } hf{hbuf};
+    // (a blocking hipMemcpy from pageable memory: no shared stream involved, and cheaper than
+    // allocating a pinned staging buffer per batch)
+    std::vector<unsigned char> hvec(total ? total : 16);
+    void *hbuf = hvec.data();
     unsigned char *hb = static_cast<unsigned char *>(hbuf);
     if (!sqs.empty()) std::memcpy(hb + o_sq, sqs.data(), sqs.size() * sizeof(slg::RoundQuery));
     if (!terms.empty()) std::memcpy(hb + o_terms, terms.data(), terms.size() * sizeof(slg::TermRef));
@@ -945,8 +1000,8 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     if (!slice_seg.empty()) std::memcpy(hb + o_sseg, slice_seg.data(), slice_seg.size() * 4);
     if (!slice_order.empty()) std::memcpy(hb + o_sord, slice_order.data(), slice_order.size() * 4);
     if (!qrefs.empty()) std::memcpy(hb + o_q, qrefs.data(), qrefs.size() * sizeof(slg::QueryRef));
-    b->d_desc.alloc(total);
-    SLG_HIP(hipMemcpyAsync(b->d_desc.p, hbuf, total, hipMemcpyHostToDevice, ix->stream));
+    b->d_desc.alloc_pooled(&ix->pool, total);
+    SLG_HIP(hipMemcpy(b->d_desc.p, hbuf, total, hipMemcpyHostToDevice));
     unsigned char *db = b->d_desc.as<unsigned char>();
     b->d_sq = reinterpret_cast<const slg::RoundQuery *>(db + o_sq);
     b->d_terms = reinterpret_cast<const slg::TermRef *>(db + o_terms);
@@ -956,31 +1011,29 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     b->d_slice_order = reinterpret_cast<const uint32_t *>(db + o_sord);
     b->d_queries = reinterpret_cast<const slg::QueryRef *>(db + o_q);
 
-    b->d_bounds.alloc((size_t)n_bounds * 4);
-    b->d_rdoc.alloc((size_t)n_bnd * 4);
+    b->d_bounds.alloc_pooled(&ix->pool, (size_t)n_bounds * 4);
+    b->d_rdoc.alloc_pooled(&ix->pool, (size_t)n_bnd * 4);
     if (b->cand_mode) {
-      b->d_cand.alloc((size_t)(cand_total + 1) * 8);
-      b->d_slice_cbeg.alloc((size_t)b->n_slices * 8);
-      b->d_slice_ccnt.alloc((size_t)b->n_slices * 4);
+      b->d_cand.alloc_pooled(&ix->pool, (size_t)(cand_total + 1) * 8);
+      b->d_slice_cbeg.alloc_pooled(&ix->pool, (size_t)b->n_slices * 8);
+      b->d_slice_ccnt.alloc_pooled(&ix->pool, (size_t)b->n_slices * 4);
     } else {
-      b->d_slice_tk.alloc((size_t)b->n_slices * k * 4);
-      b->d_slice_doc.alloc((size_t)b->n_slices * k * 4);
+      b->d_slice_tk.alloc_pooled(&ix->pool, (size_t)b->n_slices * k * 4);
+      b->d_slice_doc.alloc_pooled(&ix->pool, (size_t)b->n_slices * k * 4);
     }
-    b->d_q_scored.alloc((size_t)nq * 4);
+    b->d_q_scored.alloc_pooled(&ix->pool, (size_t)nq * 4);
     if (any_filter) {
       std::vector<uint32_t> qf(nq, 0u);
       for (uint32_t q = 0; q < nq; q++)
         if (q_filter[q] >= 0) qf[q] = (uint32_t)q_filter[q] + 1u;
-      b->d_q_filter.alloc((size_t)nq * 4);
-      SLG_HIP(hipMemcpyAsync(b->d_q_filter.p, qf.data(), (size_t)nq * 4, hipMemcpyHostToDevice, ix->stream));
-      SLG_HIP(hipStreamSynchronize(ix->stream));
+      b->d_q_filter.alloc_pooled(&ix->pool, (size_t)nq * 4);
+      SLG_HIP(hipMemcpy(b->d_q_filter.p, qf.data(), (size_t)nq * 4, hipMemcpyHostToDevice));
     }
-    b->d_out.alloc(((size_t)nq * k * 3 + nq) * 4);
+    b->d_out.alloc_pooled(&ix->pool, ((size_t)nq * k * 3 + nq) * 4);
     b->d_out_doc = b->d_out.as<uint32_t>();
     b->d_out_seg = b->d_out_doc + (size_t)nq * k;
     b->d_out_score = reinterpret_cast<float *>(b->d_out_seg + (size_t)nq * k);
     b->d_out_count = b->d_out_seg + (size_t)nq * k * 2;
-    SLG_HIP(hipStreamSynchronize(ix->stream));  // pinned staging buffer is freed on return
   });
   if (rc != SLG_OK) {
     std::string keep = g_last_error;
@@ -1108,25 +1161,31 @@ int slg_batch_fetch(slg_batch *b, uint32_t *out_doc, uint32_t *out_seg, float *o
     SLG_REQUIRE(b->nq == 0 || (out_count != nullptr), "out_count is NULL");
     SLG_REQUIRE(b->nq == 0 || b->k == 0 || (out_doc && out_seg && out_score), "output array is NULL");
     slg_index *ix = b->idx;
-    std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
-    hipStream_t st = batch_stream(b);
-    const size_t n = (size_t)b->nq * b->k;
-    if (n) {
-      SLG_HIP(hipMemcpyAsync(out_doc, b->d_out_doc, n * 4, hipMemcpyDeviceToHost, st));
-      SLG_HIP(hipMemcpyAsync(out_seg, b->d_out_seg, n * 4, hipMemcpyDeviceToHost, st));
-      SLG_HIP(hipMemcpyAsync(out_score, b->d_out_score, n * 4, hipMemcpyDeviceToHost, st));
+    hipStream_t st;
+    {  // (not held while waiting: other host threads keep launching their batches)
+      std::lock_guard<std::mutex> lk(ix->mu);
+      st = batch_stream(b);
     }
+    const size_t n = (size_t)b->nq * b->k;
     std::vector<uint32_t> scored;
     if (b->nq) {
-      SLG_HIP(hipMemcpyAsync(out_count, b->d_out_count, (size_t)b->nq * 4, hipMemcpyDeviceToHost, st));
+      // the results are one contiguous block doc | seg | score | count: one D2H copy
+      std::vector<uint32_t> blk(3 * n + b->nq);
+      SLG_HIP(hipMemcpyAsync(blk.data(), b->d_out.p, blk.size() * 4, hipMemcpyDeviceToHost, st));
       if (stats) {
         scored.resize(b->nq);
         SLG_HIP(hipMemcpyAsync(scored.data(), b->d_q_scored.p, (size_t)b->nq * 4,
                                hipMemcpyDeviceToHost, st));
       }
+      SLG_HIP(hipStreamSynchronize(st));
+      if (n) {
+        std::memcpy(out_doc, blk.data(), n * 4);
+        std::memcpy(out_seg, blk.data() + n, n * 4);
+        std::memcpy(out_score, blk.data() + 2 * n, n * 4);
+      }
+      std::memcpy(out_count, blk.data() + 3 * n, (size_t)b->nq * 4);
     }
-    SLG_HIP(hipStreamSynchronize(st));
     if (stats)
       for (uint32_t q = 0; q < b->nq; q++) {
         // brute-force accounting: wand.rs:472 (postings_advanced += len), :500-503
