@@ -33,7 +33,8 @@ extern "C" {
 #define SLG_NO_TERM 0xFFFFFFFFu      /* term absent from a segment (api/reader.rs:2989) */
 #define SLG_NO_VECTOR 0xFFFFFFFFu    /* vectors/mod.rs:65-67 (u32::MAX offset) */
 #define SLG_MAX_QUERY_TERMS 32u      /* scored terms per query per segment */
-#define SLG_MAX_K 1024u              /* k = limit+1 handed to the scorer (api/reader.rs:2618) */
+#define SLG_MAX_K 20001u             /* k = min(max(candidate_size, limit), 20000) + 1 (api/reader.rs:2615-2619) */
+#define SLG_MAX_MERGE_K 1024u        /* largest k of slg_merge_shards_device / k_out of slg_rerank_batch */
 #define SLG_BLOCK_SIZE 128u          /* index/postings.rs:11 DEFAULT_BLOCK_SIZE */
 
 /* return codes (searchlite-ffi/src/lib.rs returns NULL / -1..-5 / 0) */

@@ -13,7 +13,8 @@ from . import build as _build
 NO_TERM = 0xFFFFFFFF
 NO_VECTOR = 0xFFFFFFFF
 MAX_QUERY_TERMS = 32
-MAX_K = 1024
+MAX_K = 20001
+MAX_MERGE_K = 1024
 
 OK, ERR_INVALID, ERR_DEVICE, ERR_OOM, ERR_UNSUPPORTED, ERR_INTERNAL = 0, -1, -2, -3, -4, -5
 STRATEGY_BM25, STRATEGY_WAND, STRATEGY_BMW = 0, 1, 2

@@ -935,7 +935,10 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     }
     // large k: per-slice top-k lists would be mostly the slice itself; keep every doc above the
     // seed threshold instead (one candidate slot per posting) and select per query afterwards
-    b->cand_mode = (b->uniform || b->multi) && k > 256 && env_u32("SLG_NO_CAND_MODE", 0) == 0;
+    b->cand_mode = (b->uniform || b->multi) && k > 256 && (k > 1024 || env_u32("SLG_NO_CAND_MODE", 0) == 0);
+    if (k > 1024 && !b->cand_mode)
+      throw SlgError(SLG_ERR_UNSUPPORTED, "k > 1024 needs the candidate/select path (SLG_MAX_K: not with "
+                                          "SLG_MAXSCORE / SLG_NO_UNIFORM)");
     uint64_t cand_total = 0;
     if (b->cand_mode)
       for (size_t i = 0; i < sqs.size(); i++) {
@@ -1308,7 +1311,7 @@ int slg_merge_shards_device(slg_index *ix, uint32_t n_shards, uint32_t nq, uint3
                             uint32_t *d_out_seg, float *d_out_score, uint32_t *d_out_count) {
   return guarded([&] {
     SLG_REQUIRE(ix != nullptr, "index is NULL");
-    if (k > SLG_MAX_K) throw SlgError(SLG_ERR_UNSUPPORTED, "k > SLG_MAX_K");
+    if (k > SLG_MAX_MERGE_K) throw SlgError(SLG_ERR_UNSUPPORTED, "k > SLG_MAX_MERGE_K");
     if (nq == 0) return;
     SLG_REQUIRE(d_count && d_out_count, "count arrays are NULL");
     SLG_REQUIRE(k == 0 || (d_doc && d_seg && d_score && d_out_doc && d_out_seg && d_out_score),
@@ -1370,7 +1373,7 @@ int slg_rerank_batch_device(slg_index *ix, uint32_t nq, const float *d_qvecs, co
                             uint32_t *d_out_count) {
   return guarded([&] {
     SLG_REQUIRE(ix != nullptr, "index is NULL");
-    if (k_out > SLG_MAX_K) throw SlgError(SLG_ERR_UNSUPPORTED, "k_out > SLG_MAX_K");
+    if (k_out > SLG_MAX_MERGE_K) throw SlgError(SLG_ERR_UNSUPPORTED, "k_out > SLG_MAX_MERGE_K");
     if (nq == 0) return;
     SLG_REQUIRE(d_qvecs && d_alpha && d_cand_count && d_out_count, "device arrays are NULL");
     SLG_REQUIRE(max_cand == 0 || (d_cand_doc && d_cand_seg && d_cand_bm25), "candidate arrays are NULL");

@@ -637,14 +637,13 @@ struct SelectParams {
   uint32_t nq, k;
 };
 
-constexpr uint32_t kSelectMaxK = 1024;     // largest k
-constexpr uint32_t kSelectCap = 2048;      // keys sorted in LDS (>= kSelectMaxK)
+constexpr uint32_t kSelectCap = 2048;      // keys sorted in LDS at a time (a rank range of the result)
 constexpr uint32_t kSelectMaxSlices = 1024;  // slice table in LDS; more: strided slice loops
 constexpr uint32_t kSelectThreads = 512;
 
 static __global__ void __launch_bounds__(kSelectThreads) select_topk_kernel(SelectParams p) {
   constexpr uint32_t NT = kSelectThreads;
-  __shared__ uint32_t hist[256];
+  __shared__ uint32_t hist[256], hist0[256];  // hist0: top score byte of all live candidates
   __shared__ uint32_t w_ok[kSelectCap], w_sg[kSelectCap], w_dc[kSelectCap];
   __shared__ uint32_t sh_pre[3], sh_need, sh_done, sh_nvalid, sh_nwin, sh_anydel, sh_taken;
   __shared__ uint32_t t_end[kSelectMaxSlices];   // inclusive prefix of the slice counts
@@ -668,7 +667,7 @@ static __global__ void __launch_bounds__(kSelectThreads) select_topk_kernel(Sele
     sh_done = 0;
     sh_taken = 0;
   }
-  if (tid < 256) hist[tid] = 0;
+  if (tid < 256) hist0[tid] = 0;
   __syncthreads();
   // slice table: the query's candidates form one flat index space [0, n)
   if (table) {
@@ -747,85 +746,102 @@ static __global__ void __launch_bounds__(kSelectThreads) select_topk_kernel(Sele
         return;
       }
     }
-    atomicAdd(&hist[a >> 24], 1u);
+    atomicAdd(&hist0[a >> 24], 1u);
   });
   __syncthreads();
-
-  // ---- radix select, one byte per level, until the keys at or above the chosen prefix fit the
-  //      LDS sort buffer (they include the k best) ----
-  uint32_t level = 0;
-  for (;; level++) {
-    const uint32_t wd = level >> 2, shift = 24u - 8u * (level & 3u);
-    if (level > 0) {
-      if (tid < 256) hist[tid] = 0;
-      __syncthreads();
-      const uint32_t p0 = sh_pre[0], p1 = sh_pre[1], p2 = sh_pre[2];
-      const uint32_t himask = shift == 24u ? 0u : ~((1u << (shift + 8u)) - 1u);  // bytes above
-      for_each([&](uint32_t a, uint32_t b, uint32_t c, uint64_t) {
-        const uint32_t w = wd == 0 ? a : (wd == 1 ? b : c), pw = wd == 0 ? p0 : (wd == 1 ? p1 : p2);
-        bool m = (w & himask) == (pw & himask);
-        if (wd >= 1) m = m && a == p0;
-        if (wd >= 2) m = m && b == p1;
-        if (m) atomicAdd(&hist[(w >> shift) & 255u], 1u);
-      });
-      __syncthreads();
-    }
-    if (wave == 0) {
-      // lane l owns bins 255-4l .. 252-4l (descending); inclusive prefix of the lane sums
-      const uint32_t b0 = 255u - 4u * lane;
-      const uint32_t h0 = hist[b0], h1 = hist[b0 - 1], h2 = hist[b0 - 2], h3 = hist[b0 - 3];
-      const uint32_t tot = h0 + h1 + h2 + h3;
-      uint32_t incl = tot;
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t v = __shfl_up(incl, o, 64);
-        if ((int)lane >= o) incl += v;
-      }
-      const uint32_t matching = __shfl(incl, 63, 64);
-      if (level == 0 && lane == 0) sh_nvalid = matching;
-      const uint32_t need = sh_need, excl = incl - tot;
-      if (matching < need) {
-        // (level 0 only) fewer live candidates than k: everything is kept
-        if (lane == 0) {
-          sh_done = 2;
-          sh_taken = matching;
-        }
-      } else if (excl < need && need <= incl) {  // exactly one lane
-        uint32_t cum = excl, b = b0, h = h0;
-        if (cum + h < need) { cum += h; b = b0 - 1; h = h1; }
-        if (cum + h < need) { cum += h; b = b0 - 2; h = h2; }
-        if (cum + h < need) { cum += h; b = b0 - 3; h = h3; }
-        sh_pre[wd] = sh_pre[wd] | (b << shift);
-        sh_need = need - cum;  // rank of the k-th key inside the bucket
-        const uint32_t taken = (k - (need - cum)) + h;  // keys with prefix >= the chosen one
-        sh_taken = taken;
-        sh_done = (taken <= kSelectCap || level == 11) ? 1u : 0u;
-      }
-    }
-    __syncthreads();
-    if (sh_done) break;
+  if (tid == 0) {
+    uint32_t nv = 0;
+    for (int i = 0; i < 256; i++) nv += hist0[i];
+    sh_nvalid = nv;
   }
-  const bool all = sh_done == 2;
+  __syncthreads();
   const uint32_t nvalid = sh_nvalid;
   const uint32_t nout = nvalid < k ? nvalid : k;
-  uint32_t taken = sh_taken < kSelectCap ? sh_taken : kSelectCap;
 
-  // ---- gather the keys at or above the chosen prefix ----
-  {
+  // decided-prefix compare: key (a, b, c) >= prefix (p0, p1, p2) on the top (level + 1) bytes
+  auto at_or_above = [](uint32_t a, uint32_t b, uint32_t c, uint32_t p0, uint32_t p1, uint32_t p2,
+                        uint32_t level) {
     const uint32_t wd = level >> 2, shift = 24u - 8u * (level & 3u);
     const uint32_t keep = ~((1u << shift) - 1u);  // decided bytes of word wd
-    const uint32_t p0 = sh_pre[0], p1 = sh_pre[1], p2 = sh_pre[2];
-    for_each([&](uint32_t a, uint32_t b, uint32_t c, uint64_t) {
-      bool win = all;
-      if (!all) {
-        const uint32_t ka = wd == 0 ? (a & keep) : a, kb = wd == 1 ? (b & keep) : b,
-                       kc = wd == 2 ? (c & keep) : c;
-        if (wd == 0)
-          win = ka >= p0;
-        else if (wd == 1)
-          win = ka > p0 || (ka == p0 && kb >= p1);
-        else
-          win = ka > p0 || (ka == p0 && (kb > p1 || (kb == p1 && kc >= p2)));
+    const uint32_t ka = wd == 0 ? (a & keep) : a, kb = wd == 1 ? (b & keep) : b,
+                   kc = wd == 2 ? (c & keep) : c;
+    if (wd == 0) return ka >= p0;
+    if (wd == 1) return ka > p0 || (ka == p0 && kb >= p1);
+    return ka > p0 || (ka == p0 && (kb > p1 || (kb == p1 && kc >= p2)));
+  };
+
+  // ---- the result is produced in rank ranges of at most kSelectCap keys: for each range a
+  //      byte-wise radix select finds the prefix of its last key (exactly, except for the final
+  //      range, which may take a few keys more than needed and drops them after the sort), the
+  //      keys between this prefix and the previous range's are gathered, sorted, written ----
+  uint32_t k_done = 0;
+  bool have_prev = false;
+  uint32_t q0 = 0, q1 = 0, q2 = 0, q_level = 0;  // prefix of the previous range
+  while (k_done < nout) {
+    const uint32_t target = nout - k_done > kSelectCap ? k_done + kSelectCap : nout;
+    const bool last = target == nout;
+    const bool all = last && nvalid - k_done <= kSelectCap;  // everything left fits: no select
+    __syncthreads();
+    if (tid == 0) {
+      sh_pre[0] = sh_pre[1] = sh_pre[2] = 0;
+      sh_need = target;
+      sh_done = all ? 2u : 0u;
+      sh_taken = all ? nvalid : 0u;
+      sh_nwin = 0;
+    }
+    __syncthreads();
+    uint32_t level = 0;
+    if (!all) {
+      for (;; level++) {
+        const uint32_t wd = level >> 2, shift = 24u - 8u * (level & 3u);
+        if (tid < 256) hist[tid] = level == 0 ? hist0[tid] : 0u;
+        __syncthreads();
+        if (level > 0) {
+          const uint32_t p0 = sh_pre[0], p1 = sh_pre[1], p2 = sh_pre[2];
+          const uint32_t himask = shift == 24u ? 0u : ~((1u << (shift + 8u)) - 1u);  // bytes above
+          for_each([&](uint32_t a, uint32_t b, uint32_t c, uint64_t) {
+            const uint32_t w = wd == 0 ? a : (wd == 1 ? b : c), pw = wd == 0 ? p0 : (wd == 1 ? p1 : p2);
+            bool m = (w & himask) == (pw & himask);
+            if (wd >= 1) m = m && a == p0;
+            if (wd >= 2) m = m && b == p1;
+            if (m) atomicAdd(&hist[(w >> shift) & 255u], 1u);
+          });
+          __syncthreads();
+        }
+        if (wave == 0) {
+          // lane l owns bins 255-4l .. 252-4l (descending); inclusive prefix of the lane sums
+          const uint32_t b0 = 255u - 4u * lane;
+          const uint32_t h0 = hist[b0], h1 = hist[b0 - 1], h2 = hist[b0 - 2], h3 = hist[b0 - 3];
+          const uint32_t tot = h0 + h1 + h2 + h3;
+          uint32_t incl = tot;
+          for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o, 64);
+            if ((int)lane >= o) incl += v;
+          }
+          const uint32_t need = sh_need, excl = incl - tot;
+          if (excl < need && need <= incl) {  // exactly one lane (need <= matching keys)
+            uint32_t cum = excl, b = b0, h = h0;
+            if (cum + h < need) { cum += h; b = b0 - 1; h = h1; }
+            if (cum + h < need) { cum += h; b = b0 - 2; h = h2; }
+            if (cum + h < need) { cum += h; b = b0 - 3; h = h3; }
+            sh_pre[wd] = sh_pre[wd] | (b << shift);
+            sh_need = need - cum;  // rank of the target key inside the bucket
+            const uint32_t taken = (target - (need - cum)) + h;  // keys with prefix >= the chosen one
+            sh_taken = taken;
+            // exact when the whole bucket is wanted; the final range may overshoot within the buffer
+            sh_done = (h == need - cum || level == 11 || (last && taken - k_done <= kSelectCap)) ? 1u : 0u;
+          }
+        }
+        __syncthreads();
+        if (sh_done) break;
       }
+    }
+    const uint32_t p0 = sh_pre[0], p1 = sh_pre[1], p2 = sh_pre[2];
+    const uint32_t count = (sh_taken - k_done) < kSelectCap ? (sh_taken - k_done) : kSelectCap;
+    // ---- gather the keys of this range ----
+    for_each([&](uint32_t a, uint32_t b, uint32_t c, uint64_t) {
+      bool win = all || at_or_above(a, b, c, p0, p1, p2, level);
+      if (win && have_prev) win = !at_or_above(a, b, c, q0, q1, q2, q_level);
       if (win) {
         const uint32_t at = atomicAdd(&sh_nwin, 1u);
         if (at < kSelectCap) {
@@ -835,41 +851,51 @@ static __global__ void __launch_bounds__(kSelectThreads) select_topk_kernel(Sele
         }
       }
     });
-  }
-  __syncthreads();
-  // ---- bitonic sort, descending 96-bit key; the first nout are the result ----
-  uint32_t n2 = 1;
-  while (n2 < taken) n2 <<= 1;
-  for (uint32_t i = taken + tid; i < n2; i += NT) {
-    w_ok[i] = 0;
-    w_sg[i] = 0;
-    w_dc[i] = 0;
-  }
-  __syncthreads();
-  for (uint32_t size = 2; size <= n2; size <<= 1) {
-    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-      for (uint32_t t = tid; t < (n2 >> 1); t += NT) {
-        const uint32_t i = 2 * t - (t & (stride - 1));  // lower index of the pair
-        const uint32_t j = i + stride;
-        const bool desc = (i & size) == 0;
-        const uint32_t ai = w_ok[i], bi = w_sg[i], ci = w_dc[i];
-        const uint32_t aj = w_ok[j], bj = w_sg[j], cj = w_dc[j];
-        const bool i_lt_j = ai < aj || (ai == aj && (bi < bj || (bi == bj && ci < cj)));
-        if (i_lt_j == desc) {
-          w_ok[i] = aj; w_sg[i] = bj; w_dc[i] = cj;
-          w_ok[j] = ai; w_sg[j] = bi; w_dc[j] = ci;
-        }
-      }
-      __syncthreads();
+    __syncthreads();
+    // ---- bitonic sort, descending 96-bit key ----
+    uint32_t n2 = 1;
+    while (n2 < count) n2 <<= 1;
+    for (uint32_t i = count + tid; i < n2; i += NT) {
+      w_ok[i] = 0;
+      w_sg[i] = 0;
+      w_dc[i] = 0;
     }
+    __syncthreads();
+    for (uint32_t size = 2; size <= n2; size <<= 1) {
+      for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+        for (uint32_t t = tid; t < (n2 >> 1); t += NT) {
+          const uint32_t i = 2 * t - (t & (stride - 1));  // lower index of the pair
+          const uint32_t j = i + stride;
+          const bool desc = (i & size) == 0;
+          const uint32_t ai = w_ok[i], bi = w_sg[i], ci = w_dc[i];
+          const uint32_t aj = w_ok[j], bj = w_sg[j], cj = w_dc[j];
+          const bool i_lt_j = ai < aj || (ai == aj && (bi < bj || (bi == bj && ci < cj)));
+          if (i_lt_j == desc) {
+            w_ok[i] = aj; w_sg[i] = bj; w_dc[i] = cj;
+            w_ok[j] = ai; w_sg[j] = bi; w_dc[j] = ci;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    const uint32_t emit = target - k_done;  // (the final range drops what it took beyond k)
+    for (uint32_t i = tid; i < emit; i += NT) {
+      const int32_t tk = (int32_t)(w_ok[i] ^ 0x80000000u);
+      p.out_doc[(size_t)q * k + k_done + i] = ~w_dc[i];
+      p.out_seg[(size_t)q * k + k_done + i] = ~w_sg[i];
+      p.out_score[(size_t)q * k + k_done + i] = key_to_float(tk);
+    }
+    k_done = target;
+    have_prev = true;
+    q0 = p0;
+    q1 = p1;
+    q2 = p2;
+    q_level = level;
   }
-  for (uint32_t i = tid; i < k; i += NT) {
-    const bool real = i < nout;
-    const uint32_t ok = real ? w_ok[i] : 0u;
-    const int32_t tk = (int32_t)(ok ^ 0x80000000u);
-    p.out_doc[(size_t)q * k + i] = real ? ~w_dc[i] : 0u;
-    p.out_seg[(size_t)q * k + i] = real ? ~w_sg[i] : 0u;
-    p.out_score[(size_t)q * k + i] = real ? key_to_float(tk) : 0.0f;
+  for (uint32_t i = nout + tid; i < k; i += NT) {
+    p.out_doc[(size_t)q * k + i] = 0u;
+    p.out_seg[(size_t)q * k + i] = 0u;
+    p.out_score[(size_t)q * k + i] = 0.0f;
   }
   if (tid == 0) p.out_count[q] = nout;
 }

@@ -271,6 +271,22 @@ def test_score_plans_multi_field_and_dismax(gpu, oracle, k):
         assert_same_hits(tuple(x[q:q + 1] for x in got), one, 0.0, f"plans + filter q={q}")
 
 
+@pytest.mark.parametrize("k", [1025, 2049, 5000, 20001])
+def test_very_large_k_rank_ranges(gpu, oracle, k):
+    """k up to the reference's 20 001 (api/reader.rs:2615-2619): the select kernel emits the result
+    in rank ranges of its LDS sort buffer.  Queries with fewer hits than k, exactly-tied scores
+    (integer-ish corpus), two segments, tombstones, 3 and 7 terms (uniform / multi kernel)."""
+    rng = np.random.default_rng(9000 + k)
+    segs = [random_segment(rng, 9000 + 1500 * i, 16, 5) for i in range(2)]
+    segs[0].set_deleted(list(range(2, segs[0].n_docs, 13)))
+    for T in (3, 7):
+        offs, terms, w = random_queries(rng, 6, T, 16, n_segs=2)
+        terms[1, 0] = gpu.NO_TERM
+        want = _oracle_batch(oracle, segs, offs, terms, w, k)
+        with gpu.GpuIndex(segs) as ix:
+            assert_same_hits(ix.search_batch(offs, terms, w, k), want, 0.0, f"k={k} T={T}")
+
+
 def test_ragged_and_empty_inputs(gpu, oracle):
     rng = np.random.default_rng(3)
     seg = random_segment(rng, 300, 12, 10)
@@ -432,7 +448,7 @@ def test_error_codes(gpu):
     with gpu.GpuIndex([seg]) as ix:
         offs = np.array([0, 1], dtype=np.uint32)
         with pytest.raises(N.SlgError) as e:
-            ix.search_batch(offs, np.array([[0]], np.uint32), np.ones(1, np.float32), 2000)
+            ix.search_batch(offs, np.array([[0]], np.uint32), np.ones(1, np.float32), 20002)
         assert e.value.code == N.ERR_UNSUPPORTED        # k > SLG_MAX_K
         with pytest.raises(N.SlgError) as e:
             ix.search_batch(np.array([0, 33], np.uint32), np.arange(33, dtype=np.uint32)[:, None],
