@@ -268,7 +268,7 @@ def main():
                        "corpus_build_s": round(t_corpus, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "kernel": "score_uniform_kernel" if T <= 5 else "score_rounds_kernel",
+                         "traffic": traffic, "kernel": "score_uniform_kernel" if T <= 4 else "score_multi_kernel",
                          "kernel_ms": round(kern_avg_ms, 4), "launches": n_launch,
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
