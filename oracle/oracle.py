@@ -239,8 +239,14 @@ def search_batch_filtered(segments, q_offsets, q_terms, q_weights, k, q_filter, 
                     sg.deleted = np.packbits(dead, bitorder="little")
                 segs.append(sg)
         a, b = int(q_offsets[q]), int(q_offsets[q + 1])
+        kq = dict(kw)  # per-term / per-query plan arrays: this query's part
+        if kq.get("q_leaf") is not None:
+            kq["q_leaf"] = np.asarray(kq["q_leaf"])[a:b]
+        for name in ("q_plan", "q_tie", "q_nleaves"):
+            if kq.get(name) is not None:
+                kq[name] = np.asarray(kq[name])[q:q + 1]
         r = search_batch(segs, np.array([0, b - a], dtype=np.uint32), q_terms[a:b], q_weights[a:b], k,
-                         strategy=strategy, **kw)
+                         strategy=strategy, **kq)
         if out is None:
             out = [np.zeros((nq,) + x.shape[1:], dtype=x.dtype) for x in r[:4]]
         for o, x in zip(out, r[:4]):

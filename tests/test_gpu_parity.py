@@ -4,6 +4,8 @@ Bar: identical (segment, doc) sequence and BIT-EXACT f32 scores (the kernels add
 partials in query-term order with contraction off, exactly the reference's leaf-order sum);
 north_star only asks for 1e-4.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -261,14 +263,9 @@ def test_score_plans_multi_field_and_dismax(gpu, oracle, k):
         fid = ix.add_filter(masks)
         qf = np.array([fid if q % 2 else -1 for q in range(24)], dtype=np.int32)
         got = ix.search_plan(offs, terms, w, k, q_filter=qf, **kw)
-    for q in range(24):  # oracle per query (filter folded into the tombstones)
-        sl = slice(int(offs[q]), int(offs[q + 1]))
-        one = oracle.search_batch_filtered(
-            segs, np.array([0, sl.stop - sl.start], dtype=np.uint32), terms[sl], w[sl], k,
-            np.array([0 if q % 2 else -1], dtype=np.int32), [masks], strategy=oracle.BM25,
-            q_leaf=kw["q_leaf"][sl], q_plan=kw["q_plan"][q:q + 1], q_tie=kw["q_tie"][q:q + 1],
-            q_nleaves=kw["q_nleaves"][q:q + 1])
-        assert_same_hits(tuple(x[q:q + 1] for x in got), one, 0.0, f"plans + filter q={q}")
+    want_f = oracle.search_batch_filtered(segs, offs, terms, w, k, np.where(qf >= 0, 0, -1), [masks],
+                                          strategy=oracle.BM25, **kw)
+    assert_same_hits(got, want_f, 0.0, "plans + filter")
 
 
 @pytest.mark.parametrize("k", [1025, 2049, 5000, 20001])
@@ -285,6 +282,17 @@ def test_very_large_k_rank_ranges(gpu, oracle, k):
         want = _oracle_batch(oracle, segs, offs, terms, w, k)
         with gpu.GpuIndex(segs) as ix:
             assert_same_hits(ix.search_batch(offs, terms, w, k), want, 0.0, f"k={k} T={T}")
+
+
+def test_randomised_parity_short(gpu, oracle):
+    """40 random batches of tools/fuzz_parity.py (corpus shape, 0..32 terms, k 1..3000, zero and
+    negative weights, absent terms, tombstones, filters, score plans, strategies), bit-exact."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.run(40, 11, verbose=False)
 
 
 def test_ragged_and_empty_inputs(gpu, oracle):

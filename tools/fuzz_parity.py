@@ -1,0 +1,106 @@
+"""Randomised parity run (GPU box): random corpora, query shapes, k, weights (also zero / negative),
+tombstones, doc filters, score plans and strategies, each batch compared bit for bit with the CPU
+oracle.  usage: python tools/fuzz_parity.py [iterations] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import searchlite_amd as sa
+from oracle import oracle as O
+from tests.util import random_segment, random_multifield_segment, assert_same_hits
+
+
+
+def run(iters, seed0, verbose=True):
+  O.build()
+  t0 = time.time()
+  for it in range(iters):
+      rng = np.random.default_rng(seed0 * 100003 + it)
+      n_segs = int(rng.integers(1, 4))
+      multi = rng.random() < 0.4
+      vocab = int(rng.integers(3, 60))
+      F = int(rng.integers(2, 4)) if multi else 1
+      segs = []
+      for s in range(n_segs):
+          n_docs = int(rng.choice([37, 300, 2500, 12000]))
+          avg = int(rng.integers(2, 30))
+          sg = random_multifield_segment(rng, n_docs, vocab, F, avg) if multi else \
+              random_segment(rng, n_docs, vocab, avg, missing_len_frac=0.05 if rng.random() < 0.3 else 0.0,
+                             zipf=rng.random() < 0.7)
+          if rng.random() < 0.5:
+              sg.set_deleted(np.nonzero(rng.random(n_docs) < rng.choice([0.02, 0.3, 0.9]))[0].tolist())
+          segs.append(sg)
+      nq = int(rng.integers(1, 24))
+      k = int(rng.choice([1, 2, 11, 64, 65, 101, 256, 257, 600, 1024, 1025, 3000]))
+      offs, terms, w, leaf, plan, tie, nl = [0], [], [], [], [], [], []
+      V = vocab * F
+      for q in range(nq):
+          T = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 8, 13, 32], p=[.03, .1, .1, .2, .12, .12, .1, .1, .08, .05]))
+          T = min(T, V)
+          ids = rng.choice(V, size=T, replace=False)
+          lf = np.sort(rng.integers(0, max(1, T // 2 + 1), size=T)) if rng.random() < 0.5 else np.arange(T)
+          if rng.random() < 0.3:
+              lf = rng.permutation(lf)      # leaves need not arrive sorted
+          for i in range(T):
+              row = []
+              for s in range(n_segs):
+                  row.append(sa.NO_TERM if rng.random() < 0.1 else int(ids[i]))
+              terms.append(row)
+              r = rng.random()
+              w.append(np.float32(0.0 if r < 0.03 else (-rng.random() if r < 0.08 else rng.random() * 3 + 0.1)))
+              leaf.append(int(lf[i]))
+          offs.append(len(terms))
+          dm = rng.random() < 0.35
+          plan.append(sa.PLAN_DISMAX if dm else sa.PLAN_SUM)
+          tie.append(float(rng.choice([0.0, 0.3, 1.0])) if dm else 0.0)
+          nl.append(int(max(lf) + 1 + rng.integers(0, 2)) if T else int(rng.integers(0, 2)))
+      offs = np.array(offs, dtype=np.uint32)
+      terms = np.array(terms, dtype=np.uint32).reshape(-1, n_segs)
+      w = np.array(w, dtype=np.float32)
+      use_plan = rng.random() < 0.6
+      kw = dict(q_leaf=np.array(leaf, dtype=np.uint32), q_plan=np.array(plan, dtype=np.int32),
+                q_tie=np.array(tie, dtype=np.float32), q_nleaves=np.array(nl, dtype=np.uint32)) if use_plan else {}
+      use_filter = rng.random() < 0.4
+      masks = [rng.random(sg.n_docs) < rng.choice([0.05, 0.5, 0.95]) for sg in segs]
+      with sa.GpuIndex(segs) as ix:
+          qf = None
+          if use_filter:
+              fid = ix.add_filter(masks)
+              qf = np.array([fid if rng.random() < 0.6 else -1 for _ in range(nq)], dtype=np.int32)
+          strat = int(rng.choice([sa.Bm25, sa.Wand, sa.Bmw]))
+          got = ix.search_plan(offs, terms, w, k, strategy=strat, q_filter=qf, **kw)
+      if use_filter:
+          want = O.search_batch_filtered(segs, offs, terms, w, k, np.where(qf >= 0, 0, -1), [masks],
+                                         strategy=O.BM25, **kw)
+      else:
+          want = O.search_batch(segs, offs, terms, w, k, strategy=O.BM25, **kw)
+      try:
+          assert_same_hits(got, want, 0.0, f"fuzz it={it} seed={seed0} nq={nq} k={k} segs={n_segs} multi={multi} "
+                                           f"plan={use_plan} filter={use_filter}")
+      except AssertionError:
+          for q in range(nq):
+              n = int(want[3][q])
+              if int(got[3][q]) == n and np.array_equal(got[0][q, :n], want[0][q, :n]) and \
+                      np.array_equal(got[1][q, :n], want[1][q, :n]):
+                  continue
+              T = int(offs[q + 1] - offs[q])
+              i = 0
+              while i < min(n, int(got[3][q])) and got[0][q, i] == want[0][q, i] and got[1][q, i] == want[1][q, i]:
+                  i += 1
+              gs, gd = int(got[1][q, i]), int(got[0][q, i])
+              dead = segs[gs].deleted is not None and bool(np.unpackbits(segs[gs].deleted, bitorder="little")[gd])
+              print(f"query {q}: T={T} strat={strat} filter={None if qf is None else int(qf[q])} counts gpu/oracle "
+                    f"{int(got[3][q])}/{n} first diff at {i}: gpu (seg {gs}, doc {gd}, {got[2][q, i]}) oracle "
+                    f"(seg {int(want[1][q, i])}, doc {int(want[0][q, i])}, {want[2][q, i]}); gpu doc deleted={dead} "
+                    f"mask={bool(masks[gs][gd])} plan={plan[q]} tie={tie[q]} nl={nl[q]} "
+                    f"leaves={leaf[int(offs[q]):int(offs[q + 1])]} w={w[int(offs[q]):int(offs[q + 1])]} "
+                    f"terms={terms[int(offs[q]):int(offs[q + 1])].tolist()}")
+              break
+          raise
+      if verbose and it % 10 == 9:
+          print(f"{it + 1} batches ok ({time.time() - t0:.0f} s)", flush=True)
+  if verbose:
+    print("fuzz_parity: all", iters, "batches bit-exact")
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
