@@ -411,6 +411,36 @@ def test_sparse_lists_span_many_doc_windows(gpu, oracle):
     assert_same_hits(got, want, 0.0, "sparse windows")
 
 
+@pytest.mark.parametrize("k", [11, 400])
+def test_many_term_kernel_cut_paths(gpu, oracle, k):
+    """score_multi_kernel's chunking: (a) clustered lists put far more than 512 postings into one
+    planned round (proportional cut at a common doc id), (b) sparse lists make a round span many
+    16 384-doc windows (window cut), (c) both with a score plan (leaf closes per chunk)."""
+    n = 600_000
+    rng = np.random.default_rng(14 + k)
+    lists = [np.sort(rng.choice(n, size=40_000, replace=False)),          # the splitter
+             np.arange(300_000, 300_000 + 15_000),                        # 15k consecutive docs
+             np.arange(300_500, 300_500 + 9_000, 2),                      # overlapping, clustered
+             np.sort(rng.choice(n, size=500, replace=False)),
+             np.sort(rng.choice(n, size=60, replace=False)),
+             np.array([3, 299_999, 300_000, n - 1]),
+             np.sort(rng.choice(n, size=2_000, replace=False))]
+    seg = _skewed_segment(n, lists)
+    #   q0: all seven lists; q1: only sparse lists (window cuts); q2: clustered ones
+    offs = np.array([0, 7, 11, 16], dtype=np.uint32)
+    terms = np.array([[0], [1], [2], [3], [4], [5], [6], [3], [4], [5], [6], [1], [2], [4], [5], [3]],
+                     dtype=np.uint32)
+    w = (rng.random(16).astype(np.float32) + np.float32(0.5))
+    want = _oracle_batch(oracle, [seg], offs, terms, w, k)
+    leaf = np.array([0, 0, 1, 1, 1, 2, 2, 0, 0, 1, 1, 0, 1, 1, 0, 1], dtype=np.uint32)
+    kw = dict(q_leaf=leaf, q_plan=np.array([gpu.PLAN_SUM, gpu.PLAN_DISMAX, gpu.PLAN_SUM], dtype=np.int32),
+              q_tie=np.array([0.0, 0.4, 0.0], dtype=np.float32))
+    want_plan = oracle.search_batch([seg], offs, terms, w, k, strategy=oracle.BM25, **kw)
+    with gpu.GpuIndex([seg]) as ix:
+        assert_same_hits(ix.search_batch(offs, terms, w, k), want, 0.0, "multi kernel cuts")
+        assert_same_hits(ix.search_plan(offs, terms, w, k, **kw), want_plan, 0.0, "multi kernel cuts + plans")
+
+
 def test_three_tiny_lists_share_one_slot(gpu, oracle):
     """Three lists inside one 64-posting slot with common docs: the strictly ordered claim path
     (sum order (a+b)+c matters in f32)."""
