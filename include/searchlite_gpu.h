@@ -16,8 +16,11 @@
  *
  * Eligibility (the caller keeps every other request shape on searchlite's CPU scorer;
  * SURVEY.md section 8b): ScoreMode::Score, sort = _score desc, no collector/aggs, no
- * score_adjust/explain, no cursor, no filter, matcher = pure disjunction, ScorePlan =
- * Sum of leaves with leaf i == query term i.  accept() is then `!is_deleted(doc)`.
+ * score_adjust/explain, no cursor, matcher = pure disjunction; filters as doc bitmaps
+ * (slg_index_add_filter*: accept() = !is_deleted(doc) && filter(doc)); ScorePlan = Sum or DisMax
+ * over leaves, each leaf the sum of one or more scored terms (slg_batch_prepare_plan; the
+ * default is leaf i == query term i); k = limit + 1 up to 20 001; up to 32 scored terms per
+ * query and segment.
  */
 #ifndef SEARCHLITE_GPU_H
 #define SEARCHLITE_GPU_H
@@ -116,8 +119,8 @@ int slg_device_count(void);
 /*
  * Stage segments into HBM on `device` and precompute per-posting BM25 impacts
  * (query/bm25.rs:1-6 + query/wand.rs:269-286 with weight factored out).  Returns NULL on
- * error (see slg_last_error).  The handle may be used from several host threads; calls
- * on one handle are serialized internally.
+ * error (see slg_last_error).  The handle may be shared by host threads: batch planning
+ * takes no lock, launches are serialized, waits happen outside the lock.
  */
 slg_index *slg_index_create(const slg_segment_desc *segs, uint32_t n_segs, int device);
 void slg_index_destroy(slg_index *index);
