@@ -32,6 +32,13 @@ def test_header_declares_expected_surface():
         assert must in names
 
 
+def test_integration_doc_binds_every_declared_function():
+    """INTEGRATION.md's Rust `extern "C"` block (the reference-side binding) lists the whole ABI."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in declared_functions() if f"pub fn {n}(" not in md]
+    assert not missing, f"not bound in INTEGRATION.md: {missing}"
+
+
 def test_library_exports_every_declared_symbol(lib):
     missing = [n for n in declared_functions() if not hasattr(lib, n)]
     assert not missing, f"not exported: {missing}"
