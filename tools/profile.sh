@@ -19,5 +19,9 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_c -o c2 -- python3 $A
 echo "pmc_c rc=$?" >> $OUT/pmc_c.log
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_d -o c2 -- python3 $ARGS > $OUT/pmc_d.log 2>&1
 echo "pmc_d rc=$?" >> $OUT/pmc_d.log
+# the default bench command (two batches in flight: kernels of different batches overlap, so the
+# per-kernel durations in this trace are stretched by the co-running kernels)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_default -o c2 -- python3 $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --check 0 > $OUT/trace_default.log 2>&1
+echo "trace_default rc=$?" >> $OUT/trace_default.log
 cd $REPO && python3 tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
