@@ -80,16 +80,20 @@ uint32_t env_u32(const char *name, uint32_t dflt) {
 
 // Freed batch buffers are kept for the next batch: hipMalloc / hipFree cost ~100 us each and
 // hipFree synchronizes the device, which would serialize host threads that serve batches
-// concurrently.  Size classes are powers of two (>= 4 KiB).
+// concurrently.  Size classes: powers of two from 4 KiB to 1 MiB, above that eight steps per
+// octave (<= 12.5 % over-allocation).
 struct BufPool {
   std::mutex mu;
   std::multimap<size_t, void *> free_;
   size_t pooled = 0;
   static constexpr size_t kMaxPooled = 4ull << 30;
-  static size_t size_class(size_t n) {
+  static size_t size_class(size_t n) {  // powers of two up to 1 MiB, then eighths of an octave
     size_t c = 4096;
-    while (c < n) c <<= 1;
-    return c;
+    while (c < n && c < (1u << 20)) c <<= 1;
+    if (c >= n) return c;
+    while ((c << 1) < n) c <<= 1;  // c <= n < 2c
+    const size_t step = c >> 3;
+    return c + ((n - c + step - 1) / step) * step;
   }
   void *get(size_t cls) {
     std::lock_guard<std::mutex> lk(mu);
