@@ -72,6 +72,29 @@ def random_multifield_segment(rng, n_docs, vocab, n_fields, avg_len, k1=0.9, b=0
                    field_avgdl=avg, docs=float(n_docs), k1=k1, b=b, term_field=tfield)
 
 
+def skewed_segment(rng, n_docs, n_lists):
+    """One-field segment built list by list (fast for millions of doc ids): list sizes from a few
+    postings to ~n_docs/8, each either spread uniformly or packed into a narrow run of doc ids."""
+    from searchlite_amd.segment import Segment
+    offs, docs, tfs = [0], [], []
+    for _ in range(n_lists):
+        size = int(min(n_docs // 4, rng.choice([3, 40, 600, 5_000, 40_000, max(8, n_docs // 8)])))
+        if rng.random() < 0.35:   # clustered: (almost) consecutive doc ids
+            start = int(rng.integers(0, max(1, n_docs - size * 2)))
+            d = start + np.unique(rng.integers(0, size * 2, size=size))
+        else:
+            d = np.unique(rng.integers(0, n_docs, size=size))
+        d = d.astype(np.uint32)
+        docs.append(d)
+        tfs.append(rng.integers(1, 4, size=len(d)).astype(np.uint32))
+        offs.append(offs[-1] + len(d))
+    dl = rng.integers(5, 60, size=n_docs).astype(np.float32)
+    return Segment(n_docs=n_docs, term_offsets=np.array(offs, dtype=np.uint64),
+                   doc_ids=np.concatenate(docs), tfs=np.concatenate(tfs), field_doc_len=[dl],
+                   field_avgdl=np.array([np.float32(dl.mean())], dtype=np.float32), docs=float(n_docs),
+                   k1=1.2, b=0.75)
+
+
 def random_queries(rng, nq, n_terms, vocab, n_segs=1, lo=0, weights=False):
     offs = (np.arange(nq + 1) * n_terms).astype(np.uint32)
     terms = np.empty((nq * n_terms, n_segs), dtype=np.uint32)

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import searchlite_amd as sa
 from oracle import oracle as O
-from tests.util import random_segment, random_multifield_segment, assert_same_hits
+from tests.util import random_segment, random_multifield_segment, skewed_segment, assert_same_hits
 
 
 
@@ -16,11 +16,17 @@ def run(iters, seed0, verbose=True):
   for it in range(iters):
       rng = np.random.default_rng(seed0 * 100003 + it)
       n_segs = int(rng.integers(1, 4))
-      multi = rng.random() < 0.4
-      vocab = int(rng.integers(3, 60))
+      skew = rng.random() < 0.3          # big sparse / clustered lists: window and overflow cuts
+      multi = not skew and rng.random() < 0.4
+      vocab = int(rng.integers(4, 14)) if skew else int(rng.integers(3, 60))
       F = int(rng.integers(2, 4)) if multi else 1
       segs = []
       for s in range(n_segs):
+          if skew:
+              segs.append(skewed_segment(rng, int(rng.choice([60_000, 500_000, 3_000_000])), vocab))
+              if rng.random() < 0.4:
+                  segs[-1].set_deleted(np.nonzero(rng.random(segs[-1].n_docs) < 0.2)[0].tolist())
+              continue
           n_docs = int(rng.choice([37, 300, 2500, 12000]))
           avg = int(rng.integers(2, 30))
           sg = random_multifield_segment(rng, n_docs, vocab, F, avg) if multi else \
