@@ -163,15 +163,22 @@ def main():
         ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     step_no = [0]
     turn = [0]
+    gathered = [None] * inflight
 
     def step():
         if inflight > 1:
             i = turn[0] % inflight
             turn[0] += 1
+            if use_dist and gathered[i] is not None:
+                streams[i].wait_event(gathered[i])  # the previous gather of this block is done
             batches[i].run()
-            if use_dist:  # replica mode: one all-gather of this batch's block, on its stream
-                with torch.cuda.stream(streams[i]):
-                    dist.all_gather_into_tensor(g_blocks[i], t_blocks[i])
+            if use_dist:
+                # replica mode: one all-gather of this batch's result block.  RCCL stays on the
+                # default stream (ordered after the batch's kernels by an event); the batch's
+                # stream waits for the gather before the block is overwritten two steps later.
+                stream.wait_event(streams[i].record_event())
+                dist.all_gather_into_tensor(g_blocks[i], t_blocks[i])
+                gathered[i] = stream.record_event()
             return
         batch.run()
         if rerank:  # candidates = the BM25 pass's device results (no host round trip)
