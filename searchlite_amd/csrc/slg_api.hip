@@ -795,6 +795,7 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
           sq.plan = plan_kind == SLG_PLAN_DISMAX ? 2u : (shared ? 1u : 0u);
           sq.tie = tie;
           sq.max_init = present < n_leaves ? 0.0f : -INFINITY;
+          sq.n_leaves = n_leaves;
           if (sq.plan) any_plan = true;
         }
         // ---- MaxScore classification (opt-in with SLG_MAXSCORE=1 for strategies Wand / Bmw:

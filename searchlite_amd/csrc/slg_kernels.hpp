@@ -64,7 +64,7 @@ struct RoundQuery {  // sub-query = (query, segment) pair with >= 1 non-empty te
   uint32_t plan;
   float tie;       // DisMax tie breaker
   float max_init;  // DisMax: 0.0 if some leaf of the plan has no term in this segment, else -inf
-  uint32_t pad2;
+  uint32_t n_leaves;  // leaves of the plan (a DisMax counts every one, absent ones as 0.0)
 };
 
 struct QueryRef {

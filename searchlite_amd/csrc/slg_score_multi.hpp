@@ -90,6 +90,7 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
   const uint32_t plan = p.plan_batch ? rfl(s.plan) : 0u;
   const float tie = __uint_as_float(rfl(__float_as_uint(s.tie)));
   const uint32_t max_init = rfl(__float_as_uint(s.max_init));
+  const uint32_t n_leaves = rfl(s.n_leaves);
   float *acc = reinterpret_cast<float *>(smem + multi_wave_lds(KREGS));  // only if plan_batch
   float *mxv = acc + kMultiCap;
   const gu32_t gbounds = (gu32_t)p.bounds + s.bounds_begin + (size_t)r0 * T;
@@ -246,12 +247,18 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
       }
       wave_fence();
       // leaf close (score plans): fold the current leaf's partial sums into the per-doc totals
+      // A DisMax takes the max over ALL leaves of the plan; a leaf none of whose lists has a
+      // posting in this chunk is never closed here and counts as 0.0 (planner.rs:138-150).
+      uint32_t n_closed = 0;
       auto close_leaf = [&](const bool final) {
+        n_closed++;
+        const bool some_leaf_idle = final && n_closed < n_leaves;
         for (uint32_t r = lane; r < ndocs; r += 64) {
           const float c = __uint_as_float(vals[r]);
           const float a = acc[r] + c;
-          const float m = fmaxf(mxv[r], c);
+          float m = fmaxf(mxv[r], c);
           if (final) {
+            if (some_leaf_idle) m = fmaxf(m, 0.0f);
             vals[r] = __float_as_uint(plan == 2u ? m + tie * (a - m) : a);
           } else {
             acc[r] = a;

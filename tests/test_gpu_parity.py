@@ -441,6 +441,28 @@ def test_many_term_kernel_cut_paths(gpu, oracle, k):
         assert_same_hits(ix.search_plan(offs, terms, w, k, **kw), want_plan, 0.0, "multi kernel cuts + plans")
 
 
+def test_dismax_counts_leaves_without_postings_in_a_round(gpu, oracle):
+    """DisMax takes the max over ALL leaves (planner.rs:138-150): with a negative-weight leaf, a doc
+    found only in it scores max(0.0, x) + tie * (x - max) — also in rounds where the other leaf's
+    list has no posting at all (found by tools/fuzz_parity.py: such a leaf is never "closed")."""
+    n = 200_000
+    rng = np.random.default_rng(77)
+    lists = [np.arange(1000, 1400),                                  # leaf 0: clustered, positive
+             np.sort(rng.choice(n, size=30_000, replace=False)),     # leaf 1: everywhere, negative
+             np.sort(rng.choice(n, size=900, replace=False))]        # leaf 2
+    seg = _skewed_segment(n, lists)
+    offs = np.array([0, 2, 5], dtype=np.uint32)
+    terms = np.array([[0], [1], [0], [1], [2]], dtype=np.uint32)
+    w = np.array([1.8, -0.99, 0.7, -1.3, 0.4], dtype=np.float32)
+    kw = dict(q_leaf=np.array([0, 1, 0, 1, 2], dtype=np.uint32),
+              q_plan=np.array([gpu.PLAN_DISMAX, gpu.PLAN_DISMAX], dtype=np.int32),
+              q_tie=np.array([0.3, 0.0], dtype=np.float32), q_nleaves=np.array([2, 4], dtype=np.uint32))
+    for k in (64, 700):
+        want = oracle.search_batch([seg], offs, terms, w, k, strategy=oracle.BM25, **kw)
+        with gpu.GpuIndex([seg]) as ix:
+            assert_same_hits(ix.search_plan(offs, terms, w, k, **kw), want, 0.0, f"dismax idle leaf k={k}")
+
+
 def test_three_tiny_lists_share_one_slot(gpu, oracle):
     """Three lists inside one 64-posting slot with common docs: the strictly ordered claim path
     (sum order (a+b)+c matters in f32)."""
