@@ -727,6 +727,21 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     std::vector<uint64_t> sq_postings, sq_postings_all;
     std::vector<uint32_t> q_sq_begin(nq + 1, 0);
     bool any_filter = false, any_plan = false;
+    // Score plans run on the multi kernel only, which has no MaxScore path: if any query of the
+    // batch can need a plan (a DisMax, or two terms sharing a leaf), nothing is classified.
+    bool plans_requested = false;
+    for (uint32_t q = 0; q < nq && !plans_requested; q++) {
+      if (q_plan && q_plan[q] == SLG_PLAN_DISMAX) plans_requested = true;
+      if (q_leaf && q_offsets[q + 1] >= q_offsets[q]) {
+        const uint32_t t0 = q_offsets[q], nt = q_offsets[q + 1] - t0;
+        for (uint32_t i = 0; i < nt && !plans_requested; i++)
+          for (uint32_t j = 0; j < i; j++)
+            if (q_leaf[t0 + i] == q_leaf[t0 + j]) {
+              plans_requested = true;
+              break;
+            }
+      }
+    }
     for (uint32_t q = 0; q < nq; q++) {
       q_sq_begin[q] = (uint32_t)sqs.size();
       SLG_REQUIRE(q_offsets[q + 1] >= q_offsets[q], "q_offsets not monotone");
@@ -805,7 +820,7 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
         // their maximum contribution ub_t = w_t * champ[t][0] are non-essential while the running
         // sum of ub stays below theta0: a doc found only in them totals < theta0.
         uint32_t ess_mask = sq.n_terms >= 32 ? 0xFFFFFFFFu : ((1u << sq.n_terms) - 1u);
-        if (strategy != SLG_STRATEGY_BM25 && !sh.champ.empty() && k >= 1 && k <= 1024u && fq == 0 && sq.plan == 0 &&
+        if (strategy != SLG_STRATEGY_BM25 && !sh.champ.empty() && k >= 1 && k <= 1024u && fq == 0 && !plans_requested &&
             sq.n_terms > 1 && env_u32("SLG_MAXSCORE", 0) != 0) {
           bool ok = true;
           float theta0 = 0.0f;

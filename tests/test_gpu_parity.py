@@ -579,6 +579,12 @@ def test_maxscore_pruning_is_exact(gpu, oracle, monkeypatch):
     want = oracle.search_batch([seg], offs, terms, w, 31, strategy=oracle.BM25, n_threads=8)
     with gpu.GpuIndex([seg]) as ix:
         assert_same_hits(ix.search_batch(offs, terms, w, 31, gpu.Bmw), want, 0.0, "maxscore T=5")
+        # a batch that carries score plans is never classified (the plans run on the multi kernel,
+        # which has no MaxScore path): grouped leaves stay bit-exact under SLG_MAXSCORE=1
+        leaf = np.tile(np.array([0, 0, 1, 1, 2], dtype=np.uint32), 32)
+        want_p = oracle.search_batch([seg], offs, terms, w, 31, strategy=oracle.BM25, n_threads=8, q_leaf=leaf)
+        assert_same_hits(ix.search_plan(offs, terms, w, 31, q_leaf=leaf, strategy=gpu.Wand), want_p, 0.0,
+                         "plans under SLG_MAXSCORE")
 
 
 # ---- cross-shard merge kernel (config 4 shape, emulated on one GPU) ----------------------------
