@@ -198,6 +198,22 @@ class GpuIndex:
         n = min(int(c[0]), limit)
         return [(int(s[0, i]), int(d[0, i]), float(sc[0, i])) for i in range(n)]
 
+    def search_planned(self, planned, plan: int, n_leaves: int, tie_breaker: float = 0.0,
+                       limit: int = 10, strategy: int = Wand, filter_id: int = -1):
+        """One request whose scored terms come from segment.plan_query_string / plan_best_fields /
+        plan_most_fields / plan_dis_max_terms (the leaf assignment of query/planner.rs).
+        Returns [(segment_ord, doc_id, score)] like search()."""
+        from .segment import resolve_plan
+        if not planned:
+            return []
+        ids, w, leaf = resolve_plan(self.segments, planned)
+        offs = np.array([0, len(planned)], dtype=np.uint32)
+        d, s, sc, c = self.search_plan(offs, ids, w, limit + 1, q_leaf=leaf, q_plan=[plan],
+                                       q_tie=[tie_breaker], q_nleaves=[n_leaves], strategy=strategy,
+                                       q_filter=None if filter_id < 0 else [filter_id])
+        n = min(int(c[0]), limit)
+        return [(int(s[0, i]), int(d[0, i]), float(sc[0, i])) for i in range(n)]
+
     # -- rerank ----------------------------------------------------------------------
     def rerank_batch(self, qvecs, alpha, cand_doc, cand_seg, cand_bm25, cand_count, k_out: int):
         """gpu::rerank slot (gpu/rerank.rs:3): vector similarity + alpha blend + top-k_out."""

@@ -295,6 +295,42 @@ def test_randomised_parity_short(gpu, oracle):
     mod.run(40, 11, verbose=False)
 
 
+def test_reference_multi_field_tests_on_the_gpu(gpu, oracle):
+    """tests/multi_field.rs:104-223 (best_fields vs most_fields, dis_max tie breaker, field
+    boosts) on that test's own 5-doc corpus, through the GPU path; every hit list also equals
+    the oracle's bit for bit."""
+    b = gpu.SegmentBuilder(["body", "title"], k1=0.9, b=0.4)
+    for i, (title, body) in enumerate([("rust search", "fast"), ("rust", "search"), ("rust", "rust search"),
+                                       ("boring", "rust"), ("none", "rust fast search")]):
+        b.add_document(f"doc-{i + 1}", {"title": title, "body": body})
+    seg = b.build()
+    fields = [("title", 1.0), ("body", 1.0)]
+
+    def run(ix, planned, plan, n_leaves, tie=0.0):
+        hits = ix.search_planned(planned, plan, n_leaves, tie, limit=10)
+        ids, w, leaf = gpu.resolve_plan([seg], planned)
+        want = oracle.search_batch([seg], np.array([0, len(planned)], np.uint32), ids, w, 11,
+                                   strategy=oracle.BM25, q_leaf=leaf, q_plan=[plan], q_tie=[tie],
+                                   q_nleaves=[n_leaves])
+        n = int(want[3][0])
+        assert [h[1] for h in hits] == [int(x) for x in want[0][0, :n]]
+        assert [np.float32(h[2]).view(np.uint32) for h in hits] == [x.view(np.uint32) for x in want[2][0, :n]]
+        return {seg.ext_ids[h[1]]: h[2] for h in hits}, [seg.ext_ids[h[1]] for h in hits]
+
+    with gpu.GpuIndex([seg]) as ix:
+        best, _ = run(ix, *gpu.plan_best_fields(["rust", "search"], fields))
+        most, _ = run(ix, *gpu.plan_most_fields(["rust", "search"], fields))
+        body_only, _ = run(ix, *gpu.plan_best_fields(["rust", "search"], [("body", 1.0)]))
+        assert "doc-3" in body_only and "doc-2" in best and "doc-2" in most
+        assert most["doc-2"] > best["doc-2"]                       # :104-167
+        _, order = run(ix, *gpu.plan_dis_max_terms([("title", "rust", 1.0), ("body", "rust", 1.0)]), tie=0.5)
+        assert order[0] == "doc-3"                                 # :169-195
+        boosted, _ = run(ix, *gpu.plan_best_fields(["rust"], [("title", 2.0), ("body", 1.0)]))
+        assert boosted["doc-2"] > boosted["doc-4"]                 # :197-223
+        qs, _ = run(ix, *gpu.plan_query_string(["rust", "search"], fields))
+        assert set(qs) == {"doc-1", "doc-2", "doc-3", "doc-4", "doc-5"}
+
+
 def test_ragged_and_empty_inputs(gpu, oracle):
     rng = np.random.default_rng(3)
     seg = random_segment(rng, 300, 12, 10)
