@@ -106,7 +106,7 @@ def main():
     threads = max(1, min(32, host_cores // max(1, world)))
 
     t0 = time.time()
-    shard_mode = args.mode == "shard" and world > 1
+    shard_mode = args.mode == "shard" and (world > 1 or args.force_dist)
     seg_seed = cseed + (rank if shard_mode else 0)
     seg = corpus.zipf_segment(n_docs, vocab, seed=seg_seed, n_threads=threads)
     q_seed = 7 + (0 if shard_mode else rank)
@@ -123,8 +123,8 @@ def main():
     index.set_stream(stream.cuda_stream)
     # several batches in flight (separate work buffers, separate HIP streams): the partition /
     # merge kernels of one batch overlap the scoring kernel of another.  Not combined with the
-    # rerank stage or the cross-shard merge, which run on the index stream.
-    inflight = max(1, args.inflight) if not (rerank or shard_mode) else 1
+    # rerank stage, which runs on the index stream.
+    inflight = max(1, args.inflight) if not rerank else 1
     batches = [index.prepare(offs, terms, w, k, strategy) for _ in range(inflight)]
     streams = [torch.cuda.Stream() for _ in range(inflight)] if inflight > 1 else [stream]
     if inflight > 1:
@@ -165,6 +165,18 @@ def main():
     turn = [0]
     gathered = [None] * inflight
 
+    def shard_merge(gblk):  # api/reader.rs:2776-2778 across shards (index stream = default stream)
+        n_ = nq * k
+        gb = gblk.view(world, -1)
+        g_doc = gb[:, :n_].contiguous()
+        g_seg = gb[:, n_:2 * n_].contiguous()
+        g_score = gb[:, 2 * n_:3 * n_].contiguous()
+        g_count = gb[:, 3 * n_:].contiguous()
+        index.merge_shards_device(world, nq, k, g_doc.data_ptr(), g_seg.data_ptr(),
+                                  g_score.data_ptr(), g_count.data_ptr(), 1,
+                                  m_doc.data_ptr(), m_seg.data_ptr(), m_score.data_ptr(),
+                                  m_count.data_ptr())
+
     def step():
         if inflight > 1:
             i = turn[0] % inflight
@@ -178,6 +190,8 @@ def main():
                 # stream waits for the gather before the block is overwritten two steps later.
                 stream.wait_event(streams[i].record_event())
                 dist.all_gather_into_tensor(g_blocks[i], t_blocks[i])
+                if shard_mode:
+                    shard_merge(g_blocks[i])
                 gathered[i] = stream.record_event()
             return
         batch.run()
@@ -195,17 +209,8 @@ def main():
             # per-rank top-k exchanged over xGMI in ONE all-gather: the contiguous block
             # doc|seg|score|count = (3k+1)*Q*4 bytes per rank
             dist.all_gather_into_tensor(g_block, t_block)
-            if shard_mode:  # api/reader.rs:2776-2778 across shards
-                n_ = nq * k
-                gb = g_block.view(world, -1)
-                g_doc = gb[:, :n_].contiguous()
-                g_seg = gb[:, n_:2 * n_].contiguous()
-                g_score = gb[:, 2 * n_:3 * n_].contiguous()
-                g_count = gb[:, 3 * n_:].contiguous()
-                index.merge_shards_device(world, nq, k, g_doc.data_ptr(), g_seg.data_ptr(),
-                                          g_score.data_ptr(), g_count.data_ptr(), 1,
-                                          m_doc.data_ptr(), m_seg.data_ptr(), m_score.data_ptr(),
-                                          m_count.data_ptr())
+            if shard_mode:
+                shard_merge(g_block)
 
     def fence():
         if use_dist:
