@@ -1,4 +1,8 @@
-// slg_score.hpp — the hot kernel: exhaustive BM25 accumulate + top-k, one wave per slice.
+// slg_score.hpp — shared round-scoring definitions (partition_rounds_kernel, RoundScoreParams,
+// wave scans) and the first-generation PACKED kernel score_rounds_kernel: lists packed back to
+// back in the register slots with per-lane list ids.  It is superseded by slg_score_uni.hpp
+// (<= 4 lists) and slg_score_multi.hpp (5..32 lists, score plans) and now runs only for the
+// opt-in MaxScore path (SLG_MAXSCORE=1) or with SLG_NO_UNIFORM=1.
 //
 // Restates query/wand.rs:459-566 (brute_force: every posting of every term is scored and
 // summed per doc, here in ScorePlan leaf order planner.rs:122-135) and push_top_k

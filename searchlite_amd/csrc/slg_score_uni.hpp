@@ -1,16 +1,18 @@
-// slg_score_uni.hpp — the hot kernel for queries with <= kUniSlots terms (every benchmark
-// configuration): same algorithm as slg_score.hpp (exact pre-planned rounds, LDS bitmap-rank
-// accumulate, register top-k), but every 64-lane register slot holds postings of ONE list.
+// slg_score_uni.hpp — the hot kernel for queries with few terms (the host uses it up to 4 lists;
+// BASELINE config 2): exact pre-planned rounds, LDS bitmap-rank accumulate, buffered top-k, and
+// every 64-lane register slot holds postings of ONE list.
 //
 // Padding each list to a slot boundary makes the per-slot list id, weight, base address and
-// lane count wave-uniform scalars (one v_readlane each from a lane-held slot descriptor),
-// removes the per-lane list selects and the mixed-slot ordering paths of the packed kernel,
-// and lets the posting loads use scalar-base addressing.  Measured on config 2 it issues
-// ~2.5x fewer vector instructions per round than the packed layout.
+// lane count wave-uniform scalars (one v_readlane each from a lane-held slot descriptor; the
+// descriptors of 8 rounds are computed at once), removes the per-lane list selects and the
+// mixed-slot ordering paths of the older packed kernel (slg_score.hpp), and lets the posting
+// loads be whole-slot, scalar base + lane.
 //
 // Restates query/wand.rs:459-566 (every posting scored, per-doc sums in ScorePlan leaf order,
-// planner.rs:122-135) and push_top_k (wand.rs:905-916); see slg_score.hpp for the phase-by-
-// phase description and DESIGN.md section 4.
+// planner.rs:122-135) and push_top_k (wand.rs:905-916); phases P0..P4 are described in
+// DESIGN.md section 4.  k <= 256: candidates go to a per-wave LDS buffer (BufTopK,
+// slg_kernels.hpp); larger k: to the slice's region of a global candidate array, picked per
+// query by select_topk_kernel.  More lists than 4: slg_score_multi.hpp.
 #pragma once
 
 #include <hip/hip_runtime.h>
