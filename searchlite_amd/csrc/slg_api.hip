@@ -208,6 +208,7 @@ struct slg_batch {
   uint32_t n_sq = 0, n_slices = 0, n_terms = 0, n_boundaries = 0, max_terms = 0;
   bool uniform = false;  // every sub-query fits the one-list-per-slot kernel
   bool plan_batch = false;  // some sub-query has a score plan (multi kernel only)
+  bool pruned = false;      // some sub-query has non-essential lists (MaxScore)
   bool multi = false;    // many-term form of it (slg_score_multi.hpp); else the packed kernel
   uint64_t n_postings = 0, n_postings_essential = 0, n_rounds = 0;
   std::vector<uint64_t> q_postings;  // per query (stats.postings_advanced)
@@ -265,7 +266,8 @@ template <> void launch_score_kregs<16>(const RoundScoreParams &, uint32_t, int,
 }  // namespace slg
 namespace {
 
-// kind: 0 packed (slg_score.hpp), 1 uniform (slg_score_uni.hpp), 2 multi (slg_score_multi.hpp)
+// kind: 0 packed (slg_score.hpp), 1 uniform (slg_score_uni.hpp), 2 multi (slg_score_multi.hpp),
+// 3 multi with MaxScore-classified lists
 void launch_score(const slg::RoundScoreParams &sp, uint32_t max_terms, int kind, hipStream_t st) {
 #ifdef SLG_STAMPS  // diagnostic build: only the k <= 64 variant is compiled
   if (kregs_for(sp.k) != 1) throw SlgError(SLG_ERR_UNSUPPORTED, "stamps build supports k <= 64 only");
@@ -727,6 +729,13 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     std::vector<uint64_t> sq_postings, sq_postings_all;
     std::vector<uint32_t> q_sq_begin(nq + 1, 0);
     bool any_filter = false, any_plan = false;
+    uint32_t batch_max_nt = 0;
+    for (uint32_t q = 0; q < nq; q++)
+      if (q_offsets[q + 1] >= q_offsets[q]) batch_max_nt = std::max(batch_max_nt, q_offsets[q + 1] - q_offsets[q]);
+    const char *ms_env = getenv("SLG_MAXSCORE");
+    const bool maxscore_on = ms_env ? atoi(ms_env) != 0
+                                    : (batch_max_nt > env_u32("SLG_UNIFORM_MAX_TERMS", 4) &&
+                                       env_u32("SLG_NO_MULTI", 0) == 0 && env_u32("SLG_NO_UNIFORM", 0) == 0);
     // Score plans run on the multi kernel only, which has no MaxScore path: if any query of the
     // batch can need a plan (a DisMax, or two terms sharing a leaf), nothing is classified.
     bool plans_requested = false;
@@ -813,15 +822,16 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
           sq.n_leaves = n_leaves;
           if (sq.plan) any_plan = true;
         }
-        // ---- MaxScore classification (opt-in with SLG_MAXSCORE=1 for strategies Wand / Bmw:
-        // exact, but in round 1 not yet faster than exhaustive scoring — DESIGN.md section 4) ----
+        // ---- MaxScore classification (strategies Wand / Bmw; exact).  On by default for batches
+        // that run on the multi kernel (a query with >= 5 terms), where probing the non-essential
+        // lists is cheaper than scoring them; SLG_MAXSCORE=1 / 0 forces it on / off ----
         // theta0 = max_t w_t * champ[t][k-1] is a lower bound of the final k-th score
         // (slg_score.hpp sets the same floor on the device).  Lists taken in ascending order of
         // their maximum contribution ub_t = w_t * champ[t][0] are non-essential while the running
         // sum of ub stays below theta0: a doc found only in them totals < theta0.
         uint32_t ess_mask = sq.n_terms >= 32 ? 0xFFFFFFFFu : ((1u << sq.n_terms) - 1u);
         if (strategy != SLG_STRATEGY_BM25 && !sh.champ.empty() && k >= 1 && k <= 1024u && fq == 0 && !plans_requested &&
-            sq.n_terms > 1 && env_u32("SLG_MAXSCORE", 0) != 0) {
+            sq.n_terms > 1 && maxscore_on) {
           bool ok = true;
           float theta0 = 0.0f;
           std::vector<std::pair<float, uint32_t>> ub(sq.n_terms);
@@ -887,11 +897,12 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
       if (sqs[i].ess_mask != full) b->uniform = false;
     }
     // more terms (the multi-field shape): the same slots-of-one-list design, 8 slots at a time
+    // (the multi kernel also runs MaxScore-classified batches: non-essential lists are only probed)
     b->multi = !b->uniform && ((env_u32("SLG_NO_MULTI", 0) == 0 && env_u32("SLG_NO_UNIFORM", 0) == 0) || any_plan);
     b->plan_batch = any_plan;
-    for (size_t i = 0; i < sqs.size() && b->multi; i++) {
+    for (size_t i = 0; i < sqs.size(); i++) {
       const uint32_t full = sqs[i].n_terms >= 32 ? 0xFFFFFFFFu : ((1u << sqs[i].n_terms) - 1u);
-      if (sqs[i].ess_mask != full) b->multi = false;
+      if (sqs[i].ess_mask != full) b->pruned = true;
     }
     // rounds per slice: short slices pack the tail of the launch better (one wave per slice,
     // ~5 generations of waves per SIMD on config 2).  The uniform kernel's slices are cheap to
@@ -996,6 +1007,8 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
       for (size_t sidx = 0; sidx < slice_sq.size(); sidx++)
         slice_order[lpt ? hist[slg::kMaxRoundsPerSlice - nrounds[sidx]]++ : sidx] = (uint32_t)sidx;
     }
+    if (getenv("SLG_DEBUG_ESS"))  // TEMP
+      fprintf(stderr, "essential postings %llu of %llu\n", (unsigned long long)b->n_postings_essential, (unsigned long long)b->n_postings);
     b->n_sq = (uint32_t)sqs.size();
     b->n_terms = (uint32_t)terms.size();
     b->n_slices = (uint32_t)slice_sq.size();
@@ -1128,7 +1141,7 @@ int slg_batch_run(slg_batch *b) {
         ev = &ix->prof_events[ix->prof_used++];
         SLG_HIP(hipEventRecord(ev->first, st));
       }
-      launch_score(sp, b->max_terms, b->uniform ? 1 : (b->multi ? 2 : 0), st);
+      launch_score(sp, b->max_terms, b->uniform ? 1 : (b->multi ? (b->pruned ? 3 : 2) : 0), st);
       if (ev) SLG_HIP(hipEventRecord(ev->second, st));
     }
     if (b->k > 0 && b->cand_mode && b->n_slices > 0) {

@@ -33,9 +33,14 @@ void launch_score_kregs(const RoundScoreParams &sp, uint32_t max_terms, int kind
 template <>
 void launch_score_kregs<SLG_INST_KREGS>(const RoundScoreParams &sp, uint32_t max_terms,
                                         int kind, hipStream_t st) {
-  if (kind == 2) {  // many lists: slots of one list each, 8 at a time (slg_score_multi.hpp)
-    hipLaunchKernelGGL((score_multi_kernel<SLG_INST_KREGS>), dim3(sp.n_slices), dim3(64),
-                       (size_t)multi_wave_lds(SLG_INST_KREGS) + (sp.plan_batch ? kMultiPlanLds : 0), st, sp);
+  if (kind == 2 || kind == 3) {  // many lists: slots of one list each, 8 at a time (slg_score_multi.hpp)
+    const size_t lds = (size_t)multi_wave_lds(SLG_INST_KREGS) + (sp.plan_batch ? kMultiPlanLds : 0);
+    if (sp.plan_batch)  // score plans (never together with MaxScore)
+      hipLaunchKernelGGL((score_multi_kernel<SLG_INST_KREGS, 2>), dim3(sp.n_slices), dim3(64), lds, st, sp);
+    else if (kind == 3)  // MaxScore-classified batch
+      hipLaunchKernelGGL((score_multi_kernel<SLG_INST_KREGS, 1>), dim3(sp.n_slices), dim3(64), lds, st, sp);
+    else
+      hipLaunchKernelGGL((score_multi_kernel<SLG_INST_KREGS, 0>), dim3(sp.n_slices), dim3(64), lds, st, sp);
     return;
   }
   if (kind == 1) {  // one list per register slot (slg_score_uni.hpp); waves are independent, so

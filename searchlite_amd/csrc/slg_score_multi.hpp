@@ -17,6 +17,12 @@
 // A round whose postings exceed the 512 accumulators, or whose docs span more than the 16 384
 // doc window, is cut at a common doc id and finished in further chunks.
 //
+// MaxScore pruning (strategies Wand / Bmw; query/wand.rs:659-903 reaches the same top-k by
+// skipping): the host marks as NON-ESSENTIAL the lists whose summed maximum contributions stay
+// below the seed threshold (slg_api.hip) — a doc found only in them cannot reach the top-k.  Such
+// lists set no bitmap bits in sweep A; in sweep C their postings are only probed against the
+// bitmap of the essential lists and added (in list order) where the doc is present.
+//
 // Score plans (query/planner.rs:113-153): when several terms share a ScorePlan leaf
 // (multi-field query strings) or the root is a DisMax, the lists arrive sorted by leaf; vals[]
 // then holds the CURRENT leaf's partial sums, and at every leaf change all accumulators are
@@ -42,8 +48,13 @@ constexpr int multi_wave_lds(int kregs) {
 }
 constexpr int kMultiPlanLds = 2 * kMultiCap * 4;  // acc[] and max[] of the leaf close
 
-template <int KREGS>
+// MODE 0: flat sums; 1: the batch has MaxScore-classified sub-queries (non-essential lists are
+// only probed); 2: the batch has score plans (leaf close).  Separate instantiations: the extra
+// code of one mode costs the others registers.
+template <int KREGS, int MODE>
 __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) {
+  constexpr bool MS = MODE == 1;
+  constexpr bool PL = MODE == 2;
   constexpr int NS = kUniSlots;
   constexpr bool BUF = uni_buffered(KREGS);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -86,8 +97,10 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
     my_leaf = tr.leaf;
   }
   const uint32_t my_off_lo = (uint32_t)my_off, my_off_hi = (uint32_t)(my_off >> 32);
+  const uint32_t ess_mask = MS ? rfl(s.ess_mask) : 0xFFFFFFFFu;  // bit t: list t is essential
+  const bool my_ess = lane < T && ((ess_mask >> lane) & 1u);
   // score plan: 0 flat sum, 1 Sum of multi-term leaves, 2 DisMax of leaves
-  const uint32_t plan = p.plan_batch ? rfl(s.plan) : 0u;
+  const uint32_t plan = PL ? rfl(s.plan) : 0u;
   const float tie = __uint_as_float(rfl(__float_as_uint(s.tie)));
   const uint32_t max_init = rfl(__float_as_uint(s.max_init));
   const uint32_t n_leaves = rfl(s.n_leaves);
@@ -123,21 +136,47 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
   // registers of one batch of 8 slots, and of the next one (in flight while this one is used)
   uint32_t doc[NS], ndoc[NS];
   float imp[NS], nimp[NS];
-  auto issue_batch = [&](const uint32_t b) {
+  auto issue_batch = [&](const uint32_t b, const uint32_t lo, const uint32_t hi) {
 #pragma unroll
     for (int jj = 0; jj < NS; jj++) {
-      const uint64_t base = ((uint64_t)rl(d_hi, b * 8u + jj) << 32) | rl(d_lo, b * 8u + jj);
+      const uint64_t base = ((uint64_t)rl(hi, b * 8u + jj) << 32) | rl(lo, b * 8u + jj);
       ndoc[jj] = gdocs[base + lane];
       nimp[jj] = gimps[base + lane];
     }
   };
-  auto take_batch = [&](const uint32_t b, const uint32_t dhi) {
+  auto take_batch = [&](const uint32_t b, const uint32_t cnt, const uint32_t dhi) {
 #pragma unroll
     for (int jj = 0; jj < NS; jj++) {  // lanes past the slot's count / docs past the cut: idle
-      const bool live = lane < rl(d_cnt, b * 8u + jj) && ndoc[jj] < dhi;
+      const bool live = lane < rl(cnt, b * 8u + jj) && ndoc[jj] < dhi;
       doc[jj] = live ? ndoc[jj] : kDocEnd;
       imp[jj] = nimp[jj];
     }
+  };
+  // slot descriptors for per-list counts c (lane t): list t takes ceil(c/64) consecutive global
+  // slots; lane G of (st, cnt, lo, hi) describes slot G; returns the number of slots
+  auto describe = [&](const uint32_t c, const uint32_t cur, uint32_t &st, uint32_t &cnt, uint32_t &lo,
+                      uint32_t &hi) {
+    const uint32_t m = (c + 63u) >> 6;
+    const uint32_t gs_incl = wave_incl_scan(m);
+    const uint32_t gs = gs_incl - m;        // first global slot of my list
+    const uint32_t S = rl(gs_incl, 63);      // slots in use
+    // lane G: the list that owns slot G = number of lists that end at or before G
+    uint32_t tG = 0;
+    for (uint32_t t = 0; t < T; t++) tG += (rl(gs_incl, t) <= lane) ? 1u : 0u;
+    tG = tG < T ? tG : T - 1;
+    const uint32_t l_gs = __shfl(gs, (int)tG, 64), l_c = __shfl(c, (int)tG, 64);
+    const uint64_t l_abs = (((uint64_t)__shfl(my_off_hi, (int)tG, 64) << 32) |
+                            __shfl(my_off_lo, (int)tG, 64)) +
+                           __shfl(cur, (int)tG, 64);
+    const uint32_t kin = (lane - l_gs) * 64u;
+    const bool used = lane < S;
+    const uint32_t left = used && l_c > kin ? l_c - kin : 0u;
+    const uint64_t base = used ? l_abs + kin : 0ull;
+    st = tG;
+    cnt = left < 64u ? left : 64u;
+    lo = (uint32_t)base;
+    hi = (uint32_t)(base >> 32);
+    return S;
   };
 
   for (uint32_t rr = 0; rr < n_r; rr++) {
@@ -155,12 +194,18 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
       const uint32_t rem = end - cur;
       const uint32_t R = wave_sum(rem);
       if (R == 0) break;
+      // essential postings need accumulators; all slots' descriptors live in the 64 lanes
+      // (without pruning every posting is essential and R <= 512 already implies <= 8 + T slots)
+      const uint32_t R_ess = MS ? wave_sum(my_ess ? rem : 0u) : R;
+      const uint32_t S_all = MS ? wave_sum((rem + 63u) >> 6) : 0u;
       uint32_t chunk = rem, dhi = rdhi;
       bool cut = false;
-      if (R > (uint32_t)kMultiCap) {
-        // too many postings for the accumulators: take a proportional part of every list and
-        // cut at the smallest "last loaded doc" of the lists that were not taken whole
-        const float share = (float)kMultiFill / (float)R;
+      if (R_ess > (uint32_t)kMultiCap || S_all > 60u) {
+        // too many postings for the accumulators (or slots): take a proportional part of every
+        // list and cut at the smallest "last loaded doc" of the lists that were not taken whole
+        float share = 1.0f;
+        if (R_ess > (uint32_t)kMultiCap) share = (float)kMultiFill / (float)R_ess;
+        if (S_all > 60u) share = fminf(share, (float)(48 * 64) / (float)R);
         uint32_t c = (uint32_t)((float)rem * share);
         c = c < 1u ? 1u : c;
         chunk = rem < c ? rem : c;
@@ -175,29 +220,12 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
         dhi = wbase + kSpan;
         cut = true;
       }
-      // ---- slots: list t takes ceil(chunk/64) consecutive global slots ----
-      const uint32_t m = (chunk + 63u) >> 6;
-      const uint32_t gs_incl = wave_incl_scan(m);
-      const uint32_t gs = gs_incl - m;            // first global slot of my list
-      const uint32_t S = rl(gs_incl, 63);          // slots in use (<= 8 + T <= 40)
-      {
-        // lane G: the list that owns slot G = number of lists that end at or before G
-        uint32_t tG = 0;
-        for (uint32_t t = 0; t < T; t++) tG += (rl(gs_incl, t) <= lane) ? 1u : 0u;
-        tG = tG < T ? tG : T - 1;
-        const uint32_t l_gs = __shfl(gs, (int)tG, 64), l_chunk = __shfl(chunk, (int)tG, 64);
-        const uint64_t l_abs = (((uint64_t)__shfl(my_off_hi, (int)tG, 64) << 32) |
-                                __shfl(my_off_lo, (int)tG, 64)) +
-                               __shfl(cur, (int)tG, 64);
-        const uint32_t kin = (lane - l_gs) * 64u;
-        const bool used = lane < S;
-        const uint32_t left = used && l_chunk > kin ? l_chunk - kin : 0u;
-        const uint64_t base = used ? l_abs + kin : 0ull;
-        d_st = tG;
-        d_cnt = left < 64u ? left : 64u;
-        d_lo = (uint32_t)base;
-        d_hi = (uint32_t)(base >> 32);
-      }
+      // ---- slots of the chunk (all lists, term order); with pruning also the essential lists
+      //      alone: sweep A touches nothing else ----
+      const uint32_t S = describe(chunk, cur, d_st, d_cnt, d_lo, d_hi);
+      uint32_t a_st = d_st, a_cnt = d_cnt, a_lo = d_lo, a_hi = d_hi, S_a = S;
+      if constexpr (MS) S_a = describe(my_ess ? chunk : 0u, cur, a_st, a_cnt, a_lo, a_hi);
+      const uint32_t nb_a = (S_a + 7u) >> 3;
       const uint32_t nb = (S + 7u) >> 3;
       const uint32_t wspan = dhi - wbase;
 
@@ -215,21 +243,18 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
         mx4[lane + 64] = make_uint4(max_init, max_init, max_init, max_init);
       }
       wave_fence();
-      // ---- sweep A: one bit per posting; what every list consumes (docs below the cut) ----
-      uint32_t consumed = 0;
-      issue_batch(0);
-      for (uint32_t b = 0; b < nb; b++) {
-        take_batch(b, dhi);
-        issue_batch(b + 1 < nb ? b + 1 : 0);  // (after the last batch: sweep C's first)
+      // ---- sweep A: one bit per posting of the essential lists ----
+      if (nb_a) issue_batch(0, a_lo, a_hi);
+      for (uint32_t b = 0; b < nb_a; b++) {
+        take_batch(b, a_cnt, dhi);
+        if (b + 1 < nb_a) issue_batch(b + 1, a_lo, a_hi);
 #pragma unroll
         for (int jj = 0; jj < NS; jj++) {
           const uint32_t rel = doc[jj] - wbase;
-          const bool in = rel < wspan;
-          if (in) atomicOr(&bm[rel & (kSpanWords - 1)], 1u << (rel >> 9));
-          const uint32_t cnt = (uint32_t)__popcll(__ballot(in));
-          consumed += lane == rl(d_st, b * 8u + jj) ? cnt : 0u;
+          if (rel < wspan) atomicOr(&bm[rel & (kSpanWords - 1)], 1u << (rel >> 9));
         }
       }
+      issue_batch(0, d_lo, d_hi);  // sweep C's first batch
       wave_fence();
       // ---- P2: exclusive prefix popcount (lane l owns words 4l..4l+3 and 256+4l..256+4l+3) ----
       uint32_t ndocs;
@@ -270,9 +295,10 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
       };
       uint32_t cur_leaf = 0xFFFFFFFFu;
       // ---- sweep C: rank every posting, accumulate slot by slot (= in list order) ----
+      uint32_t consumed = 0;  // what every list consumes: its postings below the cut
       for (uint32_t b = 0; b < nb; b++) {
-        take_batch(b, dhi);
-        if (b + 1 < nb) issue_batch(b + 1);
+        take_batch(b, d_cnt, dhi);
+        if (b + 1 < nb) issue_batch(b + 1, d_lo, d_hi);
         uint32_t rank[NS];
         bool in[NS];
         {
@@ -282,12 +308,23 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
             const uint32_t rel = doc[jj] - wbase;
             const uint32_t wi = rel & (kSpanWords - 1);
             in[jj] = rel < wspan;
+            if (cut) {  // (the ballot must run in all lanes: keep it out of the lane select)
+              const uint32_t n_in = (uint32_t)__popcll(__ballot(in[jj]));
+              consumed += lane == rl(d_st, b * 8u + jj) ? n_in : 0u;
+            }
             bit[jj] = 1u << ((rel >> 9) & 31u);
             wd[jj] = bm[wi];
             pf[jj] = pre[wi];
           }
 #pragma unroll
-          for (int jj = 0; jj < NS; jj++) rank[jj] = pf[jj] + __popc(wd[jj] & (bit[jj] - 1u));
+          for (int jj = 0; jj < NS; jj++) {
+            rank[jj] = pf[jj] + __popc(wd[jj] & (bit[jj] - 1u));
+            // a posting of a non-essential list counts only if an essential list has the doc
+            if constexpr (MS) {
+              const bool ess_slot = (ess_mask >> rl(d_st, b * 8u + jj)) & 1u;  // uniform
+              in[jj] = in[jj] && (ess_slot || (wd[jj] & bit[jj]) != 0u);
+            }
+          }
         }
 #pragma unroll
         for (int jj = 0; jj < NS; jj++) {
