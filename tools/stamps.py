@@ -4,7 +4,7 @@ import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from searchlite_amd import build, corpus
-build.GPU_LIB = os.path.join(build.LIBDIR, "libsearchlite_gpu_stamps.so")
+build.GPU_LIB = build.build_gpu(stamps=True)  # (re)built when a source is newer than the library
 from searchlite_amd import searcher, _native as N
 if len(sys.argv) > 1:
     os.environ["SLG_ROUNDS_PER_SLICE"] = sys.argv[1]
