@@ -946,8 +946,13 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
       const uint32_t rps = b->multi ? std::max<uint32_t>(1, want_rps)
                                     : std::max<uint32_t>(1, std::min<uint32_t>(want_rps, 64 / sq.n_terms - 1));
       const uint64_t S = (nr + rps - 1) / rps;
+      // (the per-slice candidate lists, n_slices * k entries indexed with 32 bits, exist only for
+      //  k <= 256; larger k goes through the candidate array, one slot per posting)
+      const bool slice_lists = !((b->uniform || b->multi) && k > 256 &&
+                                 (k > 1024 || env_u32("SLG_NO_CAND_MODE", 0) == 0));  // == !cand_mode
       SLG_REQUIRE(nr < 0x7FFFFFFFull && slice_sq.size() + S < 0x7FFFFFFFull &&
-                      (slice_sq.size() + S) * (uint64_t)std::max<uint32_t>(k, 1) < 0xFFFFFFFFull,
+                      (!slice_lists ||
+                       (slice_sq.size() + S) * (uint64_t)std::max<uint32_t>(k, 1) < 0xFFFFFFFFull),
                   "batch too large (rounds)");
       sq.n_rounds = (uint32_t)nr;
       sq.rounds_per_slice = rps;
