@@ -51,7 +51,9 @@ enum {
 };
 
 /* api/types.rs:6-13 ExecutionStrategy.  All three return the exhaustive-exact top-k
- * (the reference's own parity standard: tests/pruning.rs:44-104 Bm25 == Wand == Bmw). */
+ * (the reference's own parity standard: tests/pruning.rs:44-104 Bm25 == Wand == Bmw).
+ * Scores are ordered by f32 total_cmp (-0.0 below +0.0), as RankedDoc::cmp does
+ * (query/wand.rs:30-37). */
 enum { SLG_STRATEGY_BM25 = 0, SLG_STRATEGY_WAND = 1, SLG_STRATEGY_BMW = 2 };
 
 /* index/manifest.rs VectorMetric */
@@ -110,8 +112,10 @@ typedef struct {
 
 uint32_t slg_abi_version(void);
 
-/* Thread-local description of the last failure on this thread ("" if none). */
+/* Thread-local description of the last failure on this thread ("" if none), and its code
+ * (SLG_OK if none): functions that return a handle report the reason here. */
 const char *slg_last_error(void);
+int slg_last_error_code(void);
 
 /* Number of visible HIP devices, or negative error. */
 int slg_device_count(void);
@@ -123,7 +127,42 @@ int slg_device_count(void);
  * takes no lock, launches are serialized, waits happen outside the lock.
  */
 slg_index *slg_index_create(const slg_segment_desc *segs, uint32_t n_segs, int device);
+/* Destroys the index.  Batches prepared on it that are still alive are detached first: their
+ * device buffers are freed, every later call on them fails with SLG_ERR_INVALID, and
+ * slg_batch_destroy on them stays valid (so either destruction order is safe). */
 void slg_index_destroy(slg_index *index);
+
+/*
+ * Tuning knobs of the batch planner, fixed per index at creation (they never change results,
+ * only how the work is cut).  slg_tuning_default() fills the defaults and then applies the
+ * SLG_* environment overrides named below: it is the ONLY place the library reads the
+ * environment.  slg_index_create(segs, n, dev) == slg_index_create_tuned(segs, n, dev, NULL),
+ * NULL meaning slg_tuning_default().
+ */
+typedef struct {
+  uint32_t struct_size;          /* sizeof(slg_tuning) */
+  int32_t validate;              /* SLG_VALIDATE (1): check every posting at staging; 0: only the
+                                    last doc id of each list (ids < n_docs is always enforced) */
+  int32_t champions;             /* !SLG_NO_CHAMPIONS (1): per-term champion table = threshold seed */
+  int32_t allow_any_arch;        /* SLG_ALLOW_ANY_ARCH (0) */
+  int32_t pruning;               /* SLG_MAXSCORE (-1): -1 auto = on for batches with a query of more
+                                    terms than uniform_max_terms, strategies Wand/Bmw; 0 off; 1 on */
+  uint32_t uniform_max_terms;    /* SLG_UNIFORM_MAX_TERMS (4): lists the few-term kernel takes, <= 4 */
+  uint32_t uniform_round_target; /* SLG_UNIFORM_ROUND_TARGET (0 = auto): postings per round */
+  uint32_t multi_round_target;   /* SLG_MULTI_ROUND_TARGET (448) */
+  uint32_t probe_target;         /* SLG_PROBE_TARGET (2048): postings per round incl. probed lists */
+  uint32_t rounds_per_slice;     /* SLG_ROUNDS_PER_SLICE (0 = auto) */
+  uint32_t max_rounds_per_slice; /* SLG_MAX_ROUNDS_PER_SLICE (16) */
+  uint32_t slices_per_subquery;  /* SLG_SLICES_PER_SUBQUERY (16) */
+  int32_t cand_mode;             /* !SLG_NO_CAND_MODE (1): 256 < k <= 1024 via candidates + select */
+  int32_t slice_order;           /* !SLG_NO_SLICE_ORDER (1): longest slices launch first */
+  int32_t block_max;             /* !SLG_NO_BLOCK_MAX (1): stage per-block maxima (block 128,
+                                    index/postings.rs:11,101-111) and skip blocks of probed lists */
+} slg_tuning;
+void slg_tuning_default(slg_tuning *out);
+slg_index *slg_index_create_tuned(const slg_segment_desc *segs, uint32_t n_segs, int device,
+                                  const slg_tuning *tuning_or_null);
+int slg_index_get_tuning(const slg_index *index, slg_tuning *out);
 
 /* Bytes of HBM held by the index; total postings; segments. */
 int slg_index_info(const slg_index *index, uint32_t *n_segs, uint64_t *n_postings,
@@ -188,7 +227,8 @@ slg_batch *slg_batch_prepare(slg_index *index, uint32_t nq, const uint32_t *q_of
 slg_batch *slg_batch_prepare_filtered(slg_index *index, uint32_t nq, const uint32_t *q_offsets,
                                       const uint32_t *q_term_ids, const float *q_weights,
                                       const int32_t *q_filter, uint32_t k, int strategy);
-/* Same with a score plan per query (query/planner.rs:113-153).  The reference adds
+/* Same with a score plan per query (query/planner.rs:113-153).  q_tie[q] must lie in
+ * [0, 1] (validate_tie_breaker, query/planner.rs:850-856) and leaves must be < 2^31.  The reference adds
  * every scored term's contribution to a ScorePlan leaf (wand.rs:488-497 `buf[term.leaf] +=`) and
  * combines the leaves: a multi-field query string maps all fields of a word to one leaf and sums
  * the leaves; multi_match best_fields / dis_max take DisMax over the leaves.

@@ -46,6 +46,17 @@ class Stats(C.Structure):
                 ("postings_advanced", C.c_uint64)]
 
 
+class Tuning(C.Structure):
+    """slg_tuning: planner knobs fixed per index (include/searchlite_gpu.h)."""
+    _fields_ = [("struct_size", C.c_uint32), ("validate", C.c_int32), ("champions", C.c_int32),
+                ("allow_any_arch", C.c_int32), ("pruning", C.c_int32),
+                ("uniform_max_terms", C.c_uint32), ("uniform_round_target", C.c_uint32),
+                ("multi_round_target", C.c_uint32), ("probe_target", C.c_uint32),
+                ("rounds_per_slice", C.c_uint32), ("max_rounds_per_slice", C.c_uint32),
+                ("slices_per_subquery", C.c_uint32), ("cand_mode", C.c_int32),
+                ("slice_order", C.c_int32), ("block_max", C.c_int32)]
+
+
 class Query(C.Structure):
     _fields_ = [("n_terms", C.c_uint32), ("term_ids", C.c_void_p), ("weights", C.c_void_p)]
 
@@ -82,6 +93,10 @@ def load():
     sigs = {
         "slg_abi_version": (u32, []),
         "slg_last_error": (C.c_char_p, []),
+        "slg_last_error_code": (i32, []),
+        "slg_tuning_default": (None, [vp]),
+        "slg_index_create_tuned": (vp, [vp, u32, i32, vp]),
+        "slg_index_get_tuning": (i32, [vp, vp]),
         "slg_device_count": (i32, []),
         "slg_index_create": (vp, [vp, u32, i32]),
         "slg_index_destroy": (None, [vp]),
@@ -121,6 +136,17 @@ def load():
 
 def last_error() -> str:
     return load().slg_last_error().decode("utf-8", "replace")
+
+
+def last_error_code() -> int:
+    return int(load().slg_last_error_code())
+
+
+def default_tuning() -> Tuning:
+    """Defaults + SLG_* environment overrides (slg_tuning_default)."""
+    t = Tuning()
+    load().slg_tuning_default(C.addressof(t))
+    return t
 
 
 def check(rc: int) -> None:

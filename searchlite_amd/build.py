@@ -18,7 +18,6 @@ LIBDIR = os.path.join(_HERE, "lib")
 GPU_LIB = os.path.join(LIBDIR, "libsearchlite_gpu.so")
 CORPUS_LIB = os.path.join(LIBDIR, "libslg_corpus.so")
 
-GPU_SOURCES = ["slg_api.hip", "slg_score_inst.hip", "slg_kernels.hpp", "slg_rerank.hpp", "slg_score.hpp", "slg_score_uni.hpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off",  # f32 ops rounded one by one, as the Rust reference does
                "-Wall", "-Wno-unused-function"]
@@ -41,22 +40,21 @@ def _hipcc() -> str:
 SCORE_KREGS = (1, 2, 4, 8, 16)
 
 
-def build_gpu(force: bool = False, verbose: bool = False, stamps: bool = False, ablate: int = 0) -> str:
+def build_gpu(force: bool = False, verbose: bool = False, stamps: bool = False, defines=(), tag: str = "") -> str:
     """hipcc every translation unit for gfx950 (score-kernel variants in parallel), then link.
     stamps=True builds the diagnostic library with in-kernel s_memtime stamps (tools/stamps.py);
-    ablate=N builds libsearchlite_gpu_ablN.so with phases of the uniform kernel compiled out
-    (tools/ablate.py: timing only, results are wrong)."""
+    defines/tag build an experiment library libsearchlite_gpu_<tag>.so with extra -D flags."""
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIBDIR, exist_ok=True)
-    tag = "stamps" if stamps else (f"abl{ablate}" if ablate else "")
+    tag = "stamps" if stamps else tag
     objdir = os.path.join(LIBDIR, f"obj_{tag}" if tag else "obj")
     out_lib = os.path.join(LIBDIR, f"libsearchlite_gpu_{tag}.so") if tag else GPU_LIB
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in ("slg_kernels.hpp", "slg_rerank.hpp", "slg_score.hpp", "slg_score_uni.hpp", "slg_score_multi.hpp")]
     hdrs.append(os.path.join(_HERE, "..", "include", "searchlite_gpu.h"))
     compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"] + (["-DSLG_STAMPS"] if stamps else []) \
-        + ([f"-DSLG_ABL={ablate}"] if ablate else [])
-    kregs = (1,) if (stamps or ablate) else SCORE_KREGS
+        + [f"-D{d}" for d in defines]
+    kregs = (1,) if stamps else SCORE_KREGS
     jobs = [(os.path.join(CSRC, "slg_api.hip"), os.path.join(objdir, "slg_api.o"), [])]
     for kr in kregs:
         jobs.append((os.path.join(CSRC, "slg_score_inst.hip"),
@@ -75,8 +73,6 @@ def build_gpu(force: bool = False, verbose: bool = False, stamps: bool = False, 
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
         rebuilt = list(ex.map(compile_one, jobs))
     objs = [j[1] for j in jobs]
-    if ablate:  # only the k <= 64 instantiation is rebuilt; the others come from the main build
-        objs += [os.path.join(LIBDIR, "obj", f"slg_score_k{kr}.o") for kr in SCORE_KREGS if kr != 1]
     if force or any(rebuilt) or _newer(out_lib, objs):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out_lib, *objs]
         if verbose:

@@ -31,6 +31,7 @@
 namespace {
 
 thread_local std::string g_last_error;
+thread_local int g_last_code = SLG_OK;
 
 struct SlgError : std::runtime_error {
   int code;
@@ -55,27 +56,35 @@ template <typename F>
 int guarded(F &&f) {
   try {
     g_last_error.clear();
+    g_last_code = SLG_OK;
     f();
     return SLG_OK;
   } catch (const SlgError &e) {
     g_last_error = e.what();
-    return e.code;
+    g_last_code = e.code;
   } catch (const std::bad_alloc &) {
     g_last_error = "host allocation failed";
-    return SLG_ERR_OOM;
+    g_last_code = SLG_ERR_OOM;
   } catch (const std::exception &e) {
     g_last_error = e.what();
-    return SLG_ERR_INTERNAL;
+    g_last_code = SLG_ERR_INTERNAL;
   } catch (...) {
     g_last_error = "unknown error";
-    return SLG_ERR_INTERNAL;
+    g_last_code = SLG_ERR_INTERNAL;
   }
+  return g_last_code;
 }
 
+// (the environment is read in slg_tuning_default() only)
 uint32_t env_u32(const char *name, uint32_t dflt) {
   const char *v = std::getenv(name);
   if (!v || !*v) return dflt;
   return (uint32_t)std::strtoul(v, nullptr, 10);
+}
+int32_t env_i32(const char *name, int32_t dflt) {
+  const char *v = std::getenv(name);
+  if (!v || !*v) return dflt;
+  return (int32_t)std::strtol(v, nullptr, 10);
 }
 
 // Freed batch buffers are kept for the next batch: hipMalloc / hipFree cost ~100 us each and
@@ -183,6 +192,8 @@ struct SegHost {
 
 struct slg_index {
   BufPool pool;  // work buffers of finished batches (declared first: destroyed last)
+  slg_tuning tune{};
+  std::vector<slg_batch *> live;  // batches prepared on this index and not yet destroyed (under mu)
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
@@ -230,6 +241,7 @@ struct slg_batch {
   uint32_t *d_out_doc = nullptr, *d_out_seg = nullptr, *d_out_count = nullptr;
   float *d_out_score = nullptr;
   DevBuf d_stamps;  // SLG_STAMPS diagnostic builds
+  DevBuf d_blk_skip;  // block-max pruning: per (sub-query, list) skip flags of 128-posting blocks
 };
 
 namespace {
@@ -257,30 +269,30 @@ int kregs_for(uint32_t k) {
 namespace slg {
 // defined in slg_score_inst.hip, one translation unit per KREGS
 template <int KREGS>
-void launch_score_kregs(const RoundScoreParams &sp, uint32_t max_terms, int kind, hipStream_t st);
-template <> void launch_score_kregs<1>(const RoundScoreParams &, uint32_t, int, hipStream_t);
-template <> void launch_score_kregs<2>(const RoundScoreParams &, uint32_t, int, hipStream_t);
-template <> void launch_score_kregs<4>(const RoundScoreParams &, uint32_t, int, hipStream_t);
-template <> void launch_score_kregs<8>(const RoundScoreParams &, uint32_t, int, hipStream_t);
-template <> void launch_score_kregs<16>(const RoundScoreParams &, uint32_t, int, hipStream_t);
+void launch_score_kregs(const RoundScoreParams &sp, int kind, hipStream_t st);
+template <> void launch_score_kregs<1>(const RoundScoreParams &, int, hipStream_t);
+template <> void launch_score_kregs<2>(const RoundScoreParams &, int, hipStream_t);
+template <> void launch_score_kregs<4>(const RoundScoreParams &, int, hipStream_t);
+template <> void launch_score_kregs<8>(const RoundScoreParams &, int, hipStream_t);
+template <> void launch_score_kregs<16>(const RoundScoreParams &, int, hipStream_t);
 }  // namespace slg
 namespace {
 
-// kind: 0 packed (slg_score.hpp), 1 uniform (slg_score_uni.hpp), 2 multi (slg_score_multi.hpp),
-// 3 multi with MaxScore-classified lists
-void launch_score(const slg::RoundScoreParams &sp, uint32_t max_terms, int kind, hipStream_t st) {
+// kind: 1 few-term kernel (slg_score_uni.hpp), 2 many-term kernel (slg_score_multi.hpp),
+// 3 many-term kernel with pruning-classified lists
+void launch_score(const slg::RoundScoreParams &sp, int kind, hipStream_t st) {
 #ifdef SLG_STAMPS  // diagnostic build: only the k <= 64 variant is compiled
   if (kregs_for(sp.k) != 1) throw SlgError(SLG_ERR_UNSUPPORTED, "stamps build supports k <= 64 only");
-  slg::launch_score_kregs<1>(sp, max_terms, kind, st);
+  slg::launch_score_kregs<1>(sp, kind, st);
   SLG_HIP(hipGetLastError());
   return;
 #else
   switch (kregs_for(sp.k)) {
-    case 1: slg::launch_score_kregs<1>(sp, max_terms, kind, st); break;
-    case 2: slg::launch_score_kregs<2>(sp, max_terms, kind, st); break;
-    case 4: slg::launch_score_kregs<4>(sp, max_terms, kind, st); break;
-    case 8: slg::launch_score_kregs<8>(sp, max_terms, kind, st); break;
-    default: slg::launch_score_kregs<16>(sp, max_terms, kind, st); break;
+    case 1: slg::launch_score_kregs<1>(sp, kind, st); break;
+    case 2: slg::launch_score_kregs<2>(sp, kind, st); break;
+    case 4: slg::launch_score_kregs<4>(sp, kind, st); break;
+    case 8: slg::launch_score_kregs<8>(sp, kind, st); break;
+    default: slg::launch_score_kregs<16>(sp, kind, st); break;
   }
   SLG_HIP(hipGetLastError());
 #endif
@@ -318,25 +330,30 @@ void launch_shard_merge(const slg::ShardMergeParams &mp, hipStream_t st) {
   SLG_HIP(hipGetLastError());
 }
 
-void validate_segment(const slg_segment_desc &d, uint32_t si) {
+void validate_segment(const slg_segment_desc &d, uint32_t si, bool deep) {
   const std::string pfx = "segment " + std::to_string(si) + ": ";
   SLG_REQUIRE(d.term_offsets != nullptr, pfx + "term_offsets is NULL");
   SLG_REQUIRE(d.n_fields >= 1 && d.field_avgdl && d.field_doc_len, pfx + "field arrays missing");
   SLG_REQUIRE(d.term_offsets[0] == 0, pfx + "term_offsets[0] != 0");
   const uint64_t P = d.term_offsets[d.n_terms];
   SLG_REQUIRE(P == 0 || (d.doc_ids && d.tfs), pfx + "doc_ids/tfs missing");
-  const bool deep = env_u32("SLG_VALIDATE", 1) != 0;
   for (uint32_t t = 0; t < d.n_terms; t++) {
     const uint64_t a = d.term_offsets[t], b = d.term_offsets[t + 1];
     SLG_REQUIRE(b >= a, pfx + "term_offsets not monotone");
     SLG_REQUIRE(b - a <= 0xFFFFFFFEull, pfx + "posting list too long");
     if (d.term_field) SLG_REQUIRE(d.term_field[t] < d.n_fields, pfx + "term_field out of range");
+    // The kernels index per-doc bitmaps with the raw doc id and the planner interpolates on
+    // doc / n_docs, so ids must be < n_docs: checked on every posting, or (validate == 0, where
+    // the caller vouches for increasing ids) on the last = largest posting of each list.
     if (deep) {
       for (uint64_t i = a; i < b; i++) {
-        SLG_REQUIRE(d.doc_ids[i] != 0xFFFFFFFFu, pfx + "doc id u32::MAX is reserved");
+        SLG_REQUIRE(d.doc_ids[i] < d.n_docs,
+                    pfx + "doc id >= n_docs in term " + std::to_string(t));
         SLG_REQUIRE(i == a || d.doc_ids[i] > d.doc_ids[i - 1],
                     pfx + "doc ids not strictly increasing in term " + std::to_string(t));
       }
+    } else if (b > a) {
+      SLG_REQUIRE(d.doc_ids[b - 1] < d.n_docs, pfx + "doc id >= n_docs in term " + std::to_string(t));
     }
   }
   if (d.vec_dim) {
@@ -433,7 +450,7 @@ void stage_segment(slg_index *ix, SegHost &sh, const slg_segment_desc &d) {
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(want, 256ull * 32);
     hipLaunchKernelGGL(slg::stage_impacts_kernel, dim3(blocks), dim3(256), 0, st, sp);
     SLG_HIP(hipGetLastError());
-    if (env_u32("SLG_NO_CHAMPIONS", 0) == 0) {
+    if (ix->tune.champions) {
       sh.d_champ.alloc((size_t)d.n_terms * slg::kChampions * 4);
       ix->device_bytes += sh.d_champ.bytes;
       slg::ChampParams cp{};
@@ -483,6 +500,7 @@ extern "C" {
 uint32_t slg_abi_version(void) { return SLG_ABI_VERSION; }
 
 const char *slg_last_error(void) { return g_last_error.c_str(); }
+int slg_last_error_code(void) { return g_last_code; }
 
 int slg_device_count(void) {
   int n = 0;
@@ -494,21 +512,57 @@ int slg_device_count(void) {
   return n;
 }
 
+void slg_tuning_default(slg_tuning *t) {
+  if (!t) return;
+  std::memset(t, 0, sizeof(*t));
+  t->struct_size = (uint32_t)sizeof(slg_tuning);
+  t->validate = env_i32("SLG_VALIDATE", 1) != 0;
+  t->champions = env_i32("SLG_NO_CHAMPIONS", 0) == 0;
+  t->allow_any_arch = env_i32("SLG_ALLOW_ANY_ARCH", 0) != 0;
+  t->pruning = env_i32("SLG_MAXSCORE", -1);
+  t->uniform_max_terms = env_u32("SLG_UNIFORM_MAX_TERMS", 4);
+  t->uniform_round_target = env_u32("SLG_UNIFORM_ROUND_TARGET", 0);
+  t->multi_round_target = env_u32("SLG_MULTI_ROUND_TARGET", slg::kMultiTarget);
+  t->probe_target = env_u32("SLG_PROBE_TARGET", 2048);
+  t->rounds_per_slice = env_u32("SLG_ROUNDS_PER_SLICE", 0);
+  t->max_rounds_per_slice = env_u32("SLG_MAX_ROUNDS_PER_SLICE", slg::kMaxRoundsPerSlice);
+  t->slices_per_subquery = env_u32("SLG_SLICES_PER_SUBQUERY", 16);
+  t->cand_mode = env_i32("SLG_NO_CAND_MODE", 0) == 0;
+  t->slice_order = env_i32("SLG_NO_SLICE_ORDER", 0) == 0;
+  t->block_max = env_i32("SLG_NO_BLOCK_MAX", 0) == 0;
+}
+
 slg_index *slg_index_create(const slg_segment_desc *segs, uint32_t n_segs, int device) {
+  return slg_index_create_tuned(segs, n_segs, device, nullptr);
+}
+
+slg_index *slg_index_create_tuned(const slg_segment_desc *segs, uint32_t n_segs, int device,
+                                  const slg_tuning *tuning) {
   slg_index *ix = nullptr;
   int rc = guarded([&] {
     SLG_REQUIRE(segs != nullptr && n_segs >= 1, "segs is NULL or n_segs == 0");
-    for (uint32_t s = 0; s < n_segs; s++) validate_segment(segs[s], s);
+    slg_tuning tune;
+    if (tuning) {
+      SLG_REQUIRE(tuning->struct_size == sizeof(slg_tuning), "slg_tuning.struct_size mismatch");
+      tune = *tuning;
+    } else {
+      slg_tuning_default(&tune);
+    }
+    tune.uniform_max_terms = std::min<uint32_t>(tune.uniform_max_terms, slg::kUniMaxLists);
+    tune.max_rounds_per_slice = std::max<uint32_t>(1, std::min<uint32_t>(tune.max_rounds_per_slice, slg::kMaxRoundsPerSlice));
+    tune.slices_per_subquery = std::max<uint32_t>(1, tune.slices_per_subquery);
+    for (uint32_t s = 0; s < n_segs; s++) validate_segment(segs[s], s, tune.validate != 0);
     int ndev = 0;
     SLG_HIP(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev)
       throw SlgError(SLG_ERR_DEVICE, "no such HIP device " + std::to_string(device));
     ix = new slg_index();
+    ix->tune = tune;
     ix->device = device;
     DeviceGuard g(device);
     hipDeviceProp_t prop;
     SLG_HIP(hipGetDeviceProperties(&prop, device));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && env_u32("SLG_ALLOW_ANY_ARCH", 0) == 0)
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !tune.allow_any_arch)
       throw SlgError(SLG_ERR_DEVICE,
                      std::string("device is ") + prop.gcnArchName + ", this library targets gfx950");
     SLG_HIP(hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking));
@@ -540,20 +594,45 @@ slg_index *slg_index_create(const slg_segment_desc *segs, uint32_t n_segs, int d
                       hipMemcpyHostToDevice));
   });
   if (rc != SLG_OK) {
-    std::string keep = g_last_error;
+    const std::string keep = g_last_error;
     if (ix) slg_index_destroy(ix);
     g_last_error = keep;
+    g_last_code = rc;
     return nullptr;
   }
   return ix;
 }
+
+namespace {
+// free everything a batch holds on the device; with `to_pool` false the blocks go straight back
+// to the runtime (the index and its pool are going away)
+void release_batch_buffers(slg_batch *b, bool to_pool) {
+  DevBuf *bufs[] = {&b->d_desc, &b->d_bounds, &b->d_rdoc, &b->d_slice_tk, &b->d_slice_doc,
+                    &b->d_q_scored, &b->d_q_filter, &b->d_cand, &b->d_slice_cbeg, &b->d_slice_ccnt,
+                    &b->d_out, &b->d_stamps, &b->d_blk_skip};
+  for (DevBuf *d : bufs) {
+    if (!to_pool) d->pool = nullptr;
+    d->release();
+  }
+}
+}  // namespace
 
 void slg_index_destroy(slg_index *ix) {
   if (!ix) return;
   int prev = -1;
   (void)hipGetDevice(&prev);
   (void)hipSetDevice(ix->device);
-  if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+  (void)hipDeviceSynchronize();  // batches may run on streams of their own
+  {
+    // batches that outlive the index are detached: buffers freed, handle stays valid for
+    // slg_batch_destroy, every other call on it fails with SLG_ERR_INVALID
+    std::lock_guard<std::mutex> lk(ix->mu);
+    for (slg_batch *b : ix->live) {
+      release_batch_buffers(b, false);
+      b->idx = nullptr;
+    }
+    ix->live.clear();
+  }
   for (auto &pr : ix->prof_events) {
     (void)hipEventDestroy(pr.first);
     (void)hipEventDestroy(pr.second);
@@ -564,6 +643,13 @@ void slg_index_destroy(slg_index *ix) {
   if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
   delete ix;
   if (prev >= 0) (void)hipSetDevice(prev);
+}
+
+int slg_index_get_tuning(const slg_index *ix, slg_tuning *out) {
+  return guarded([&] {
+    SLG_REQUIRE(ix != nullptr && out != nullptr, "index or out is NULL");
+    *out = ix->tune;
+  });
 }
 
 int slg_index_info(const slg_index *ix, uint32_t *n_segs, uint64_t *n_postings,
@@ -732,10 +818,8 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     uint32_t batch_max_nt = 0;
     for (uint32_t q = 0; q < nq; q++)
       if (q_offsets[q + 1] >= q_offsets[q]) batch_max_nt = std::max(batch_max_nt, q_offsets[q + 1] - q_offsets[q]);
-    const char *ms_env = getenv("SLG_MAXSCORE");
-    const bool maxscore_on = ms_env ? atoi(ms_env) != 0
-                                    : (batch_max_nt > env_u32("SLG_UNIFORM_MAX_TERMS", 4) &&
-                                       env_u32("SLG_NO_MULTI", 0) == 0 && env_u32("SLG_NO_UNIFORM", 0) == 0);
+    const slg_tuning &tn = ix->tune;
+    const bool maxscore_on = tn.pruning >= 0 ? tn.pruning != 0 : batch_max_nt > tn.uniform_max_terms;
     // Score plans run on the multi kernel only, which has no MaxScore path: if any query of the
     // batch can need a plan (a DisMax, or two terms sharing a leaf), nothing is classified.
     bool plans_requested = false;
@@ -770,9 +854,16 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
       SLG_REQUIRE(plan_kind == SLG_PLAN_SUM || plan_kind == SLG_PLAN_DISMAX,
                   "unknown score plan in query " + std::to_string(q));
       const float tie = q_tie ? q_tie[q] : 0.0f;
-      SLG_REQUIRE(std::isfinite(tie), "non-finite tie breaker in query " + std::to_string(q));
+      // validate_tie_breaker (query/planner.rs:850-856); the threshold seed and the pruning bounds
+      // also rely on it: with tie in [0, 1] a DisMax is >= each of its non-negative leaves
+      SLG_REQUIRE(tie >= 0.0f && tie <= 1.0f,
+                  "tie breaker outside [0, 1] in query " + std::to_string(q));
       uint32_t n_leaves = q_nleaves ? q_nleaves[q] : 0;
-      for (uint32_t i = 0; i < nt; i++) n_leaves = std::max(n_leaves, (q_leaf ? q_leaf[t0 + i] : i) + 1u);
+      for (uint32_t i = 0; i < nt; i++) {
+        const uint32_t lf = q_leaf ? q_leaf[t0 + i] : i;
+        SLG_REQUIRE(lf < 0x80000000u, "leaf index >= 2^31 in query " + std::to_string(q));
+        n_leaves = std::max(n_leaves, lf + 1u);
+      }
       if (k == 0) continue;  // wand.rs:413-416: k == 0 and no collector => no work
       for (uint32_t s = 0; s < n_segs; s++) {
         const SegHost &sh = *ix->segs[s];
@@ -883,22 +974,19 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     }
     q_sq_begin[nq] = (uint32_t)sqs.size();
 
-    // ---- pass 2: rounds of ~kRoundTarget postings, slices of consecutive rounds ----
-    const uint32_t round_target_packed = std::max<uint32_t>(64, std::min<uint32_t>(
-        env_u32("SLG_ROUND_TARGET", slg::kRoundTarget), slg::kCap));
-    const uint32_t probe_target = std::max<uint32_t>(round_target_packed, env_u32("SLG_PROBE_TARGET", 2048));
+    // ---- pass 2: rounds of about one register set of postings, slices of consecutive rounds ----
+    const uint32_t probe_target = std::max<uint32_t>(slg::kMultiCap, tn.probe_target);
     std::vector<uint32_t> slice_sq, slice_seg, bnd_sq;
     uint64_t n_bounds = 0, n_bnd = 0;
     // one-list-per-slot kernel (slg_score_uni.hpp): few terms, no non-essential lists
-    const uint32_t uni_max_terms = std::min<uint32_t>(env_u32("SLG_UNIFORM_MAX_TERMS", 4), slg::kUniSlots);
-    b->uniform = env_u32("SLG_NO_UNIFORM", 0) == 0 && b->max_terms <= uni_max_terms && !any_plan;
+    b->uniform = b->max_terms <= tn.uniform_max_terms && !any_plan;
     for (size_t i = 0; i < sqs.size() && b->uniform; i++) {
       const uint32_t full = sqs[i].n_terms >= 32 ? 0xFFFFFFFFu : ((1u << sqs[i].n_terms) - 1u);
       if (sqs[i].ess_mask != full) b->uniform = false;
     }
     // more terms (the multi-field shape): the same slots-of-one-list design, 8 slots at a time
     // (the multi kernel also runs MaxScore-classified batches: non-essential lists are only probed)
-    b->multi = !b->uniform && ((env_u32("SLG_NO_MULTI", 0) == 0 && env_u32("SLG_NO_UNIFORM", 0) == 0) || any_plan);
+    b->multi = !b->uniform;
     b->plan_batch = any_plan;
     for (size_t i = 0; i < sqs.size(); i++) {
       const uint32_t full = sqs[i].n_terms >= 32 ? 0xFFFFFFFFu : ((1u << sqs[i].n_terms) - 1u);
@@ -908,28 +996,26 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     // ~5 generations of waves per SIMD on config 2).  The uniform kernel's slices are cheap to
     // start (threshold seed + buffered top-k) as long as k is small: every slice writes k
     // candidates for the merge (measured: config 2 k=11 best at 4, config 3 k=101 best at 8).
+    const bool rps_pinned = tn.rounds_per_slice != 0;
     const uint32_t max_rps = std::max<uint32_t>(1, std::min<uint32_t>(
-        env_u32("SLG_ROUNDS_PER_SLICE", b->uniform && k <= 64 ? slg::kUniRoundsPerSlice
-                                                               : slg::kDefaultRoundsPerSlice),
+        rps_pinned ? tn.rounds_per_slice
+                   : (b->uniform && k <= 64 ? slg::kUniRoundsPerSlice : slg::kDefaultRoundsPerSlice),
         slg::kMaxRoundsPerSlice));
-    const bool rps_pinned = getenv("SLG_ROUNDS_PER_SLICE") != nullptr;
-    const uint32_t rps_cap = std::max<uint32_t>(max_rps, std::min<uint32_t>(
-        env_u32("SLG_MAX_ROUNDS_PER_SLICE", slg::kMaxRoundsPerSlice), slg::kMaxRoundsPerSlice));
-    const uint32_t slices_per_sq = std::max<uint32_t>(1, env_u32("SLG_SLICES_PER_SUBQUERY", 16));
+    const uint32_t rps_cap = std::max<uint32_t>(max_rps, tn.max_rounds_per_slice);
+    const uint32_t slices_per_sq = tn.slices_per_subquery;
     for (size_t i = 0; i < sqs.size(); i++) {
       slg::RoundQuery &sq = sqs[i];
       const uint32_t dfL = terms[sq.term_begin + sq.longest].df;
-      uint32_t round_target = round_target_packed;
+      uint32_t round_target;
       if (b->uniform) {
         // every list is padded to a 64-lane slot (half a slot wasted per list on average): aim
         // at (slots - terms + 1) slots of postings; measured optimum on config 2 (384 for 3 terms)
         const uint32_t t = sq.n_terms;
         const uint32_t dflt = 64u * (slg::kUniSlots > t ? slg::kUniSlots - t : 0u) + 64u;
         round_target = std::max<uint32_t>(48, std::min<uint32_t>(
-            env_u32("SLG_UNIFORM_ROUND_TARGET", dflt), slg::kUniCap));
-      } else if (b->multi) {
-        round_target = std::max<uint32_t>(64, std::min<uint32_t>(
-            env_u32("SLG_MULTI_ROUND_TARGET", slg::kMultiTarget), slg::kMultiCap));
+            tn.uniform_round_target ? tn.uniform_round_target : dflt, slg::kUniCap));
+      } else {
+        round_target = std::max<uint32_t>(64, std::min<uint32_t>(tn.multi_round_target, slg::kMultiCap));
       }
       // a round holds <= ~round_target postings of the essential lists (register slots) and
       // <= ~probe_target postings overall (non-essential lists are streamed per round), so
@@ -948,8 +1034,7 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
       const uint64_t S = (nr + rps - 1) / rps;
       // (the per-slice candidate lists, n_slices * k entries indexed with 32 bits, exist only for
       //  k <= 256; larger k goes through the candidate array, one slot per posting)
-      const bool slice_lists = !((b->uniform || b->multi) && k > 256 &&
-                                 (k > 1024 || env_u32("SLG_NO_CAND_MODE", 0) == 0));  // == !cand_mode
+      const bool slice_lists = !(k > 256 && (k > 1024 || tn.cand_mode));  // == !cand_mode
       SLG_REQUIRE(nr < 0x7FFFFFFFull && slice_sq.size() + S < 0x7FFFFFFFull &&
                       (!slice_lists ||
                        (slice_sq.size() + S) * (uint64_t)std::max<uint32_t>(k, 1) < 0xFFFFFFFFull),
@@ -971,10 +1056,7 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     }
     // large k: per-slice top-k lists would be mostly the slice itself; keep every doc above the
     // seed threshold instead (one candidate slot per posting) and select per query afterwards
-    b->cand_mode = (b->uniform || b->multi) && k > 256 && (k > 1024 || env_u32("SLG_NO_CAND_MODE", 0) == 0);
-    if (k > 1024 && !b->cand_mode)
-      throw SlgError(SLG_ERR_UNSUPPORTED, "k > 1024 needs the candidate/select path (SLG_MAX_K: not with "
-                                          "SLG_MAXSCORE / SLG_NO_UNIFORM)");
+    b->cand_mode = k > 256 && (k > 1024 || tn.cand_mode);
     uint64_t cand_total = 0;
     if (b->cand_mode)
       for (size_t i = 0; i < sqs.size(); i++) {
@@ -1008,12 +1090,10 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
         }
       }
       for (int i = 1; i <= slg::kMaxRoundsPerSlice + 1; i++) hist[i] += hist[i - 1];
-      const bool lpt = env_u32("SLG_NO_SLICE_ORDER", 0) == 0;
+      const bool lpt = tn.slice_order != 0;
       for (size_t sidx = 0; sidx < slice_sq.size(); sidx++)
         slice_order[lpt ? hist[slg::kMaxRoundsPerSlice - nrounds[sidx]]++ : sidx] = (uint32_t)sidx;
     }
-    if (getenv("SLG_DEBUG_ESS"))  // TEMP
-      fprintf(stderr, "essential postings %llu of %llu\n", (unsigned long long)b->n_postings_essential, (unsigned long long)b->n_postings);
     b->n_sq = (uint32_t)sqs.size();
     b->n_terms = (uint32_t)terms.size();
     b->n_slices = (uint32_t)slice_sq.size();
@@ -1075,19 +1155,28 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     b->d_out_seg = b->d_out_doc + (size_t)nq * k;
     b->d_out_score = reinterpret_cast<float *>(b->d_out_seg + (size_t)nq * k);
     b->d_out_count = b->d_out_seg + (size_t)nq * k * 2;
+    {
+      std::lock_guard<std::mutex> lk(ix->mu);
+      ix->live.push_back(b);
+    }
   });
   if (rc != SLG_OK) {
-    std::string keep = g_last_error;
+    const std::string keep = g_last_error;
+    const int keep_code = g_last_code;
     delete b;
     g_last_error = keep;
+    g_last_code = keep_code;
     return nullptr;
   }
   return b;
 }
 
+#define SLG_REQUIRE_LIVE(b) \
+  SLG_REQUIRE((b) != nullptr && (b)->idx != nullptr, "batch is NULL or its index was destroyed")
+
 int slg_batch_run(slg_batch *b) {
   return guarded([&] {
-    SLG_REQUIRE(b != nullptr, "batch is NULL");
+    SLG_REQUIRE_LIVE(b);
     slg_index *ix = b->idx;
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
@@ -1129,7 +1218,6 @@ int slg_batch_run(slg_batch *b) {
       sp.q_scored = b->d_q_scored.as<uint32_t>();
       sp.n_slices = b->n_slices;
       sp.k = b->k;
-      sp.dbg = env_u32("SLG_DEBUG_FLAGS", 0);
       sp.stamps = nullptr;
 #ifdef SLG_STAMPS
       b->d_stamps.alloc((size_t)b->n_slices * 64);
@@ -1146,7 +1234,7 @@ int slg_batch_run(slg_batch *b) {
         ev = &ix->prof_events[ix->prof_used++];
         SLG_HIP(hipEventRecord(ev->first, st));
       }
-      launch_score(sp, b->max_terms, b->uniform ? 1 : (b->multi ? (b->pruned ? 3 : 2) : 0), st);
+      launch_score(sp, b->uniform ? 1 : (b->pruned ? 3 : 2), st);
       if (ev) SLG_HIP(hipEventRecord(ev->second, st));
     }
     if (b->k > 0 && b->cand_mode && b->n_slices > 0) {
@@ -1189,7 +1277,7 @@ int slg_batch_run(slg_batch *b) {
 
 int slg_batch_sync(slg_batch *b) {
   return guarded([&] {
-    SLG_REQUIRE(b != nullptr, "batch is NULL");
+    SLG_REQUIRE_LIVE(b);
     DeviceGuard g(b->idx->device);
     SLG_HIP(hipStreamSynchronize(batch_stream(b)));
   });
@@ -1198,7 +1286,7 @@ int slg_batch_sync(slg_batch *b) {
 int slg_batch_fetch(slg_batch *b, uint32_t *out_doc, uint32_t *out_seg, float *out_score,
                     uint32_t *out_count, slg_stats *stats) {
   return guarded([&] {
-    SLG_REQUIRE(b != nullptr, "batch is NULL");
+    SLG_REQUIRE_LIVE(b);
     SLG_REQUIRE(b->nq == 0 || (out_count != nullptr), "out_count is NULL");
     SLG_REQUIRE(b->nq == 0 || b->k == 0 || (out_doc && out_seg && out_score), "output array is NULL");
     slg_index *ix = b->idx;
@@ -1240,7 +1328,7 @@ int slg_batch_fetch(slg_batch *b, uint32_t *out_doc, uint32_t *out_seg, float *o
 int slg_batch_device_results(slg_batch *b, void **d_doc, void **d_seg, void **d_score,
                              void **d_count) {
   return guarded([&] {
-    SLG_REQUIRE(b != nullptr, "batch is NULL");
+    SLG_REQUIRE_LIVE(b);
     if (d_doc) *d_doc = b->d_out_doc;
     if (d_seg) *d_seg = b->d_out_seg;
     if (d_score) *d_score = b->d_out_score;
@@ -1250,7 +1338,7 @@ int slg_batch_device_results(slg_batch *b, void **d_doc, void **d_seg, void **d_
 
 int slg_batch_device_result_block(slg_batch *b, void **d_block, uint64_t *n_bytes) {
   return guarded([&] {
-    SLG_REQUIRE(b != nullptr, "batch is NULL");
+    SLG_REQUIRE_LIVE(b);
     if (d_block) *d_block = b->d_out.p;
     if (n_bytes) *n_bytes = ((uint64_t)b->nq * b->k * 3 + b->nq) * 4;
   });
@@ -1277,7 +1365,7 @@ int slg_debug_read_stamps(slg_batch *b, unsigned long long *out, uint32_t n_slic
 
 int slg_batch_set_stream(slg_batch *b, void *hip_stream) {
   return guarded([&] {
-    SLG_REQUIRE(b != nullptr, "batch is NULL");
+    SLG_REQUIRE_LIVE(b);
     slg_index *ix = b->idx;
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
@@ -1289,10 +1377,25 @@ int slg_batch_set_stream(slg_batch *b, void *hip_stream) {
 
 void slg_batch_destroy(slg_batch *b) {
   if (!b) return;
+  slg_index *ix = b->idx;
+  if (!ix) {  // detached by slg_index_destroy: nothing left on the device
+    delete b;
+    return;
+  }
   int prev = -1;
   (void)hipGetDevice(&prev);
-  (void)hipSetDevice(b->idx->device);
-  (void)hipStreamSynchronize(batch_stream(b));
+  (void)hipSetDevice(ix->device);
+  hipStream_t st;
+  {
+    std::lock_guard<std::mutex> lk(ix->mu);
+    st = batch_stream(b);
+    auto it = std::find(ix->live.begin(), ix->live.end(), b);
+    if (it != ix->live.end()) {
+      *it = ix->live.back();
+      ix->live.pop_back();
+    }
+  }
+  (void)hipStreamSynchronize(st);
   delete b;
   if (prev >= 0) (void)hipSetDevice(prev);
 }
@@ -1328,18 +1431,13 @@ int slg_search_batch_filtered(slg_index *ix, const slg_query *queries, uint32_t 
   });
   if (rc != SLG_OK) return rc;
   b = slg_batch_prepare_filtered(ix, nq, offs.data(), tids.data(), ws.data(), q_filter, k, strategy);
-  if (!b) {
-    // slg_batch_prepare already set the thread-local error; map it back to a code
-    return g_last_error.find("SLG_MAX") != std::string::npos ||
-                   g_last_error.find("more than") != std::string::npos
-               ? SLG_ERR_UNSUPPORTED
-               : SLG_ERR_INVALID;
-  }
+  if (!b) return g_last_code;  // slg_batch_prepare set the thread-local error and its code
   rc = slg_batch_run(b);
   if (rc == SLG_OK) rc = slg_batch_fetch(b, out_doc, out_seg, out_score, out_count, stats);
-  std::string keep = g_last_error;
+  const std::string keep = g_last_error;
   slg_batch_destroy(b);
   g_last_error = keep;
+  g_last_code = rc;
   return rc;
 }
 

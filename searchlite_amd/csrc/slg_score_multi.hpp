@@ -188,7 +188,6 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
     }
     uint32_t dlo = rfl(grdoc[rr]);
     const uint32_t rdhi = rfl(grdoc[rr + 1]);
-    if (p.dbg & 4u) continue;
 
     for (uint32_t guard = 0; guard < (1u << 22); guard++) {  // chunks of the round (usually one)
       const uint32_t rem = end - cur;

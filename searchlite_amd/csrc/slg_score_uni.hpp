@@ -1,18 +1,36 @@
-// slg_score_uni.hpp — the hot kernel for queries with few terms (the host uses it up to 4 lists;
-// BASELINE config 2): exact pre-planned rounds, LDS bitmap-rank accumulate, buffered top-k, and
-// every 64-lane register slot holds postings of ONE list.
+// slg_score_uni.hpp — the hot kernel for queries with few terms (<= 4 lists per sub-query;
+// BASELINE config 2): exact pre-planned rounds, every 64-lane register slot holds postings of ONE
+// list, and a FILTER + JOIN accumulate that keeps docs found in a single list entirely in
+// registers.
+//
+// Restates query/wand.rs:459-566 (every posting scored, per-doc sums in ScorePlan leaf order,
+// planner.rs:122-135) and push_top_k (wand.rs:905-916).  k <= 256: candidates go to a per-wave
+// LDS buffer (BufTopK, slg_kernels.hpp); larger k: to the slice's region of a global candidate
+// array, picked per query by select_topk_kernel.  More lists than 4: slg_score_multi.hpp.
 //
 // Padding each list to a slot boundary makes the per-slot list id, weight, base address and
 // lane count wave-uniform scalars (one v_readlane each from a lane-held slot descriptor; the
-// descriptors of 8 rounds are computed at once), removes the per-lane list selects and the
-// mixed-slot ordering paths of the older packed kernel (slg_score.hpp), and lets the posting
-// loads be whole-slot, scalar base + lane.
+// descriptors of 8 rounds are computed at once) and lets the posting loads be whole-slot,
+// scalar base + lane.
 //
-// Restates query/wand.rs:459-566 (every posting scored, per-doc sums in ScorePlan leaf order,
-// planner.rs:122-135) and push_top_k (wand.rs:905-916); phases P0..P4 are described in
-// DESIGN.md section 4.  k <= 256: candidates go to a per-wave LDS buffer (BufTopK,
-// slg_kernels.hpp); larger k: to the slice's region of a global candidate array, picked per
-// query by select_topk_kernel.  More lists than 4: slg_score_multi.hpp.
+// The accumulate.  With the sparse lists of a real query almost every doc of a round occurs in
+// ONE of its lists (config 2: ~98 % of the postings); such a doc's score is 0.0 + w*impact
+// (`or_insert(0.0) += score`, wand.rs:539) and needs no accumulator at all.  Per round:
+//   P0  clear a 1024-word LDS filter (4 wide stores);
+//   P1  every posting ORs ONE bit (ds_or, no return): word = doc mod 1024, 4-bit field =
+//       (doc / 1024) mod 8, bit = its list (<= 4 lists);
+//   P2  every posting reads its word back: the field names the lists that hold this doc (or a
+//       doc that aliases it — the filter is one-sided: it never misses a shared doc);
+//   P3  postings whose field shows only their own list are SINGLES: scored in registers,
+//       compared with the threshold, (rarely) appended to the top-k buffer;
+//   P4  the others (both the first and the later postings of a shared doc, plus aliases) are
+//       compacted into an LDS queue (it overlays the filter, which is dead by now) in slot =
+//       list order; each queue entry then sums the entries with ITS doc id in queue order:
+//       ((0.0 + x_a) + x_b) + ..., bit for bit the reference's term-order sum; the entry that
+//       comes first for its doc owns the result.  Aliased docs simply find no partner.
+// One round is 3 dependent LDS round trips (the bitmap-rank accumulate it replaces had ~10, and
+// twice the LDS instructions), there are no doc windows (the filter wraps) and no per-posting
+// accumulator traffic.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -20,38 +38,33 @@
 
 #include "slg_score.hpp"
 
-#ifndef SLG_ABL
-#define SLG_ABL 0  // diagnostic builds only (tools/ablate.py): bit i skips a phase; results are wrong
-#endif
-
 namespace slg {
 
-constexpr int kUniSlots = 8;                 // 64-posting slots per round; also max lists
-constexpr int kUniCap = kUniSlots * 64;
-constexpr int kUniWaveLdsBase = kSpanWords * 4 + kSpanWords * 4 + kUniCap * 4 + 64 * 4;
+constexpr int kUniSlots = 8;                 // 64-posting slots per round
+constexpr int kUniCap = kUniSlots * 64;      // postings per round
+constexpr int kUniMaxLists = 4;              // lists per sub-query (one filter bit each)
+constexpr int kJoinWords = 1024;             // filter words = 8192 doc fields; also the join queue
+static_assert(kJoinWords * 4 >= kUniCap * 8, "the join queue (doc, score per posting) overlays the filter");
 // k <= 256 (KREGS <= 4): buffered top-k in LDS (BufTopK); larger k: every doc above the seed
 // threshold goes to the slice's candidate region and select_topk_kernel picks the k best
 constexpr bool uni_buffered(int kregs) { return kregs <= 4; }
 constexpr int uni_wave_lds(int kregs) {
-  return kUniWaveLdsBase + (uni_buffered(kregs) ? 128 * kregs * 8 : 0);
+  return kJoinWords * 4 + (uni_buffered(kregs) ? 128 * kregs * 8 : 0);
 }
 
 template <int KREGS>
-__global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams p) {
+__global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
   constexpr int NS = kUniSlots;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lane = threadIdx.x & 63;
-  const uint32_t wib = threadIdx.x >> 6;
-  const uint32_t widx = rfl(blockIdx.x * (blockDim.x >> 6) + wib);
+  const uint32_t widx = blockIdx.x;
   if (widx >= p.n_slices) return;  // waves are independent: no workgroup barrier anywhere
   const uint32_t slice = rfl(p.slice_order[widx]);
 
   constexpr bool BUF = uni_buffered(KREGS);
-  uint32_t *bm = reinterpret_cast<uint32_t *>(smem + (size_t)wib * uni_wave_lds(KREGS));
-  uint32_t *pre = bm + kSpanWords;
-  uint32_t *vals = pre + kSpanWords;
-  uint4 *bm4 = reinterpret_cast<uint4 *>(bm);
-  uint4 *pre4 = reinterpret_cast<uint4 *>(pre);
+  uint32_t *flt = reinterpret_cast<uint32_t *>(smem);
+  uint4 *flt4 = reinterpret_cast<uint4 *>(smem);
+  uint2 *queue = reinterpret_cast<uint2 *>(smem);  // overlays flt (see P4)
 
   const uint32_t sqi = rfl(p.slice_sq[slice]);
   const RoundQuery s = p.sq[sqi];
@@ -79,14 +92,13 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
     my_term = tr.term;
   }
   const uint32_t my_off_lo = (uint32_t)my_off, my_off_hi = (uint32_t)(my_off >> 32);
-  // all cut points of the slice in one register (lane i: bounds[r0*T + i]); round doc starts
+  // all cut points of the slice in one register (lane i: bounds[r0*T + i])
   const uint32_t bflat = lane < (n_r + 1) * T ? p.bounds[s.bounds_begin + r0 * T + lane] : 0u;
-  const uint32_t dflat = lane <= n_r ? p.rdoc[s.rdoc_begin + r0 + lane] : 0u;
   // lane i = r*T + t: postings of list t in round r
   const uint32_t dcnt = __shfl(bflat, (lane + T) & 63u, 64) - bflat;
 
   BufTopK<BUF ? KREGS : 1> btop;  // k <= 256; for larger k only its threshold is used
-  btop.init(reinterpret_cast<uint64_t *>(vals + kUniCap + 64));
+  btop.init(reinterpret_cast<uint64_t *>(smem + kJoinWords * 4));
   // k > 256: the slice's candidate region starts at (sub-query base) + (postings of all lists
   // before the slice's first round) and can hold one entry per posting of the slice
   uint32_t ccur = 0;
@@ -97,7 +109,10 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
     cbeg = (((uint64_t)rfl(s.cand_hi) << 32) | rfl(s.cand_lo)) + before;
   }
   uint2 *const creg = BUF ? nullptr : p.cand + cbeg;
-  if (sd.champ != nullptr && k <= 1024u && fid == 0) {  // (a filter may reject the champions)  // threshold seed (see slg_score.hpp)
+  // threshold seed: theta0 = max_t w_t * champ[t][rank(k)].  At least k live docs have a single
+  // contribution >= theta0, and a doc's total is >= any one of its (non-negative) contributions,
+  // so nothing below theta0 can reach the top-k.  (A doc filter may reject the champions.)
+  if (sd.champ != nullptr && k <= 1024u && fid == 0) {
     float f = 0.0f;
     if (lane < T && my_w > 0.0f)
       f = my_w * ((const gf32_t)sd.champ)[(size_t)my_term * kChampions + champ_index(k)];
@@ -198,8 +213,8 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
     }
   };
   // ---- dst = the loaded round src, ready to accumulate: lanes beyond each slot's count become
-  //      idle lanes (kDocEnd is never inside a doc window) and the impacts are multiplied by
-  //      the slot's list weight (score_tf, query/wand.rs:285: one scalar per slot) ----
+  //      idle lanes (doc = kDocEnd) and the impacts are multiplied by the slot's list weight
+  //      (score_tf, query/wand.rs:285: one scalar per slot) ----
   auto settle = [&](URound &dst, const URound &src) {
     dst.st = src.st;
     dst.cnt = src.cnt;
@@ -213,146 +228,106 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
     }
   };
 
-  // ---- accumulate the postings of `e` whose docs lie in [wbase, wbase + wspan) ----
-  auto accumulate = [&](URound &e, const uint32_t wbase, const uint32_t wspan) {
-    SLG_STAMP(1);
-    if (SLG_ABL & 32) {
-      n_scored += e.doc[0] & 1u;
-      return;
+  // ---- offer finished (doc, score) pairs of the lanes in `own` to the top-k ----
+  auto offer = [&](const bool own, const float score, const uint32_t doc) {
+    const uint32_t ok = ordered_score(score);
+    const bool ps = own && btop.passes(ok, ~doc);
+    const uint64_t m = __ballot(ps);
+    if (m == 0ull) return;  // the common case: nobody beats the threshold
+#ifdef SLG_STAMPS
+    st_ins += (uint32_t)__popcll(m);
+#endif
+    if constexpr (BUF) {
+      btop.append_checked(ps, ok, ~doc, k, lane, (const uint32_t *)gdel);
+    } else {
+      const uint32_t at = ccur + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      if (ps) creg[at] = make_uint2(ok, doc);
+      ccur += (uint32_t)__popcll(m);
     }
-    // P0: clear the bitmap
-    bm4[lane] = make_uint4(0u, 0u, 0u, 0u);
-    bm4[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
-    wave_fence();
-    // P1: one bit per posting (transposed bitmap: doc d -> word d mod 512, bit d / 512); the
-    // returned old word tells which posting of a doc came first = the owner.  Slots are in
-    // list order and a slot holds one list, so the owner is the first list in term order.
-    uint32_t wi[NS], bit[NS];
-    bool own[NS];
-    {
-      uint32_t oldw[NS];
+  };
+
+  // ---- score the postings of `e` (all docs of a doc range; idle lanes hold kDocEnd) ----
+  auto accumulate = [&](const URound &e) {
+    SLG_STAMP(1);
+    if (T == 1) {  // one list: every posting is its doc's only one
 #pragma unroll
       for (int jj = 0; jj < NS; jj++) {
-        const uint32_t rel = e.doc[jj] - wbase;
-        wi[jj] = (SLG_ABL & 64) ? ((lane * 8u + jj) & (kSpanWords - 1)) : (rel & (kSpanWords - 1));
-        bit[jj] = rel < wspan ? 1u << (rel >> 9) : 0u;  // rel < 16384 => rel >> 9 < 32
-        if (SLG_ABL & 4) {
-          oldw[jj] = 0;
-          bm[wi[jj]] = bit[jj];
-        } else {
-          oldw[jj] = atomicOr(&bm[wi[jj]], bit[jj]);
-        }
+        const bool v = e.doc[jj] != kDocEnd;
+        n_scored += (uint32_t)__popcll(__ballot(v));
+        offer(v, 0.0f + e.imp[jj], e.doc[jj]);
       }
+      return;
+    }
+    // P0: clear the filter
+    flt4[lane] = make_uint4(0u, 0u, 0u, 0u);
+    flt4[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
+    flt4[lane + 128] = make_uint4(0u, 0u, 0u, 0u);
+    flt4[lane + 192] = make_uint4(0u, 0u, 0u, 0u);
+    wave_fence();
+    // P1: one bit per posting: word = doc mod 1024, field = (doc / 1024) mod 8, bit = list
+    uint32_t sh[NS];
 #pragma unroll
-      for (int jj = 0; jj < NS; jj++) own[jj] = (bit[jj] & ~oldw[jj]) != 0u;
+    for (int jj = 0; jj < NS; jj++) {
+      const uint32_t tj = rl(e.st, e.dbase + jj);
+      sh[jj] = ((e.doc[jj] >> 8) & 0x1Cu);  // 4 * field
+      if (e.doc[jj] != kDocEnd) atomicOr(&flt[e.doc[jj] & (kJoinWords - 1)], (1u << tj) << sh[jj]);
     }
     wave_fence();
     SLG_STAMP(2);
-    // P2: exclusive prefix popcount (lane l owns words 4l..4l+3 and 256+4l..256+4l+3)
-    if (!(SLG_ABL & 16)) {
-      const uint4 a = bm4[lane], b = bm4[lane + 64];
-      const uint32_t c0 = __popc(a.x), c1 = c0 + __popc(a.y), c2 = c1 + __popc(a.z),
-                     c3 = c2 + __popc(a.w), c4 = c3 + __popc(b.x), c5 = c4 + __popc(b.y),
-                     c6 = c5 + __popc(b.z), c7 = c6 + __popc(b.w);
-      const uint32_t incl = wave_incl_scan(c7);
-      const uint32_t ex = incl - c7;
-      pre4[lane] = make_uint4(ex, ex + c0, ex + c1, ex + c2);
-      pre4[lane + 64] = make_uint4(ex + c3, ex + c4, ex + c5, ex + c6);
-      n_scored += rl(incl, 63);
-    }
-    wave_fence();
+    // P2: the lists that hold my doc (or an alias of it)
+    uint32_t fin[NS];
+#pragma unroll
+    for (int jj = 0; jj < NS; jj++) fin[jj] = flt[e.doc[jj] & (kJoinWords - 1)];
+    wave_fence();  // the queue below overlays the filter: all reads are issued before its writes
     SLG_STAMP(3);
-    // P3a: rank(doc) = accumulator slot (< kUniCap: a round holds <= kUniCap postings; idle
-    // lanes index at most kUniCap + 31, inside the dump words); x = impact * weight (settle());
-    // owners store 0.0 + x (`or_insert(0.0) += score`, query/wand.rs:539)
-    uint32_t slot[NS];
-    if (SLG_ABL & 8) {
+    // P3 / P4: singles are scored in registers; shared docs (and aliases) are queued
+    uint32_t n = 0;
 #pragma unroll
-      for (int jj = 0; jj < NS; jj++) slot[jj] = wi[jj];
-    } else {
-      uint32_t wd[NS], pf[NS];
-#pragma unroll
-      for (int jj = 0; jj < NS; jj++) {
-        wd[jj] = bm[wi[jj]];
-        pf[jj] = pre[wi[jj]];
+    for (int jj = 0; jj < NS; jj++) {
+      const uint32_t tj = rl(e.st, e.dbase + jj);
+      const bool v = e.doc[jj] != kDocEnd;
+      const bool shared = v && (((fin[jj] >> sh[jj]) & 0xFu) & ~(1u << tj)) != 0u;
+      const uint64_t m = __ballot(shared);
+      if (m != 0ull) {
+        const uint32_t at = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (shared) queue[at] = make_uint2(e.doc[jj], __float_as_uint(e.imp[jj]));
+        n += (uint32_t)__popcll(m);
       }
-#pragma unroll
-      for (int jj = 0; jj < NS; jj++) {
-        slot[jj] = pf[jj] + __popc(wd[jj] & (bit[jj] - 1u));
-        vals[own[jj] ? slot[jj] : kUniCap + lane] = __float_as_uint(0.0f + e.imp[jj]);
-      }
-    }
-    wave_fence();
-    // P3b: later postings of a doc (it was first seen in an earlier list = an earlier slot)
-    // add to the owner's value, slot by slot: a wave's LDS operations execute in program
-    // order and slots are in list order, so the sum is ((0.0 + x_a) + x_b) + ... in term order.
-#pragma unroll
-    for (int jj = 1; jj < NS; jj++) {
-      const bool later = bit[jj] != 0u && !own[jj];
-      if (!(SLG_ABL & 1) && __ballot(later) != 0ull) {
-        const uint32_t old = vals[slot[jj]];
-        vals[later ? slot[jj] : kUniCap + lane] = __float_as_uint(__uint_as_float(old) + e.imp[jj]);
-        wave_fence();
-      }
+      const bool single = v && !shared;
+      n_scored += (uint32_t)__popcll(__ballot(single));
+      offer(single, 0.0f + e.imp[jj], e.doc[jj]);
     }
     wave_fence();
     SLG_STAMP(4);
-    // P4: owners read the finished sums and offer them to the top-k
-    if (SLG_ABL & 2) {
-      n_scored += slot[0] & 1u;
-      return;
-    }
-    uint32_t v[NS];
-#pragma unroll
-    for (int jj = 0; jj < NS; jj++) v[jj] = vals[slot[jj]];
-    if constexpr (BUF) {
-      uint32_t okey[NS];
-      bool pass[NS];
-      bool any = false;
-#pragma unroll
-      for (int jj = 0; jj < NS; jj++) {
-        okey[jj] = ordered_score(__uint_as_float(v[jj]));
-        pass[jj] = own[jj] && btop.passes(((uint64_t)okey[jj] << 32) | (uint32_t)~e.doc[jj]);
-        any = any || pass[jj];
-      }
-      if (__ballot(any) != 0ull) {
-        uint32_t tot = 0;
-#pragma unroll
-        for (int jj = 0; jj < NS; jj++) tot += (uint32_t)__popcll(__ballot(pass[jj]));
-#ifdef SLG_STAMPS
-        st_ins += tot;
-#endif
-        if (btop.count + tot <= btop.kEntries) {  // the common case: everything fits
-#pragma unroll
-          for (int jj = 0; jj < NS; jj++) btop.append(pass[jj], okey[jj], ~e.doc[jj], lane);
-        } else {  // rank-and-trim between slots; one site, slot registers selected at run time
-#pragma unroll 1
-          for (uint32_t it = 0; it < (uint32_t)NS; it++) {
-            uint32_t ok = okey[0], dc = e.doc[0];
-            bool ps = pass[0];
-#pragma unroll
-            for (int j = 1; j < NS; j++) {
-              ok = it == (uint32_t)j ? okey[j] : ok;
-              dc = it == (uint32_t)j ? e.doc[j] : dc;
-              ps = it == (uint32_t)j ? pass[j] : ps;
-            }
-            btop.append_checked(ps && btop.passes(ok, ~dc), ok, ~dc, k, lane, (const uint32_t *)gdel);
-          }
+    // P4: join.  Queue order = slot order = list order, so summing the entries of my doc in
+    // queue order gives ((0.0 + x_a) + x_b) + ... in term order; the first entry of a doc owns it.
+    for (uint32_t base = 0; base < n; base += 64) {
+      const uint32_t idx = base + lane;
+      const bool have = idx < n;
+      const uint2 me = have ? queue[idx] : make_uint2(kDocEnd, 0u);
+      float acc = 0.0f;
+      bool earlier = false;
+      if (n <= 64u) {  // the usual case: the senders come from registers
+        for (uint32_t l = 0; l < n; l++) {
+          const uint32_t dl = rl(me.x, l);
+          const float xl = __uint_as_float(rl(me.y, l));
+          const bool hit = dl == me.x;
+          acc = hit ? acc + xl : acc;
+          earlier = earlier || (hit && l < lane);
+        }
+      } else {
+        for (uint32_t l = 0; l < n; l++) {
+          const uint2 sn = queue[l];  // same address in every lane: an LDS broadcast
+          const bool hit = sn.x == me.x;
+          acc = hit ? acc + __uint_as_float(sn.y) : acc;
+          earlier = earlier || (hit && l < idx);
         }
       }
-    } else {
-#pragma unroll
-      for (int jj = 0; jj < NS; jj++) {
-        const uint32_t ok = ordered_score(__uint_as_float(v[jj]));
-        const bool ps = own[jj] && btop.passes(((uint64_t)ok << 32) | (uint32_t)~e.doc[jj]);
-        const uint64_t m = __ballot(ps);
-        if (m != 0ull) {
-          const uint32_t at = ccur + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-          if (ps) creg[at] = make_uint2(ok, e.doc[jj]);
-          ccur += (uint32_t)__popcll(m);
-        }
-      }
+      const bool owner = have && !earlier;
+      n_scored += (uint32_t)__popcll(__ballot(owner));
+      offer(owner, acc, me.x);
     }
     wave_fence();
     SLG_STAMP(5);
@@ -373,7 +348,7 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
 
   // ---- driver: planned rounds are prefetched one ahead (`en` loads while `ew` is processed);
   //      a round that needs more than NS slots is streamed in chunks cut at a common doc id.
-  //      Both paths and all doc windows share ONE accumulate site (code size / I-cache). ----
+  //      Both paths share ONE accumulate site (code size / I-cache). ----
   URound ew, en;
   Desc G, C;  // descriptors of the current group of 8 planned rounds / of the current chunk
   describe_group(G, 0);
@@ -398,16 +373,13 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
       en.dbase = db;
       if (en.nslots <= (uint32_t)NS) issue(en, G, db);
     }
-    uint32_t dlo = rl(dflat, rr), dhi = rl(dflat, rr + 1);
     SLG_STAMP(0);
-    const uint32_t rhi = dhi;
-    if (p.dbg & 4u) continue;
     uint32_t guard = 0;
     do {
       if (big) {
         // next chunk of an over-full round: every list gets >= 1 slot, the rest in proportion
         // to what it has left; the chunk ends at the smallest "last loaded doc" of the lists
-        // that did not finish
+        // that did not finish, so all postings of a doc are scored in the same chunk
         const uint32_t rem = oend - ocur;
         const uint32_t nne = (uint32_t)__popcll(__ballot(rem != 0u));
         const uint32_t R = lane_sum_T(rem);
@@ -419,21 +391,18 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
           const uint32_t mslots = rem == 0u ? 0u : 1u + (uint32_t)share;
           chunk = rem < mslots * 64u ? rem : mslots * 64u;
         }
-        uint32_t lastdoc = kDocEnd, firstdoc = kDocEnd;
+        uint32_t lastdoc = kDocEnd;
         if (chunk < rem) lastdoc = gdocs[my_off + ocur + chunk - 1];
-        if (rem > 0) firstdoc = gdocs[my_off + ocur];
         describe_chunk(C, ocur, chunk);
         ew.nslots = C.nsl;
         issue(ew, C, 0);
         settle(ew, ew);
         uint32_t bound = kDocEnd;
-        dlo = kDocEnd;
         for (uint32_t t = 0; t < T; t++) {
-          const uint32_t ld = rl(lastdoc, t), fd = rl(firstdoc, t);
+          const uint32_t ld = rl(lastdoc, t);
           bound = ld < bound ? ld : bound;
-          dlo = fd < dlo ? fd : dlo;
         }
-        dhi = bound == kDocEnd ? rhi : bound + 1u;
+        const uint32_t dhi = bound == kDocEnd ? kDocEnd : bound + 1u;  // kDocEnd: nothing was cut
         // what each list consumed: its postings with doc < dhi (a prefix of its slots)
         uint32_t consumed = 0;
 #pragma unroll
@@ -445,19 +414,7 @@ __global__ void __launch_bounds__(256, 4) score_uniform_kernel(RoundScoreParams 
         ocur += consumed;
       }
       if (ew.nslots == 0) break;
-      // doc windows: one in the common case (the postings span <= kSpan docs)
-      uint32_t wbase = dlo & ~31u;
-      for (;;) {
-        const uint32_t wend = (dhi - wbase) <= kSpan ? dhi : wbase + kSpan;
-        accumulate(ew, wbase, wend - wbase);
-        if (wend == dhi) break;
-        uint32_t mn = kDocEnd;  // next window starts at the smallest doc not yet covered
-#pragma unroll
-        for (int jj = 0; jj < NS; jj++) mn = (ew.doc[jj] >= wend && ew.doc[jj] < mn) ? ew.doc[jj] : mn;
-        mn = wave_min(mn);
-        if (mn >= dhi) break;
-        wbase = mn & ~31u;
-      }
+      accumulate(ew);
     } while (big);
   }
 

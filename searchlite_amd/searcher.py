@@ -9,6 +9,7 @@ No CPU fallback lives here: every search goes through libsearchlite_gpu.so.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -33,10 +34,13 @@ def device_count() -> int:
 class GpuIndex:
     """All segments of one shard, staged in HBM (slg_index_create)."""
 
-    def __init__(self, segments: Sequence[Segment], device: int = 0):
+    def __init__(self, segments: Sequence[Segment], device: int = 0, tuning: Optional[dict] = None):
+        """tuning: overrides of slg_tuning fields by name (e.g. {"pruning": 1}) on top of the
+        defaults / SLG_* environment."""
         self._lib = N.load()
         self.segments = list(segments)
         self.device = device
+        self._batches = weakref.WeakSet()  # closed with the index
         descs = (N.SegmentDesc * len(self.segments))()
         keep = []
         for i, s in enumerate(self.segments):
@@ -49,13 +53,25 @@ class GpuIndex:
                 _ptr(s.term_field), nf, C.addressof(ptrs), _ptr(s.field_avgdl),
                 s.docs, s.k1, s.b, _ptr(s.deleted),
                 s.vec_dim, s.vec_metric, _ptr(s.vec_offsets), _ptr(s.vec_values), vec_rows)
-        self._h = self._lib.slg_index_create(descs, len(self.segments), device)
+        tune = N.default_tuning()
+        for name, val in (tuning or {}).items():
+            if not hasattr(tune, name):
+                raise KeyError(f"slg_tuning has no field {name!r}")
+            setattr(tune, name, val)
+        self._h = self._lib.slg_index_create_tuned(descs, len(self.segments), device, C.addressof(tune))
         if not self._h:
-            raise N.SlgError(N.ERR_INVALID, N.last_error())
+            raise N.SlgError(N.last_error_code() or N.ERR_INVALID, N.last_error())
+
+    def tuning(self) -> "N.Tuning":
+        t = N.Tuning()
+        N.check(self._lib.slg_index_get_tuning(self._h, C.addressof(t)))
+        return t
 
     # -- lifecycle -------------------------------------------------------------------
     def close(self) -> None:
         if getattr(self, "_h", None):
+            for b in list(self._batches):  # batches die with their index
+                b.close()
             self._lib.slg_index_destroy(self._h)
             self._h = None
 
@@ -276,9 +292,8 @@ class PreparedBatch:
             index._h, self.nq, _ptr(q_offsets), _ptr(q_terms), _ptr(q_weights), opt(ql), opt(qp),
             opt(qt), opt(qn), opt(qf), k, strategy)
         if not self._h:
-            msg = N.last_error()
-            code = N.ERR_UNSUPPORTED if ("SLG_MAX" in msg or "more than" in msg) else N.ERR_INVALID
-            raise N.SlgError(code, msg)
+            raise N.SlgError(N.last_error_code() or N.ERR_INVALID, N.last_error())
+        index._batches.add(self)
 
     def close(self) -> None:
         if getattr(self, "_h", None):

@@ -95,3 +95,61 @@ def test_no_cpu_fallback_without_device():
     with pytest.raises(N.SlgError) as ei:
         sa.GpuIndex([seg])
     assert ei.value.code in (N.ERR_DEVICE, N.ERR_INVALID)
+
+
+def _seg_desc(n_docs, offs, docs, tfs, keep):
+    import numpy as np
+    from searchlite_amd import _native as N
+    offs = np.asarray(offs, dtype=np.uint64)
+    docs = np.asarray(docs, dtype=np.uint32)
+    tfs = np.asarray(tfs, dtype=np.uint32)
+    dl = np.ones(max(n_docs, 1), dtype=np.float32)
+    avg = np.ones(1, dtype=np.float32)
+    ptrs = (C.c_void_p * 1)(dl.ctypes.data)
+    keep += [offs, docs, tfs, dl, avg, ptrs]
+    return N.SegmentDesc(n_docs, len(offs) - 1, offs.ctypes.data, docs.ctypes.data, tfs.ctypes.data,
+                         None, 1, C.addressof(ptrs), avg.ctypes.data, float(n_docs), 0.9, 0.4, None,
+                         0, 0, None, None, 0)
+
+
+@pytest.mark.parametrize("validate", [1, 0])
+def test_doc_id_beyond_n_docs_is_rejected(lib, validate):
+    """The kernels index per-doc bitmaps with the raw doc id and the round planner interpolates on
+    doc / n_docs: a posting with doc >= n_docs must fail with SLG_ERR_INVALID at the boundary,
+    also when per-posting validation is switched off (then the last posting of each list is checked)."""
+    from searchlite_amd import _native as N
+    keep = []
+    d = _seg_desc(4, [0, 2, 3], [1, 9, 3], [1, 1, 1], keep)  # doc 9 in a 4-doc segment
+    arr = (N.SegmentDesc * 1)(d)
+    t = N.default_tuning()
+    t.validate = validate
+    assert lib.slg_index_create_tuned(arr, 1, 0, C.addressof(t)) is None
+    assert b">= n_docs" in lib.slg_last_error()
+    assert lib.slg_last_error_code() == N.ERR_INVALID
+
+
+def test_last_error_code_follows_handle_returning_functions(lib):
+    from searchlite_amd import _native as N
+    assert lib.slg_index_create(None, 0, 0) is None
+    assert lib.slg_last_error_code() == N.ERR_INVALID
+    assert lib.slg_index_info(None, None, None, None) == N.ERR_INVALID
+    assert lib.slg_last_error_code() == N.ERR_INVALID
+
+
+def test_tuning_defaults_come_from_the_environment_once(lib, monkeypatch):
+    """slg_tuning_default() is the only reader of SLG_* variables."""
+    from searchlite_amd import _native as N
+    monkeypatch.delenv("SLG_MAXSCORE", raising=False)
+    t = N.default_tuning()
+    assert t.struct_size == C.sizeof(N.Tuning) and t.pruning == -1 and t.uniform_max_terms == 4
+    assert t.validate == 1 and t.champions == 1 and t.cand_mode == 1 and t.block_max == 1
+    monkeypatch.setenv("SLG_MAXSCORE", "1")
+    monkeypatch.setenv("SLG_UNIFORM_MAX_TERMS", "0")
+    t = N.default_tuning()
+    assert t.pruning == 1 and t.uniform_max_terms == 0
+    bad = N.Tuning()
+    bad.struct_size = 3
+    keep = []
+    arr = (N.SegmentDesc * 1)(_seg_desc(4, [0, 1], [1], [1], keep))
+    assert lib.slg_index_create_tuned(arr, 1, 0, C.addressof(bad)) is None
+    assert b"struct_size" in lib.slg_last_error()

@@ -1,0 +1,218 @@
+"""BASELINE configs 3 and 4 at full size, the kernels they select pinned on small deterministic
+cases, and fixed-seed regressions of mismatches seen in development (-m gpu)."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import assert_same_hits, random_queries, random_segment
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import searchlite_amd as sa
+    from searchlite_amd import searcher
+    assert searcher.device_count() >= 1
+    return sa
+
+
+def _fuzz():
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "tools", "fuzz_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _properties(d, s, sc, c, k, n_docs):
+    """Size-independent properties of a top-k block: full rows, (score desc, seg asc, doc asc),
+    distinct (seg, doc) pairs in range."""
+    assert (c == k).all()
+    assert (sc[:, :-1] >= sc[:, 1:]).all()
+    tie = sc[:, :-1] == sc[:, 1:]
+    key = s.astype(np.uint64) << np.uint64(32) | d.astype(np.uint64)
+    assert (key[:, :-1][tie] < key[:, 1:][tie]).all()
+    assert (d < n_docs).all()
+    for r in key[:: max(1, len(key) // 64)]:
+        assert len(set(r.tolist())) == k
+
+
+# ---- config 3: 10M docs, 5-term OR with pruning, batch 4096, top-100 --------------------------------
+def test_config3_full_size_properties(gpu, oracle):
+    """BASELINE config 3 exactly as bench.py --config c3 builds it (zipf seed 43, V = 2^20, query
+    seed 7, k = 101, strategy Wand => many-term kernel with pruning-classified lists): determinism,
+    sortedness, distinctness, and a 32-query sample bit-exact against the exhaustive oracle."""
+    from searchlite_amd import corpus
+    n_docs, vocab, nq, T, k = 10_000_000, 1 << 20, 4096, 5, 101
+    seg = corpus.zipf_segment(n_docs, vocab, seed=43, n_threads=16)
+    offs, terms, w = corpus.zipf_queries(nq, T, seed=7, vocab=vocab)
+    with gpu.GpuIndex([seg]) as ix:
+        b = ix.prepare(offs, terms, w, k, gpu.Wand)
+        b.run()
+        d, s, sc, c = b.fetch()
+        b.run()
+        d2, s2, sc2, c2 = b.fetch()
+        b.close()
+        # the exhaustive strategy on the same index returns the same block
+        d3, s3, sc3, c3 = ix.search_batch(offs[:257], terms[:256 * T], w[:256 * T], k, gpu.Bm25)
+    assert np.array_equal(d, d2) and np.array_equal(sc.view(np.uint32), sc2.view(np.uint32))
+    assert np.array_equal(d[:256], d3) and np.array_equal(sc[:256].view(np.uint32), sc3.view(np.uint32))
+    _properties(d, s, sc, c, k, n_docs)
+    nchk = 32
+    want = oracle.search_batch([seg], offs[:nchk + 1], terms[:nchk * T], w[:nchk * T], k,
+                               strategy=oracle.BM25, n_threads=16)
+    assert_same_hits((d[:nchk], s[:nchk], sc[:nchk], c[:nchk]), want, 0.0, "config 3 sample")
+
+
+@pytest.mark.parametrize("tuning", [None, {"block_max": 0}, {"pruning": 0}])
+def test_five_terms_top100_pruned_kernel_small(gpu, oracle, tuning):
+    """The kernel config 3 selects — score_multi_kernel<2, 1>: T = 5, k = 101 (two registers per
+    lane), classification on — on a corpus small enough for the oracle to check every query."""
+    from searchlite_amd import corpus
+    seg = corpus.zipf_segment(300_000, 1 << 16, seed=43)
+    offs, terms, w = corpus.zipf_queries(192, 5, rank_lo=8, rank_hi=4096, seed=7, vocab=1 << 16)
+    want = oracle.search_batch([seg], offs, terms, w, 101, strategy=oracle.BM25, n_threads=8)
+    with gpu.GpuIndex([seg], tuning=tuning) as ix:
+        for strat in (gpu.Wand, gpu.Bmw, gpu.Bm25):
+            got = ix.search_batch(offs, terms, w, 101, strat, want_stats=True)
+            assert_same_hits(got[:4], want, 0.0, f"T=5 k=101 strategy {strat} tuning {tuning}")
+        if tuning is None:  # pruning really happened: fewer docs scored than the exhaustive strategy
+            pr = ix.search_batch(offs, terms, w, 101, gpu.Wand, want_stats=True)[4]
+            ex = ix.search_batch(offs, terms, w, 101, gpu.Bm25, want_stats=True)[4]
+            assert sum(pr[q].scored_docs for q in range(192)) < sum(ex[q].scored_docs for q in range(192))
+
+
+# ---- config 4: 8 index shards, batch 8192, all-gather + merge -----------------------------------------
+def test_config4_eight_shards_merge_on_one_gpu(gpu, oracle):
+    """Config 4's data path on one GPU: the 8 shards bench.py --config c4 builds (1.25M docs each,
+    seeds 43 + r), every shard scored alone for all 8192 5-term queries at k = 101, the result blocks
+    stacked shard-major exactly as the RCCL all-gather delivers them, merged by
+    slg_merge_shards_device.  Checked: properties on all queries; a sample against the oracle run
+    on the 8 shards as 8 segments (api/reader.rs:2670-2778, query/sort.rs:80-93)."""
+    import torch
+    from searchlite_amd import corpus
+    from searchlite_amd import dist as sdist
+    n_shards, n_docs, vocab, nq, T, k = 8, 1_250_000, 1 << 20, 8192, 5, 101
+    offs, terms, w = corpus.zipf_queries(nq, T, seed=7, vocab=vocab)
+    segs, blocks = [], []
+    for r in range(n_shards):
+        seg = corpus.zipf_segment(n_docs, vocab, seed=43 + r, n_threads=16)
+        segs.append(seg)
+        ix = gpu.GpuIndex([seg])
+        ix.set_stream(torch.cuda.current_stream().cuda_stream)
+        b = ix.prepare(offs, terms, w, k, gpu.Wand)
+        b.run()
+        blocks.append(sdist.batch_result_block(b).clone())
+        torch.cuda.synchronize()
+        b.close()
+        ix.close()
+    g = torch.stack(blocks)
+    g_doc, g_seg, g_score, g_count = [x.contiguous() for x in sdist.split_result_block(g, nq, k)]
+    m_doc = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+    m_seg = torch.empty_like(m_doc)
+    m_score = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    m_count = torch.empty((nq,), dtype=torch.int32, device="cuda")
+    small = random_segment(np.random.default_rng(1), 64, 7, 6)  # any index of this device owns the merge
+    with gpu.GpuIndex([small]) as ix:
+        ix.set_stream(torch.cuda.current_stream().cuda_stream)
+        ix.merge_shards_device(n_shards, nq, k, g_doc.data_ptr(), g_seg.data_ptr(), g_score.data_ptr(),
+                               g_count.data_ptr(), 1, m_doc.data_ptr(), m_seg.data_ptr(),
+                               m_score.data_ptr(), m_count.data_ptr())
+        torch.cuda.synchronize()
+    got = (m_doc.cpu().numpy().view(np.uint32), m_seg.cpu().numpy().view(np.uint32),
+           m_score.cpu().numpy(), m_count.cpu().numpy().view(np.uint32))
+    _properties(got[0], got[1], got[2], got[3], k, n_docs)
+    assert (got[1] < n_shards).all()
+    nchk = 24
+    terms8 = np.repeat(terms[:nchk * T].reshape(-1, 1), n_shards, axis=1)
+    want = oracle.search_batch(segs, offs[:nchk + 1], terms8, w[:nchk * T], k, strategy=oracle.BM25,
+                               n_threads=16)
+    assert_same_hits(tuple(x[:nchk] for x in got), want, 0.0, "config 4 sample (8 shards merged)")
+
+
+# ---- fixed-seed regressions ------------------------------------------------------------------------------
+@pytest.mark.parametrize("tuning", [None, {"pruning": 1}, {"uniform_max_terms": 0}, {"block_max": 0}])
+def test_fuzz_seed72_batch2_regression(gpu, oracle, tuning):
+    """gpurun_out/fuzz_72.log of round 1: T = 6 among the queries, k = 600, 3 multi-field segments,
+    filtered and unfiltered queries in one batch, strategy Wand — three queries came back wrong while
+    pruning on the many-term kernel was being built.  Replayed with the same generator and key under
+    the default planner and with pruning / the many-term kernel forced."""
+    _fuzz().run_case(72, 2, tuning)
+
+
+@pytest.mark.parametrize("seed", [72, 73])
+def test_fuzz_neighbourhood_of_seed72(gpu, oracle, seed):
+    mod = _fuzz()
+    for it in range(6):
+        mod.run_case(seed, it, {"pruning": 1})
+
+
+def test_filters_many_terms_large_k(gpu, oracle):
+    """T >= 5 and k > 256 with doc filters (a shape test_doc_filters_match_accept_semantics lacks):
+    mixed filtered / unfiltered queries, three segments, tombstones, strategy Wand."""
+    rng = np.random.default_rng(720)
+    segs = [random_segment(rng, 9000 + 1000 * i, 40, 25) for i in range(3)]
+    segs[1].set_deleted(np.nonzero(rng.random(segs[1].n_docs) < 0.2)[0].tolist())
+    masks = [rng.random(sg.n_docs) < 0.5 for sg in segs]
+    nq, T, k = 20, 6, 600
+    offs, terms, w = random_queries(rng, nq, T, 40, n_segs=3, weights=True)
+    qf = np.array([0 if q % 3 else -1 for q in range(nq)], dtype=np.int32)
+    want = oracle.search_batch_filtered(segs, offs, terms, w, k, qf, [masks], strategy=oracle.BM25)
+    for tuning in (None, {"pruning": 1}, {"pruning": 0}):
+        with gpu.GpuIndex(segs, tuning=tuning) as ix:
+            fid = ix.add_filter(masks)
+            assert fid == 0
+            got = ix.search_batch(offs, terms, w, k, gpu.Wand, q_filter=qf)
+        assert_same_hits(got, want, 0.0, f"filters T=6 k=600 tuning {tuning}")
+
+
+def test_tie_breaker_outside_unit_interval_is_rejected(gpu):
+    """validate_tie_breaker (query/planner.rs:850-856): tie must lie in [0, 1]; a negative tie would
+    also break the threshold seed (a DisMax could fall below its largest leaf)."""
+    from searchlite_amd import _native as N
+    seg = random_segment(np.random.default_rng(5), 500, 20, 10)
+    offs = np.array([0, 2], dtype=np.uint32)
+    terms = np.array([[1], [2]], dtype=np.uint32)
+    w = np.ones(2, dtype=np.float32)
+    with gpu.GpuIndex([seg]) as ix:
+        for tie in (-0.25, 1.5, float("nan")):
+            with pytest.raises(N.SlgError) as e:
+                ix.search_plan(offs, terms, w, 5, q_plan=[gpu.PLAN_DISMAX], q_tie=[tie])
+            assert e.value.code == N.ERR_INVALID and "tie" in e.value.msg
+        with pytest.raises(N.SlgError) as e:
+            ix.search_plan(offs, terms, w, 5, q_leaf=np.array([0, 0xFFFFFFFF], dtype=np.uint32))
+        assert e.value.code == N.ERR_INVALID
+        ix.search_plan(offs, terms, w, 5, q_plan=[gpu.PLAN_DISMAX], q_tie=[1.0])  # the ends are legal
+        ix.search_plan(offs, terms, w, 5, q_plan=[gpu.PLAN_DISMAX], q_tie=[0.0])
+
+
+def test_index_closed_before_its_batches(gpu):
+    """Either destruction order is safe: a batch that outlives its index is detached (calls fail
+    with SLG_ERR_INVALID, destroy stays valid)."""
+    from searchlite_amd import _native as N
+    import ctypes as C
+    seg = random_segment(np.random.default_rng(6), 800, 20, 10)
+    offs, terms, w = random_queries(np.random.default_rng(7), 4, 2, 20)
+    ix = gpu.GpuIndex([seg])
+    b = ix.prepare(offs, terms, w, 5)
+    b.run()
+    b.fetch()
+    # through the raw ABI: destroy the index first, then use and destroy the batch
+    lib = N.load()
+    h_ix, h_b = ix._h, b._h
+    ix._h = None
+    ix._batches.clear()
+    lib.slg_index_destroy(h_ix)
+    assert lib.slg_batch_run(h_b) == N.ERR_INVALID
+    assert lib.slg_batch_sync(h_b) == N.ERR_INVALID
+    lib.slg_batch_destroy(h_b)
+    b._h = None
+    # through the Python mirror: closing the index closes its batches
+    ix2 = gpu.GpuIndex([seg])
+    b2 = ix2.prepare(offs, terms, w, 5)
+    ix2.close()
+    assert b2._h is None
+    b2.close()

@@ -1,6 +1,7 @@
 """Randomised parity run (GPU box): random corpora, query shapes, k, weights (also zero / negative),
 tombstones, doc filters, score plans and strategies, each batch compared bit for bit with the CPU
-oracle.  usage: python tools/fuzz_parity.py [iterations] [seed]"""
+oracle.  usage: python tools/fuzz_parity.py [iterations] [seed]
+(SLG_MAXSCORE=1 / SLG_UNIFORM_MAX_TERMS=0 in the environment force pruning / the many-term kernel.)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,10 +11,8 @@ from tests.util import random_segment, random_multifield_segment, skewed_segment
 
 
 
-def run(iters, seed0, verbose=True):
-  O.build()
-  t0 = time.time()
-  for it in range(iters):
+def run_case(seed0, it, tuning=None):
+      """One random batch, keyed (seed0, it): GPU through the C ABI vs the oracle, bit for bit."""
       rng = np.random.default_rng(seed0 * 100003 + it)
       n_segs = int(rng.integers(1, 4))
       skew = rng.random() < 0.3          # big sparse / clustered lists: window and overflow cuts
@@ -67,19 +66,13 @@ def run(iters, seed0, verbose=True):
                 q_tie=np.array(tie, dtype=np.float32), q_nleaves=np.array(nl, dtype=np.uint32)) if use_plan else {}
       use_filter = rng.random() < 0.4
       masks = [rng.random(sg.n_docs) < rng.choice([0.05, 0.5, 0.95]) for sg in segs]
-      with sa.GpuIndex(segs) as ix:
+      with sa.GpuIndex(segs, tuning=tuning) as ix:
           qf = None
           if use_filter:
               fid = ix.add_filter(masks)
               qf = np.array([fid if rng.random() < 0.6 else -1 for _ in range(nq)], dtype=np.int32)
           strat = int(rng.choice([sa.Bm25, sa.Wand, sa.Bmw]))
-          try:
-              got = ix.search_plan(offs, terms, w, k, strategy=strat, q_filter=qf, **kw)
-          except sa.SlgError as e:
-              # the packed kernel (forced with SLG_MAXSCORE=1 / SLG_NO_UNIFORM=1) stops at k = 1024
-              if e.code == -4 and k > 1024 and (os.environ.get("SLG_MAXSCORE") or os.environ.get("SLG_NO_UNIFORM")):
-                  continue
-              raise
+          got = ix.search_plan(offs, terms, w, k, strategy=strat, q_filter=qf, **kw)
       if use_filter:
           want = O.search_batch_filtered(segs, offs, terms, w, k, np.where(qf >= 0, 0, -1), [masks],
                                          strategy=O.BM25, **kw)
@@ -108,10 +101,17 @@ def run(iters, seed0, verbose=True):
                     f"terms={terms[int(offs[q]):int(offs[q + 1])].tolist()}")
               break
           raise
-      if verbose and it % 10 == 9:
-          print(f"{it + 1} batches ok ({time.time() - t0:.0f} s)", flush=True)
-  if verbose:
-    print("fuzz_parity: all", iters, "batches bit-exact")
+
+
+def run(iters, seed0, verbose=True, tuning=None):
+    O.build()
+    t0 = time.time()
+    for it in range(iters):
+        run_case(seed0, it, tuning)
+        if verbose and it % 10 == 9:
+            print(f"{it + 1} batches ok ({time.time() - t0:.0f} s)", flush=True)
+    if verbose:
+        print("fuzz_parity: all", iters, "batches bit-exact")
 
 
 if __name__ == "__main__":

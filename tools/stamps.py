@@ -22,8 +22,8 @@ L = N.load()
 L.slg_debug_read_stamps.restype = C.c_int
 L.slg_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 assert L.slg_debug_read_stamps(b._h, out.ctypes.data, n) == 0
-names = ["0 plan/issue next", "1 window setup", "2 P0+P1 clear+or", "3 P2 scan", "4 P3 rmw",
-         "5 P4 read+topk", "6 wait loads+copy", "7 tail / probe"]
+names = ["0 plan/issue next", "1 chunk setup", "2 P0+P1 clear+or", "3 P2 read back", "4 P3 singles+queue",
+         "5 P4 join", "6 wait loads+copy", "7 tail"]
 ins = out[:, 7].copy(); out[:, 7] = 0
 tot = out.sum()
 print("inserts/slice mean", ins.mean(), "max", ins.max(), "p50", np.median(ins), "p90", np.percentile(ins, 90))
