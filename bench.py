@@ -1,67 +1,106 @@
 #!/usr/bin/env python3
 """bench.py — queries/sec of the batched BM25 top-k scorer on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path over one batch of synthetic queries: the partition,
-scoring and merge kernels of `slg_batch_run` with the index and the planned batch already
-resident in HBM (plus, for N > 1, the RCCL all-gather of the per-rank top-k).
+A "step" is one pass of the hot path over one batch of synthetic queries.
 
-N = 1 workload = BASELINE.json configs[1]: 1M-doc synthetic Zipf corpus (avg 256 tokens),
-3-term OR queries, batch = 1024, top-10 (k = limit + 1 = 11).
-N > 1: query batches shard across GPUs — every rank holds a replica of the index, scores its
-own 1024-query batch, and the per-rank top-k are exchanged with one all-gather ("weak" scaling:
-per-GPU work fixed).  `--mode shard` instead shards the INDEX (configs[3] shape): every rank
-scores all queries against its own segment, all-gather, device merge.
+`value` (N = 1, BASELINE.json configs[1]: 1M-doc Zipf corpus, 3-term OR, batch 1024, top-10) is
+the SURVEY section 8(d) figure: the index is resident in HBM, every step takes a FRESH query
+batch as host arrays through the C ABI — slg_batch_prepare (plan + H2D) -> slg_batch_run (three
+kernels) -> slg_batch_fetch (D2H into host arrays) -> destroy — from `--host-threads` caller
+threads, each on its own HIP stream (the reference serves one request per thread,
+searchlite-http/src/lib.rs:640-643).  The batches rotate over `--rotate` distinct query sets, so
+the posting working set (8 x 262 MB for config 2) is far beyond the 256 MiB Infinity Cache.
+Reported beside it (config.*): the device-resident rate of pre-planned batches, and the scoring
+kernel's own duration (HIP events on its stream, batches rotating, one at a time) for `roofline`.
+
+N > 1 (launched by the driver through torch.distributed.run, or by `--gpus N` itself, which starts
+the N ranks as a child torchrun before touching any GPU): query batches shard across replicas of
+the index (weak scaling, no data-path collective; the device-resident leg exchanges the per-rank
+top-k with ONE RCCL all-gather per step).  In addition the BASELINE configs[3] shape is timed
+(`c4` object; `--config c4` makes it the main workload): the 10M-doc corpus as 8 segments of
+1.25M docs (seeds 43..50) index-sharded over the N ranks, batch 8192 x 5 terms, top-100; every
+rank scores all queries against its segments, ONE all-gather of the (3k+1)*Q*4-byte result
+blocks over xGMI, device merge (strong scaling: the same 8 segments at every N).
 
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import itertools
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
-
-def parse_args():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5", "small"])
-    ap.add_argument("--dim", type=int, default=768, help="vector dimension (config c5)")
-    ap.add_argument("--mode", default="replica", choices=["replica", "shard"])
-    ap.add_argument("--docs", type=int, default=0)
-    ap.add_argument("--nq", type=int, default=0)
-    ap.add_argument("--terms", type=int, default=0)
-    ap.add_argument("--limit", type=int, default=0)
-    ap.add_argument("--strategy", default="wand", choices=["bm25", "wand", "bmw"])
-    ap.add_argument("--inflight", type=int, default=2,
-                    help="prepared batches in flight, each on its own HIP stream (steps go "
-                         "round-robin over them; every step still does the whole batch's work)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-queries", type=int, default=0, help="queries in the CPU sample")
-    ap.add_argument("--check", type=int, default=64, help="queries parity-checked vs the oracle")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="initialise torch.distributed (RCCL) even for one rank, to exercise the all-gather path")
-    return ap.parse_args()
-
-
 CONFIGS = {
     # name: (docs, vocab, corpus_seed, nq, terms, limit)
     "c2": (1_000_000, 1 << 18, 42, 1024, 3, 10),
     "c3": (10_000_000, 1 << 20, 43, 4096, 5, 100),
     "small": (100_000, 1 << 15, 42, 256, 3, 10),
+    # config 4: 8 segments x 1.25M docs (seeds 43 + s), index-sharded over the ranks
+    "c4": (1_250_000, 1 << 20, 43, 8192, 5, 100),
     # config 5: BM25 top-1000 (k = 1001) -> cosine rerank over 768-d f32 vectors -> top-10
     "c5": (1_000_000, 1 << 18, 42, 1024, 3, 1000),
 }
+C4_SEGMENTS = 8
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--dim", type=int, default=768, help="vector dimension (config c5)")
+    ap.add_argument("--docs", type=int, default=0)
+    ap.add_argument("--nq", type=int, default=0)
+    ap.add_argument("--terms", type=int, default=0)
+    ap.add_argument("--limit", type=int, default=0)
+    ap.add_argument("--strategy", default="wand", choices=["bm25", "wand", "bmw"])
+    ap.add_argument("--rotate", type=int, default=8, help="distinct query sets the steps rotate over")
+    ap.add_argument("--host-threads", type=int, default=8,
+                    help="caller threads of the host-inclusive leg (each: prepare -> run -> fetch)")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="device-resident leg: prepared batches in flight, each on its own HIP stream")
+    ap.add_argument("--kernel-leg-only", action="store_true",
+                    help="profiling runs: only the rotating, one-at-a-time kernel leg (value = its rate)")
+    ap.add_argument("--no-c4", action="store_true", help="N > 1: skip the config-4 (index-sharded) leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-queries", type=int, default=0, help="queries in the CPU sample")
+    ap.add_argument("--check", type=int, default=64, help="queries parity-checked vs the oracle")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) even for one rank")
+    return ap.parse_args()
+
+
+def spawn_ranks_if_needed(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child torchrun and
+    exit with its code.  Runs before anything in this process touches a GPU."""
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is not None:
+        if int(world_env) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}")
+        return
+    if args.gpus <= 1:
+        return
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 class _DevArray:
@@ -74,15 +113,14 @@ class _DevArray:
 
 def main():
     args = parse_args()
+    spawn_ranks_if_needed(args)
+    import numpy as np
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -90,10 +128,141 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
     from searchlite_amd import corpus, searcher
+
+    host_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    gen_threads = max(1, min(32, host_cores // max(1, world)))
+    strategy = {"bm25": searcher.Bm25, "wand": searcher.Wand, "bmw": searcher.Bmw}[args.strategy]
+    stream = torch.cuda.current_stream()
+
+    def fence():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if not use_dist:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(x):
+        if not use_dist:
+            return x
+        t = torch.tensor([float(x)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def query_sets(nq, T, vocab, n_segs, first_seed, n_sets):
+        out = []
+        for j in range(n_sets):
+            offs, terms, w = corpus.zipf_queries(nq, T, seed=first_seed + j, vocab=vocab)
+            # term id == rank - 1 in every zipf segment: the same id in each segment's dictionary
+            t2 = np.ascontiguousarray(np.repeat(terms.reshape(-1, 1), n_segs, axis=1))
+            out.append((offs, t2, w))
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    # index-sharded workload (config 4 shape): device-resident index, fresh host queries per step,
+    # ONE all-gather of the per-rank result blocks + device merge, merged top-k back on the host
+    # ------------------------------------------------------------------------------------------
+    def run_sharded(cfg_name, steps, warmup):
+        n_docs, vocab, cseed, nq, T, limit = CONFIGS[cfg_name]
+        n_docs = args.docs or n_docs
+        nq = (args.nq or nq) if args.config == cfg_name else nq
+        k = limit + 1
+        if C4_SEGMENTS % world:
+            raise SystemExit(f"config c4 needs a rank count that divides {C4_SEGMENTS}")
+        per_rank = C4_SEGMENTS // world
+        t0 = time.time()
+        segs = [corpus.zipf_segment(n_docs, vocab, seed=cseed + rank * per_rank + s, n_threads=gen_threads)
+                for s in range(per_rank)]
+        t_corpus = time.time() - t0
+        index = searcher.GpuIndex(segs, device=local_rank)
+        index.set_stream(stream.cuda_stream)
+        del segs
+        qs = query_sets(nq, T, vocab, per_rank, 7, max(2, args.rotate))
+        n_flight = 2
+        streams = [torch.cuda.Stream() for _ in range(n_flight)]
+        blk_words = (3 * k + 1) * nq
+        g_blocks = [torch.empty((world * blk_words,), dtype=torch.int32, device="cuda") for _ in range(n_flight)]
+        merged = [[torch.empty((nq, k), dtype=torch.int32, device="cuda"),
+                   torch.empty((nq, k), dtype=torch.int32, device="cuda"),
+                   torch.empty((nq, k), dtype=torch.float32, device="cuda"),
+                   torch.empty((nq,), dtype=torch.int32, device="cuda")] for _ in range(n_flight)]
+        host_out = [[torch.empty((nq, k), dtype=torch.int32).pin_memory(),
+                     torch.empty((nq, k), dtype=torch.int32).pin_memory(),
+                     torch.empty((nq, k), dtype=torch.float32).pin_memory(),
+                     torch.empty((nq,), dtype=torch.int32).pin_memory()] for _ in range(n_flight)]
+        live = [None] * n_flight
+        done_ev = [None] * n_flight
+        postings = []
+
+        def step(i):
+            f = i % n_flight
+            if live[f] is not None:  # the slot's previous batch: results are on the host by now
+                done_ev[f].synchronize()
+                live[f].close()
+            offs, terms, w = qs[i % len(qs)]
+            b = index.prepare(offs, terms, w, k, strategy)  # host planning + H2D of the descriptors
+            b.set_stream(streams[f].cuda_stream)
+            b.run()
+            if len(postings) < len(qs):
+                postings.append(b.info())
+            live[f] = b
+            ptr, nbytes = b.device_result_block()
+            blk = torch.as_tensor(_DevArray(ptr, (nbytes // 4,), "<i4"), device="cuda")
+            stream.wait_event(streams[f].record_event())
+            if use_dist:
+                dist.all_gather_into_tensor(g_blocks[f], blk)
+                gb = g_blocks[f].view(world, -1)
+            else:
+                gb = blk.view(1, -1)
+            n_ = nq * k
+            g_doc, g_seg = gb[:, :n_].contiguous(), gb[:, n_:2 * n_].contiguous()
+            g_score, g_count = gb[:, 2 * n_:3 * n_].contiguous(), gb[:, 3 * n_:].contiguous()
+            m = merged[f]
+            index.merge_shards_device(world, nq, k, g_doc.data_ptr(), g_seg.data_ptr(), g_score.data_ptr(),
+                                      g_count.data_ptr(), per_rank, m[0].data_ptr(), m[1].data_ptr(),
+                                      m[2].data_ptr(), m[3].data_ptr())
+            for h, d in zip(host_out[f], m):
+                h.copy_(d, non_blocking=True)
+            done_ev[f] = stream.record_event()
+
+        for i in range(warmup):
+            step(i)
+        fence()
+        t1 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        for f in range(n_flight):
+            if done_ev[f] is not None:
+                done_ev[f].synchronize()
+        fence()
+        elapsed = max_over_ranks(time.perf_counter() - t1)
+        last = (warmup + steps - 1) % n_flight
+        res = tuple(x.numpy().copy() for x in host_out[last])
+        last_q = qs[(warmup + steps - 1) % len(qs)]
+        for b in live:
+            if b is not None:
+                b.close()
+        info = index.info()
+        index.close()
+        out = {"workload": f"{C4_SEGMENTS} segments x {n_docs} synthetic Zipf docs (V={vocab}, seeds {cseed}.."
+                           f"{cseed + C4_SEGMENTS - 1}) index-sharded over {world} GPU(s), {T}-term OR, "
+                           f"batch={nq}, top-{limit} (k={k}), strategy={args.strategy}; fresh host query "
+                           f"batch per step, one all-gather of (3k+1)*Q*4 B per rank, device merge, merged "
+                           f"top-k copied to the host",
+               "queries_per_s": round(nq / (elapsed / steps), 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
+               "steps": steps, "scaling": "strong", "segments_per_rank": per_rank,
+               "postings_per_batch_this_rank": int(np.mean([p["n_postings"] for p in postings])),
+               "index_postings_this_rank": int(info["n_postings"]), "corpus_build_s": round(t_corpus, 1)}
+        return out, res, last_q, (n_docs, vocab, cseed, nq, T, k)
 
     n_docs, vocab, cseed, nq, T, limit = CONFIGS[args.config]
     n_docs = args.docs or n_docs
@@ -101,57 +270,122 @@ def main():
     T = args.terms or T
     limit = args.limit or limit
     k = limit + 1  # api/reader.rs:2615-2619
-    strategy = {"bm25": searcher.Bm25, "wand": searcher.Wand, "bmw": searcher.Bmw}[args.strategy]
-    host_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, min(32, host_cores // max(1, world)))
+    out = None
 
+    if args.config == "c4":
+        c4, res, last_q, _ = run_sharded("c4", args.steps, args.warmup)
+        if rank == 0:
+            out = {"metric": "queries/sec at top-10 (batch=1024) + achieved HBM GB/s vs peak",
+                   "value": c4["queries_per_s"], "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+                   "warmup": args.warmup, "ms_per_step": c4["ms_per_step"], "higher_is_better": True,
+                   "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                   "config": c4}
+            if world == 1 and args.check:
+                from oracle import oracle as O
+                segs = [corpus.zipf_segment(n_docs, vocab, seed=cseed + s, n_threads=gen_threads)
+                        for s in range(C4_SEGMENTS)]
+                nchk = min(args.check, 16)
+                offs, terms, w = last_q
+                want = O.search_batch(segs, offs[:nchk + 1], terms[:nchk * T], w[:nchk * T], k,
+                                      strategy=O.BM25, n_threads=gen_threads)
+                ok = all(int(res[3][q]) == int(want[3][q]) and
+                         np.array_equal(res[0][q].view(np.uint32), want[0][q]) and
+                         np.array_equal(res[1][q].view(np.uint32), want[1][q]) and
+                         np.array_equal(res[2][q].view(np.uint32), want[2][q].view(np.uint32))
+                         for q in range(nchk))
+                out["parity"] = {"queries_checked": nchk, "bit_exact": bool(ok)}
+                if not ok:
+                    print(json.dumps(out))
+                    raise SystemExit("bench.py: GPU results differ from the oracle")
+            print(json.dumps(out), flush=True)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ------------------------------------------------------------------------------------------
+    # replica workload (configs 2 / 3 / 5 / small)
+    # ------------------------------------------------------------------------------------------
     t0 = time.time()
-    shard_mode = args.mode == "shard" and (world > 1 or args.force_dist)
-    seg_seed = cseed + (rank if shard_mode else 0)
-    seg = corpus.zipf_segment(n_docs, vocab, seed=seg_seed, n_threads=threads)
-    q_seed = 7 + (0 if shard_mode else rank)
-    offs, terms, w = corpus.zipf_queries(nq, T, seed=q_seed, vocab=vocab)
+    seg = corpus.zipf_segment(n_docs, vocab, seed=cseed, n_threads=gen_threads)
     t_corpus = time.time() - t0
-
     rerank = args.config == "c5"
     if rerank:
         seg.vec_dim, seg.vec_metric = args.dim, 0
         seg.vec_offsets = np.arange(n_docs, dtype=np.uint32)
         seg.vec_values = corpus.unit_vectors(n_docs, args.dim, seed=11)
     index = searcher.GpuIndex([seg], device=local_rank)
-    stream = torch.cuda.current_stream()
     index.set_stream(stream.cuda_stream)
-    # several batches in flight (separate work buffers, separate HIP streams): the partition /
-    # merge kernels of one batch overlap the scoring kernel of another.  Not combined with the
-    # rerank stage, which runs on the index stream.
+    n_sets = max(1, args.rotate)
+    qs = query_sets(nq, T, vocab, 1, 7 + rank * n_sets, n_sets)  # seeds 7.. (rank 0), distinct per rank
+
+    # ---- leg 1 (`value`): host arrays in -> prepare -> run -> fetch -> host arrays out ----
+    n_thr = max(1, args.host_threads)
+    thr_streams = [torch.cuda.Stream() for _ in range(n_thr)]
+    first_results = {}
+
+    def host_leg(n_steps, first):
+        counter = itertools.count(first)
+        lock = threading.Lock()
+        errors = []
+
+        def worker(tid):
+            try:
+                torch.cuda.set_device(local_rank)
+                while True:
+                    with lock:
+                        i = next(counter)
+                    if i >= first + n_steps:
+                        return
+                    offs, terms, w = qs[i % n_sets]
+                    b = index.prepare(offs, terms, w, k, strategy)
+                    b.set_stream(thr_streams[tid].cuda_stream)
+                    b.run()
+                    res = b.fetch()
+                    b.close()
+                    if (i % n_sets) not in first_results:
+                        first_results[i % n_sets] = res
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(n_thr)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        if errors:
+            raise errors[0]
+
+    value = ms_per_step = None
+    if not rerank and not args.kernel_leg_only:
+        host_leg(args.warmup, 0)
+        fence()
+        t1 = time.perf_counter()
+        host_leg(args.steps, args.warmup)
+        fence()
+        elapsed = max_over_ranks(time.perf_counter() - t1)
+        ms_per_step = elapsed / args.steps * 1e3
+        value = nq * world / (elapsed / args.steps)
+
+    # ---- leg 2: device-resident pre-planned batches, rotating, `inflight` streams ----
     inflight = max(1, args.inflight) if not rerank else 1
-    batches = [index.prepare(offs, terms, w, k, strategy) for _ in range(inflight)]
+    batches = [index.prepare(*q, k, strategy) for q in qs]
+    infos = [b.info() for b in batches]
     streams = [torch.cuda.Stream() for _ in range(inflight)] if inflight > 1 else [stream]
     if inflight > 1:
-        for b_, s_ in zip(batches, streams):
-            b_.set_stream(s_.cuda_stream)
-    batch = batches[0]
-    info = batch.info()
-    d_doc, d_seg, d_score, d_count = batch.device_results()
-    t_doc = torch.as_tensor(_DevArray(d_doc, (nq, k), "<i4"), device="cuda")
-    t_seg = torch.as_tensor(_DevArray(d_seg, (nq, k), "<i4"), device="cuda")
-    t_score = torch.as_tensor(_DevArray(d_score, (nq, k), "<f4"), device="cuda")
-    t_count = torch.as_tensor(_DevArray(d_count, (nq,), "<i4"), device="cuda")
+        for j, b in enumerate(batches):
+            b.set_stream(streams[j % inflight].cuda_stream)
     if use_dist:
         t_blocks, g_blocks = [], []
-        for b_ in batches:
-            blk_ptr, blk_bytes = b_.device_result_block()
-            t_blocks.append(torch.as_tensor(_DevArray(blk_ptr, (blk_bytes // 4,), "<i4"), device="cuda"))
-            g_blocks.append(torch.empty((world * (blk_bytes // 4),), dtype=torch.int32, device="cuda"))
-        t_block, g_block = t_blocks[0], g_blocks[0]
-        m_doc = torch.empty((nq, k), dtype=torch.int32, device="cuda")
-        m_seg = torch.empty_like(m_doc)
-        m_score = torch.empty((nq, k), dtype=torch.float32, device="cuda")
-        m_count = torch.empty((nq,), dtype=torch.int32, device="cuda")
-
+        for b in batches:
+            ptr, nbytes = b.device_result_block()
+            t_blocks.append(torch.as_tensor(_DevArray(ptr, (nbytes // 4,), "<i4"), device="cuda"))
+            g_blocks.append(torch.empty((world * (nbytes // 4),), dtype=torch.int32, device="cuda"))
     if rerank:
         seg.vec_values = None  # staged in HBM; free the host copy
         k_out = 10
+        d_res = [b.device_results() for b in batches]
+        cnt_t = [torch.as_tensor(_DevArray(d[3], (nq,), "<i4"), device="cuda") for d in d_res]
         qv = torch.from_numpy(corpus.unit_vectors(nq, args.dim, seed=12)).cuda()
         alpha = torch.full((nq,), 0.5, dtype=torch.float32, device="cuda")
         r_doc = torch.empty((nq, k_out), dtype=torch.int32, device="cuda")
@@ -161,153 +395,136 @@ def main():
         r_count = torch.empty((nq,), dtype=torch.int32, device="cuda")
         ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
         ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    step_no = [0]
+    gathered = [None] * n_sets
     turn = [0]
-    gathered = [None] * inflight
 
-    def shard_merge(gblk):  # api/reader.rs:2776-2778 across shards (index stream = default stream)
-        n_ = nq * k
-        gb = gblk.view(world, -1)
-        g_doc = gb[:, :n_].contiguous()
-        g_seg = gb[:, n_:2 * n_].contiguous()
-        g_score = gb[:, 2 * n_:3 * n_].contiguous()
-        g_count = gb[:, 3 * n_:].contiguous()
-        index.merge_shards_device(world, nq, k, g_doc.data_ptr(), g_seg.data_ptr(),
-                                  g_score.data_ptr(), g_count.data_ptr(), 1,
-                                  m_doc.data_ptr(), m_seg.data_ptr(), m_score.data_ptr(),
-                                  m_count.data_ptr())
-
-    def step():
-        if inflight > 1:
-            i = turn[0] % inflight
-            turn[0] += 1
-            if use_dist and gathered[i] is not None:
-                streams[i].wait_event(gathered[i])  # the previous gather of this block is done
-            batches[i].run()
-            if use_dist:
-                # replica mode: one all-gather of this batch's result block.  RCCL stays on the
-                # default stream (ordered after the batch's kernels by an event); the batch's
-                # stream waits for the gather before the block is overwritten two steps later.
-                stream.wait_event(streams[i].record_event())
-                dist.all_gather_into_tensor(g_blocks[i], t_blocks[i])
-                if shard_mode:
-                    shard_merge(g_blocks[i])
-                gathered[i] = stream.record_event()
-            return
-        batch.run()
+    def resident_step(timed_idx=None):
+        j = turn[0] % n_sets
+        turn[0] += 1
+        b = batches[j]
+        if inflight > 1 and use_dist and gathered[j] is not None:
+            streams[j % inflight].wait_event(gathered[j])  # the previous gather of this block is done
+        b.run()
         if rerank:  # candidates = the BM25 pass's device results (no host round trip)
-            timed = step_no[0] >= args.warmup
-            if timed:
-                ev_a[step_no[0] - args.warmup].record()
-            index.rerank_batch_device(nq, qv.data_ptr(), alpha.data_ptr(), d_doc, d_seg, d_score,
-                                      d_count, k, k_out, r_doc.data_ptr(), r_seg.data_ptr(),
-                                      r_score.data_ptr(), r_vec.data_ptr(), r_count.data_ptr())
-            if timed:
-                ev_b[step_no[0] - args.warmup].record()
-            step_no[0] += 1
+            if timed_idx is not None:
+                ev_a[timed_idx].record()
+            d = d_res[j]
+            index.rerank_batch_device(nq, qv.data_ptr(), alpha.data_ptr(), d[0], d[1], d[2], d[3], k, k_out,
+                                      r_doc.data_ptr(), r_seg.data_ptr(), r_score.data_ptr(),
+                                      r_vec.data_ptr(), r_count.data_ptr())
+            if timed_idx is not None:
+                ev_b[timed_idx].record()
         if use_dist:
             # per-rank top-k exchanged over xGMI in ONE all-gather: the contiguous block
-            # doc|seg|score|count = (3k+1)*Q*4 bytes per rank
-            dist.all_gather_into_tensor(g_block, t_block)
-            if shard_mode:
-                shard_merge(g_block)
-
-    def fence():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+            # doc|seg|score|count = (3k+1)*Q*4 bytes per rank (RCCL stays on the default stream)
+            if inflight > 1:
+                stream.wait_event(streams[j % inflight].record_event())
+            dist.all_gather_into_tensor(g_blocks[j], t_blocks[j])
+            gathered[j] = stream.record_event()
 
     for _ in range(args.warmup):
-        step()
+        resident_step()
     fence()
-    if inflight == 1:
-        index.profile(True)
-        index.profile_read()
     t1 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(1 if args.kernel_leg_only else args.steps):
+        resident_step(i)
     fence()
-    elapsed = time.perf_counter() - t1
-    if inflight > 1:
-        # scoring-kernel duration (HIP events on the kernel's stream): measured on one batch
-        # running alone, after the timed region, so overlap with other batches does not blur it
-        index.profile(True)
-        index.profile_read()
-        for _ in range(max(5, min(args.steps, 20))):
-            batch.run()
-        fence()
+    res_elapsed = max_over_ranks(time.perf_counter() - t1) * (args.steps if args.kernel_leg_only else 1)
+    resident_qps = nq * world / (res_elapsed / args.steps)
+    if rerank:
+        value, ms_per_step = resident_qps, res_elapsed / args.steps * 1e3
+
+    # ---- leg 3: the scoring kernel alone (HIP events on its launch stream), batches rotating ----
+    for b in batches:
+        b.set_stream(None)  # back on the index stream: one kernel at a time
+    index.profile(True)
+    index.profile_read()
+    reps = max(2, min(8, (args.steps + n_sets - 1) // n_sets))
+    for _ in range(reps):
+        for b in batches:
+            b.run()
+    fence()
     n_launch, kern_ms = index.profile_read()
     index.profile(False)
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        pp = torch.tensor([float(info["n_postings"])], dtype=torch.float64, device="cuda")
-        dist.all_reduce(pp, op=dist.ReduceOp.SUM)
-        total_postings = float(pp.item())
-    else:
-        total_postings = float(info["n_postings"])
+    if args.kernel_leg_only:
+        value = nq * world / (kern_ms / max(n_launch, 1) * 1e-3)
+        ms_per_step = kern_ms / max(n_launch, 1)
+    total_postings = sum_over_ranks(float(np.mean([i["n_postings"] for i in infos])))
 
-    ms_per_step = elapsed / args.steps * 1e3
-    queries_per_step = nq if shard_mode else nq * world
-    value = queries_per_step / (elapsed / args.steps)
-
-    out = None
     if rank == 0:
         kern_avg_ms = kern_ms / max(n_launch, 1)
-        alg_bytes = info["algorithmic_bytes"]  # 12 B/posting + 8*k*nq
+        alg_bytes = float(np.mean([i["algorithmic_bytes"] for i in infos]))  # 12 B/posting + 8*k*nq
         achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_c2.json")
-        if args.config == "c2" and world == 1 and os.path.exists(tpath):
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
+        if world == 1 and os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
+                tj = json.load(open(tpath))
+                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
+            except Exception:  # noqa: BLE001
                 traffic = None
         out = {
             "metric": "queries/sec at top-10 (batch=1024) + achieved HBM GB/s vs peak",
             "value": round(value, 1), "unit": "queries/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "strong" if shard_mode else "weak",
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n_docs} synthetic Zipf docs (avg 256 tokens, V={vocab}, "
                                    f"s=1.0, seed {cseed}), {T}-term OR, batch={nq} per GPU, "
                                    f"top-{limit} (k={k}), strategy={args.strategy}, "
-                                   f"{'index-sharded' if shard_mode else 'query-sharded replicas'}",
-                       "postings_per_batch": int(info["n_postings"]),
-                       "slices": int(info["n_slices"]), "batches_in_flight": inflight,
+                                   f"query-sharded replicas",
+                       "value_is": ("--kernel-leg-only: rate of the scoring kernel alone (profiling run)"
+                                    if args.kernel_leg_only else
+                                    "device-resident index; every step a fresh host query batch through the "
+                                    "C ABI: slg_batch_prepare (plan + H2D) -> run -> fetch (D2H) -> destroy"
+                                    if not rerank else
+                                    "device-resident pipeline BM25 top-1000 -> rerank -> top-10 of pre-planned batches"),
+                       "host_threads": None if rerank else n_thr,
+                       "rotating_query_sets": n_sets,
+                       "posting_working_set_bytes": int(8 * sum(i["n_postings"] for i in infos)),
+                       "kernel_only_qps": round(resident_qps, 1),
+                       "kernel_only_ms_per_step": round(res_elapsed / args.steps * 1e3, 4),
+                       "kernel_only_is": f"pre-planned device-resident batches, {inflight} in flight"
+                                         + (", + one all-gather of the result block per step" if use_dist else ""),
+                       "postings_per_batch": int(np.mean([i["n_postings"] for i in infos])),
+                       "slices": int(np.mean([i["n_slices"] for i in infos])),
                        "all_ranks_postings": int(total_postings),
                        "corpus_build_s": round(t_corpus, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "kernel": "score_uniform_kernel" if T <= 4 else "score_multi_kernel",
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "score_uniform_kernel" if T <= 4 else "score_multi_kernel",
                          "kernel_ms": round(kern_avg_ms, 4), "launches": n_launch,
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
+        if rerank:
+            rr_ms = sum(a.elapsed_time(b_) for a, b_ in zip(ev_a, ev_b)) / args.steps
+            cands = int(sum(int(c.sum().item()) for c in cnt_t) / n_sets)
+            rr_bytes = 4 * args.dim * cands + 8 * cands + 4 * args.dim * nq
+            out["rerank"] = {"kernel": "rerank_kernel", "kernel_ms": round(rr_ms, 4),
+                             "candidates": cands, "algorithmic_bytes": rr_bytes,
+                             "achieved_GBps": round(rr_bytes / (rr_ms * 1e-3) / 1e9, 1),
+                             "frac_of_hbm_peak": round(rr_bytes / (rr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "note": "BM25 top-1000 candidates reranked by cosine (dot of unit vectors) "
+                                     "with alpha=0.5 blend to top-10; value = whole pipeline"}
 
-    if rank == 0 and rerank:
-        rr_ms = sum(a.elapsed_time(b_) for a, b_ in zip(ev_a, ev_b)) / args.steps
-        cands = int(t_count.sum().item())
-        rr_bytes = 4 * args.dim * cands + 8 * cands + 4 * args.dim * nq
-        out["rerank"] = {"kernel": "rerank_kernel", "kernel_ms": round(rr_ms, 4),
-                         "candidates": cands, "algorithmic_bytes": rr_bytes,
-                         "achieved_GBps": round(rr_bytes / (rr_ms * 1e-3) / 1e9, 1),
-                         "frac_of_hbm_peak": round(rr_bytes / (rr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "note": "BM25 top-1000 candidates reranked by cosine (dot of unit vectors) "
-                                 "with alpha=0.5 blend to top-10; value = whole pipeline"}
-    # ---- parity spot-check + CPU baseline (rank 0, N = 1 only for the baseline) ----
+    # ---- parity spot-check + CPU baseline (rank 0; the baseline at N = 1 only) ----
     if rank == 0:
         from oracle import oracle as O
-        got = batch.fetch()
-        for b_ in batches[1:]:  # every in-flight batch computed the same results
-            other = b_.fetch()
-            if not all(np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32))
-                       for x, y in zip(got[:4], other[:4])):
-                raise SystemExit("bench.py: in-flight batches disagree")
+        offs, terms, w = qs[0]
+        terms = terms.reshape(-1)
+        got = batches[0].fetch() if rerank else None
+        if not rerank:
+            batches[0].run()
+            got = batches[0].fetch()
+            hp = first_results.get(0)  # (absent with --kernel-leg-only)  # the host-inclusive leg's result for the same query set
+            if hp is not None and not all(np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32))
+                                          for x, y in zip(got[:4], hp[:4])):
+                raise SystemExit("bench.py: host-inclusive and device-resident results disagree")
         nchk = min(args.check, nq)
         if nchk:
             want = O.search_batch([seg], offs[:nchk + 1], terms[:nchk * T], w[:nchk * T], k,
-                                  strategy=O.BM25, n_threads=threads)
+                                  strategy=O.BM25, n_threads=gen_threads)
             ok = True
             for q in range(nchk):
                 n = int(want[3][q])
@@ -318,7 +535,14 @@ def main():
                 print(json.dumps(out))
                 raise SystemExit("bench.py: GPU results differ from the oracle")
         if rerank and nchk:
-            # rerank spot check against the oracle (tolerance 1e-5 on blended scores)
+            # rerank spot check against the oracle (tolerance 1e-5 on blended scores): re-run set 0
+            batches[0].run()
+            d = d_res[0]
+            index.rerank_batch_device(nq, qv.data_ptr(), alpha.data_ptr(), d[0], d[1], d[2], d[3], k, k_out,
+                                      r_doc.data_ptr(), r_seg.data_ptr(), r_score.data_ptr(),
+                                      r_vec.data_ptr(), r_count.data_ptr())
+            torch.cuda.synchronize()
+            got = batches[0].fetch()
             hv = index.segments[0]
             vv = corpus.unit_vectors(n_docs, args.dim, seed=11)
             qh = qv.cpu().numpy()
@@ -336,14 +560,13 @@ def main():
             co, ct, cw = offs[:ncpu + 1], terms[:ncpu * T], w[:ncpu * T]
             ostrat = {"bm25": O.BM25, "wand": O.WAND, "bmw": O.BMW}[args.strategy]
             # strict baseline: scorer only, min_doc_len cached (a cache the reference lacks)
-            reps, t_cpu = 0, 0.0
-            while t_cpu < 10.0 and reps < 50:
+            reps_c, t_cpu = 0, 0.0
+            while t_cpu < 10.0 and reps_c < 50:
                 tc = time.perf_counter()
-                O.search_batch([seg], co, ct, cw, k, strategy=ostrat, n_threads=cores,
-                               cache_min_len=True)
+                O.search_batch([seg], co, ct, cw, k, strategy=ostrat, n_threads=cores, cache_min_len=True)
                 t_cpu += time.perf_counter() - tc
-                reps += 1
-            strict = ncpu * reps / t_cpu
+                reps_c += 1
+            strict = ncpu * reps_c / t_cpu
             # faithful: TermState::new rescans all doc lengths per term per query (wand.rs:111-125)
             nf = min(ncpu, 256)
             tc = time.perf_counter()
@@ -352,7 +575,7 @@ def main():
             faithful = nf / (time.perf_counter() - tc)
             out["cpu_baseline"] = {
                 "value": round(strict, 1), "unit": "queries/s", "cores": cores, "kind": "port",
-                "sample": f"{ncpu} queries of the same batch x {reps} reps, oracle "
+                "sample": f"{ncpu} queries of query set 0 x {reps_c} reps, oracle "
                           f"{args.strategy} (C restatement of searchlite-core's scorer, "
                           f"pre-decoded postings, cached doc lengths and min_doc_len), "
                           f"{cores} threads, one query per thread",
@@ -360,11 +583,19 @@ def main():
                 "faithful_note": "same, but with the reference's per-term O(N) min_doc_len scan "
                                  f"(wand.rs:111-125) on {nf} queries",
                 "gpu_over_cpu": round(value / strict, 1)}
-        print(json.dumps(out), flush=True)
 
-    for b_ in batches:
-        b_.close()
+    for b in batches:
+        b.close()
     index.close()
+    del seg
+
+    # ---- N > 1: the BASELINE configs[3] shape, index-sharded (strong scaling) ----
+    if world > 1 and not args.no_c4 and not rerank:
+        c4, _, _, _ = run_sharded("c4", max(4, min(args.steps, 16)), max(1, min(args.warmup, 3)))
+        if rank == 0:
+            out["c4"] = c4
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -223,6 +223,7 @@ struct slg_batch {
   bool multi = false;    // many-term form of it (slg_score_multi.hpp); else the packed kernel
   uint64_t n_postings = 0, n_postings_essential = 0, n_rounds = 0;
   std::vector<uint64_t> q_postings;  // per query (stats.postings_advanced)
+  bool launched = false;             // slg_batch_run was called at least once
   bool own_stream_set = false;       // slg_batch_set_stream: run on `stream` instead of the index's
   hipStream_t stream = nullptr;
   DevBuf d_desc;                     // packed descriptors
@@ -1181,6 +1182,7 @@ int slg_batch_run(slg_batch *b) {
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
     hipStream_t st = batch_stream(b);
+    b->launched = true;
     if (b->nq == 0) return;
     if (b->n_slices == 0) SLG_HIP(hipMemsetAsync(b->d_q_scored.p, 0, (size_t)b->nq * 4, st));
     if (b->n_slices > 0) {
@@ -1220,7 +1222,7 @@ int slg_batch_run(slg_batch *b) {
       sp.k = b->k;
       sp.stamps = nullptr;
 #ifdef SLG_STAMPS
-      b->d_stamps.alloc((size_t)b->n_slices * 64);
+      b->d_stamps.alloc((size_t)b->n_slices * 96);
       sp.stamps = b->d_stamps.as<unsigned long long>();
 #endif
       std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
@@ -1358,7 +1360,7 @@ int slg_batch_info(const slg_batch *b, uint64_t *n_postings, uint32_t *n_slices,
 int slg_debug_read_stamps(slg_batch *b, unsigned long long *out, uint32_t n_slices) {
   return guarded([&] {
     SLG_HIP(hipStreamSynchronize(batch_stream(b)));
-    SLG_HIP(hipMemcpy(out, b->d_stamps.p, (size_t)n_slices * 64, hipMemcpyDeviceToHost));
+    SLG_HIP(hipMemcpy(out, b->d_stamps.p, (size_t)n_slices * 96, hipMemcpyDeviceToHost));
   });
 }
 #endif
@@ -1369,7 +1371,7 @@ int slg_batch_set_stream(slg_batch *b, void *hip_stream) {
     slg_index *ix = b->idx;
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
-    SLG_HIP(hipStreamSynchronize(batch_stream(b)));  // work already queued finishes first
+    if (b->launched) SLG_HIP(hipStreamSynchronize(batch_stream(b)));  // queued work finishes first
     b->own_stream_set = hip_stream != SLG_OWN_STREAM;
     b->stream = b->own_stream_set ? (hipStream_t)hip_stream : nullptr;
   });

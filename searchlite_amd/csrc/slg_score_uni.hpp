@@ -44,12 +44,13 @@ constexpr int kUniSlots = 8;                 // 64-posting slots per round
 constexpr int kUniCap = kUniSlots * 64;      // postings per round
 constexpr int kUniMaxLists = 4;              // lists per sub-query (one filter bit each)
 constexpr int kJoinWords = 1024;             // filter words = 8192 doc fields; also the join queue
-static_assert(kJoinWords * 4 >= kUniCap * 8, "the join queue (doc, score per posting) overlays the filter");
+constexpr int kJoinPairs = 24;               // queue sizes up to this are joined all-pairs in registers
+static_assert(kJoinWords * 4 >= kUniCap * 8, "the join queue ({doc, list} per posting) overlays the filter");
 // k <= 256 (KREGS <= 4): buffered top-k in LDS (BufTopK); larger k: every doc above the seed
 // threshold goes to the slice's candidate region and select_topk_kernel picks the k best
 constexpr bool uni_buffered(int kregs) { return kregs <= 4; }
-constexpr int uni_wave_lds(int kregs) {
-  return kJoinWords * 4 + (uni_buffered(kregs) ? 128 * kregs * 8 : 0);
+constexpr int uni_wave_lds(int kregs) {  // filter / queue keys, queue scores, top-k buffer
+  return kJoinWords * 4 + kUniCap * 4 + (uni_buffered(kregs) ? 128 * kregs * 8 : 0);
 }
 
 template <int KREGS>
@@ -64,7 +65,8 @@ __global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
   constexpr bool BUF = uni_buffered(KREGS);
   uint32_t *flt = reinterpret_cast<uint32_t *>(smem);
   uint4 *flt4 = reinterpret_cast<uint4 *>(smem);
-  uint2 *queue = reinterpret_cast<uint2 *>(smem);  // overlays flt (see P4)
+  uint2 *qkey = reinterpret_cast<uint2 *>(smem);   // {doc, list} of queued postings; overlays flt (see P4)
+  float *qx = reinterpret_cast<float *>(smem + kJoinWords * 4);  // their scores
 
   const uint32_t sqi = rfl(p.slice_sq[slice]);
   const RoundQuery s = p.sq[sqi];
@@ -98,7 +100,7 @@ __global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
   const uint32_t dcnt = __shfl(bflat, (lane + T) & 63u, 64) - bflat;
 
   BufTopK<BUF ? KREGS : 1> btop;  // k <= 256; for larger k only its threshold is used
-  btop.init(reinterpret_cast<uint64_t *>(smem + kJoinWords * 4));
+  btop.init(reinterpret_cast<uint64_t *>(smem + kJoinWords * 4 + kUniCap * 4));
   // k > 256: the slice's candidate region starts at (sub-query base) + (postings of all lists
   // before the slice's first round) and can hold one entry per posting of the slice
   uint32_t ccur = 0;
@@ -124,8 +126,9 @@ __global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
   }
   uint32_t n_scored = 0;
 #ifdef SLG_STAMPS
-  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_ins = 0;
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_ins = 0, st_queued = 0;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+  const unsigned long long st_begin = wall_clock64();  // 100 MHz, device-wide
 #endif
 
   // One round's postings: slot jj holds <= 64 postings of one list.  A slot is described by one
@@ -228,18 +231,20 @@ __global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
     }
   };
 
-  // ---- offer finished (doc, score) pairs of the lanes in `own` to the top-k ----
-  auto offer = [&](const bool own, const float score, const uint32_t doc) {
+  // ---- candidates -> top-k.  Cheap necessary condition first (an IEEE compare with the
+  //      threshold's score: total_cmp order implies it), exact compare + append in take_checked.
+  //      ONE take_checked site per candidate source (the ranking code of BufTopK::compact is large). ----
+  auto threshold_score = [&]() {  // score part of the current threshold as a float (-inf: none)
+    const uint32_t hi = (uint32_t)(btop.th >> 32);
+    return hi < 0x00800000u ? -INFINITY : key_to_float((int32_t)(hi ^ 0x80000000u));
+  };
+  auto take_checked = [&](const bool cand, const float score, const uint32_t doc) {
     const uint32_t ok = ordered_score(score);
-    const bool ps = own && btop.passes(ok, ~doc);
-    const uint64_t m = __ballot(ps);
-    if (m == 0ull) return;  // the common case: nobody beats the threshold
-#ifdef SLG_STAMPS
-    st_ins += (uint32_t)__popcll(m);
-#endif
+    const bool ps = cand && btop.passes(ok, ~doc);
     if constexpr (BUF) {
       btop.append_checked(ps, ok, ~doc, k, lane, (const uint32_t *)gdel);
-    } else {
+    } else {  // the candidate region holds one entry per posting
+      const uint64_t m = __ballot(ps);
       const uint32_t at = ccur + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
       if (ps) creg[at] = make_uint2(ok, doc);
@@ -247,90 +252,146 @@ __global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
     }
   };
 
-  // ---- score the postings of `e` (all docs of a doc range; idle lanes hold kDocEnd) ----
+  // ---- score the postings of `e` (all docs of a doc range; idle lanes hold kDocEnd).  Lane sets
+  //      are kept as 64-bit wave masks (scalar registers), the per-slot code is branch-free. ----
   auto accumulate = [&](const URound &e) {
     SLG_STAMP(1);
-    if (T == 1) {  // one list: every posting is its doc's only one
+    uint64_t validm[NS], sharedm[NS];  // sharedm: my doc is (or aliases) a doc of another list
+    uint32_t n = 0;                    // queued postings
+#pragma unroll
+    for (int jj = 0; jj < NS; jj++) {
+      validm[jj] = __ballot(e.doc[jj] != kDocEnd);
+      sharedm[jj] = 0ull;
+    }
+    if (T > 1) {
+      // P0: clear the filter
+      flt4[lane] = make_uint4(0u, 0u, 0u, 0u);
+      flt4[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
+      flt4[lane + 128] = make_uint4(0u, 0u, 0u, 0u);
+      flt4[lane + 192] = make_uint4(0u, 0u, 0u, 0u);
+      wave_fence();
+      // P1: one bit per posting: word = doc mod 1024, field = (doc / 1024) mod 8, bit = list
 #pragma unroll
       for (int jj = 0; jj < NS; jj++) {
-        const bool v = e.doc[jj] != kDocEnd;
-        n_scored += (uint32_t)__popcll(__ballot(v));
-        offer(v, 0.0f + e.imp[jj], e.doc[jj]);
+        const uint32_t lbit = 1u << rl(e.st, e.dbase + jj);  // uniform
+        if (e.doc[jj] != kDocEnd)
+          atomicOr(&flt[e.doc[jj] & (kJoinWords - 1)], lbit << ((e.doc[jj] >> 8) & 0x1Cu));
       }
-      return;
-    }
-    // P0: clear the filter
-    flt4[lane] = make_uint4(0u, 0u, 0u, 0u);
-    flt4[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
-    flt4[lane + 128] = make_uint4(0u, 0u, 0u, 0u);
-    flt4[lane + 192] = make_uint4(0u, 0u, 0u, 0u);
-    wave_fence();
-    // P1: one bit per posting: word = doc mod 1024, field = (doc / 1024) mod 8, bit = list
-    uint32_t sh[NS];
+      wave_fence();
+      SLG_STAMP(2);
+      // P2: the lists that hold my doc (or an alias of it).  Idle lanes read word 1023.
+      uint32_t fin[NS];
 #pragma unroll
-    for (int jj = 0; jj < NS; jj++) {
-      const uint32_t tj = rl(e.st, e.dbase + jj);
-      sh[jj] = ((e.doc[jj] >> 8) & 0x1Cu);  // 4 * field
-      if (e.doc[jj] != kDocEnd) atomicOr(&flt[e.doc[jj] & (kJoinWords - 1)], (1u << tj) << sh[jj]);
-    }
-    wave_fence();
-    SLG_STAMP(2);
-    // P2: the lists that hold my doc (or an alias of it)
-    uint32_t fin[NS];
+      for (int jj = 0; jj < NS; jj++) fin[jj] = flt[e.doc[jj] & (kJoinWords - 1)];
+      wave_fence();  // the queue below overlays the filter: all reads are issued before its writes
+      SLG_STAMP(3);
+      // P3: shared docs (and aliases) are queued, in slot = list order
 #pragma unroll
-    for (int jj = 0; jj < NS; jj++) fin[jj] = flt[e.doc[jj] & (kJoinWords - 1)];
-    wave_fence();  // the queue below overlays the filter: all reads are issued before its writes
-    SLG_STAMP(3);
-    // P3 / P4: singles are scored in registers; shared docs (and aliases) are queued
-    uint32_t n = 0;
-#pragma unroll
-    for (int jj = 0; jj < NS; jj++) {
-      const uint32_t tj = rl(e.st, e.dbase + jj);
-      const bool v = e.doc[jj] != kDocEnd;
-      const bool shared = v && (((fin[jj] >> sh[jj]) & 0xFu) & ~(1u << tj)) != 0u;
-      const uint64_t m = __ballot(shared);
-      if (m != 0ull) {
-        const uint32_t at = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (shared) queue[at] = make_uint2(e.doc[jj], __float_as_uint(e.imp[jj]));
-        n += (uint32_t)__popcll(m);
+      for (int jj = 0; jj < NS; jj++) {
+        const uint32_t tj = rl(e.st, e.dbase + jj);  // uniform
+        const uint32_t others = 0xFu & ~(1u << tj);
+        const uint32_t fld = (fin[jj] >> ((e.doc[jj] >> 8) & 0x1Cu)) & others;
+        const uint64_t m = __ballot(fld != 0u) & validm[jj];
+        sharedm[jj] = m;
+        if (m != 0ull) {
+          const uint32_t at = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          if ((m >> lane) & 1ull) {
+            qkey[at] = make_uint2(e.doc[jj], tj);
+            qx[at] = e.imp[jj];
+          }
+          n += (uint32_t)__popcll(m);
+        }
       }
-      const bool single = v && !shared;
-      n_scored += (uint32_t)__popcll(__ballot(single));
-      offer(single, 0.0f + e.imp[jj], e.doc[jj]);
+      wave_fence();
     }
-    wave_fence();
     SLG_STAMP(4);
-    // P4: join.  Queue order = slot order = list order, so summing the entries of my doc in
-    // queue order gives ((0.0 + x_a) + x_b) + ... in term order; the first entry of a doc owns it.
-    for (uint32_t base = 0; base < n; base += 64) {
-      const uint32_t idx = base + lane;
+#ifdef SLG_STAMPS
+    st_queued += n;
+#endif
+    // singles: the doc occurs in this list only; score = 0.0 + w*impact (wand.rs:539)
+    {
+      const float thf = threshold_score();
+      uint64_t hotm[NS];
+      uint64_t anyhot = 0ull;
+#pragma unroll
+      for (int jj = 0; jj < NS; jj++) {
+        const uint64_t singles = validm[jj] & ~sharedm[jj];
+        n_scored += (uint32_t)__popcll(singles);
+        hotm[jj] = __ballot(0.0f + e.imp[jj] >= thf) & singles;
+        anyhot |= hotm[jj];
+      }
+      if (anyhot != 0ull) {  // rank-and-trim may be needed between slots: one site, the slot's
+                             // registers are selected at run time
+#pragma unroll 1
+        for (uint32_t it = 0; it < (uint32_t)NS; it++) {
+          float x = e.imp[0];
+          uint32_t dc = e.doc[0];
+          uint64_t hm = hotm[0];
+#pragma unroll
+          for (int j = 1; j < NS; j++) {
+            x = it == (uint32_t)j ? e.imp[j] : x;
+            dc = it == (uint32_t)j ? e.doc[j] : dc;
+            hm = it == (uint32_t)j ? hotm[j] : hm;
+          }
+          if (hm == 0ull) continue;
+#ifdef SLG_STAMPS
+          st_ins += (uint32_t)__popcll(hm);
+#endif
+          take_checked((hm >> lane) & 1ull, 0.0f + x, dc);
+        }
+      }
+    }
+    SLG_STAMP(5);
+    // P4: join.  The queue is sorted by (list, doc): slots are in list order and a list's
+    // postings in doc order.  A doc's sum is ((0.0 + x_a) + x_b) + ... over the lists that hold it,
+    // in list order (= the reference's term order); its entry in the lowest list owns the result.
+    // Receivers in blocks of 64 lanes.
+    for (uint32_t rb = 0; rb < n; rb += 64) {
+      const uint32_t idx = rb + lane;
       const bool have = idx < n;
-      const uint2 me = have ? queue[idx] : make_uint2(kDocEnd, 0u);
+      const uint2 me = have ? qkey[idx] : make_uint2(kDocEnd, 0u);
+      const float mx = have ? qx[idx] : 0.0f;
       float acc = 0.0f;
-      bool earlier = false;
-      if (n <= 64u) {  // the usual case: the senders come from registers
+      bool lower = false;  // a lower list holds my doc
+      if (n <= (uint32_t)kJoinPairs) {
+        // few entries (the usual case): all pairs, the senders read from registers lane by lane
         for (uint32_t l = 0; l < n; l++) {
           const uint32_t dl = rl(me.x, l);
-          const float xl = __uint_as_float(rl(me.y, l));
+          const float xl = __uint_as_float(rl(__float_as_uint(mx), l));
           const bool hit = dl == me.x;
           acc = hit ? acc + xl : acc;
-          earlier = earlier || (hit && l < lane);
+          lower = lower || (hit && l < lane);
         }
       } else {
-        for (uint32_t l = 0; l < n; l++) {
-          const uint2 sn = queue[l];  // same address in every lane: an LDS broadcast
-          const bool hit = sn.x == me.x;
-          acc = hit ? acc + __uint_as_float(sn.y) : acc;
-          earlier = earlier || (hit && l < idx);
+        // many entries (dense lists): for every list u in order, a binary search of (u, my doc)
+        const uint32_t steps = 32u - (uint32_t)__builtin_clz(n);  // halvings that empty [0, n)
+        for (uint32_t u = 0; u < T; u++) {
+          const uint64_t want = ((uint64_t)u << 32) | me.x;
+          uint32_t lo = 0, hi = n;
+          for (uint32_t st = 0; st < steps; st++) {
+            const uint32_t mid = (lo + hi) >> 1;  // < n while lo < hi
+            const uint2 kk = qkey[mid < n ? mid : n - 1u];
+            const bool less = ((((uint64_t)kk.y) << 32) | kk.x) < want;
+            const bool open = lo < hi;
+            lo = open && less ? mid + 1u : lo;
+            hi = open && !less ? mid : hi;
+          }
+          const uint32_t at = lo < n ? lo : n - 1u;
+          const uint2 kk = qkey[at];
+          const float xu = qx[at];
+          const bool mine = me.y == u;
+          const bool hit = have && (mine || (lo < n && kk.x == me.x && kk.y == u));
+          acc = hit ? acc + (mine ? mx : xu) : acc;
+          lower = lower || (hit && u < me.y);
         }
       }
-      const bool owner = have && !earlier;
-      n_scored += (uint32_t)__popcll(__ballot(owner));
-      offer(owner, acc, me.x);
+      const uint64_t ownerm = __ballot(have && !lower);
+      n_scored += (uint32_t)__popcll(ownerm);
+      if ((__ballot(acc >= threshold_score()) & ownerm) != 0ull) take_checked((ownerm >> lane) & 1ull, acc, me.x);
     }
     wave_fence();
-    SLG_STAMP(5);
+    SLG_STAMP(6);
   };
 
   // lane t < T: cut points of round rr and rr + 1 of this slice
@@ -364,7 +425,7 @@ __global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
 #ifdef SLG_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-    SLG_STAMP(6);
+    SLG_STAMP(7);
     if (rr + 1 < n_r) {  // prefetch the next round
       const uint32_t nx = rr + 1, db = (nx & 7u) * 8u;
       if (db == 0) describe_group(G, nx);
@@ -428,10 +489,14 @@ __global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
   }
   if (p.q_scored && lane == 0 && n_scored) atomicAdd(&p.q_scored[s.q], n_scored);
 #ifdef SLG_STAMPS
-  SLG_STAMP(7);
-  st_acc[7] = st_ins;
-  if (p.stamps && lane == 0)
-    for (int i = 0; i < 8; i++) p.stamps[(size_t)slice * 8 + i] = st_acc[i];
+  const unsigned long long st_extra = st_ins | (st_queued << 32);
+  if (p.stamps && lane == 0) {
+    for (int i = 0; i < 8; i++) p.stamps[(size_t)slice * 12 + i] = st_acc[i];
+    p.stamps[(size_t)slice * 12 + 8] = st_extra;
+    p.stamps[(size_t)slice * 12 + 9] = st_begin;
+    p.stamps[(size_t)slice * 12 + 10] = wall_clock64();
+    p.stamps[(size_t)slice * 12 + 11] = ((unsigned long long)n_r << 32) | (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+  }
 #endif
 }
 

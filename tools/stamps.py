@@ -17,14 +17,44 @@ for _ in range(3):
 b.sync()
 info = b.info()
 n = info["n_slices"]
-out = np.zeros((n, 8), dtype=np.uint64)
+out = np.zeros((n, 12), dtype=np.uint64)
 L = N.load()
 L.slg_debug_read_stamps.restype = C.c_int
 L.slg_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 assert L.slg_debug_read_stamps(b._h, out.ctypes.data, n) == 0
-names = ["0 plan/issue next", "1 chunk setup", "2 P0+P1 clear+or", "3 P2 read back", "4 P3 singles+queue",
-         "5 P4 join", "6 wait loads+copy", "7 tail"]
-ins = out[:, 7].copy(); out[:, 7] = 0
+names = ["0 plan/issue next", "1 chunk setup", "2 P0+P1 clear+or", "3 P2 read back", "4 P3 queue",
+         "5 singles", "6 P4 join", "7 wait loads+copy"]
+ins = out[:, 8] & np.uint64(0xFFFFFFFF); queued = out[:, 8] >> np.uint64(32)
+t0s, t1s, nr = out[:, 9].astype(np.int64), out[:, 10].astype(np.int64), (out[:, 11] >> np.uint64(32)).astype(np.int64)
+xcc = (out[:, 11] & np.uint64(0xF)).astype(np.int64)
+out = out[:, :8]
+b0 = t0s.min()
+t0s -= b0
+t1s -= b0
+span = t1s.max()
+print("kernel span (10 ns ticks)", span, "sum of slice durations", int((t1s - t0s).sum()),
+      "=> mean waves in flight", float((t1s - t0s).sum()) / span, "of", 256 * 4 * 5, "wave slots at 5/SIMD")
+edges = np.linspace(0, span, 21)
+for a, b in zip(edges[:-1], edges[1:]):
+    mid = (a + b) / 2
+    live = ((t0s <= mid) & (t1s > mid)).sum()
+    started = ((t0s >= a) & (t0s < b)).sum()
+    print(f"  t {a / span * 100:5.1f}%..{b / span * 100:5.1f}%: waves alive at mid {live:6d} started {started:6d}")
+for r in sorted(set(nr.tolist())):
+    m = nr == r
+    print(f"  slices with {r:2d} rounds: {m.sum():6d}, mean duration {float((t1s - t0s)[m].mean()):10.0f}, per round {float((t1s - t0s)[m].mean()) / max(r, 1):8.0f}")
+order = np.argsort(-(t1s - t0s))[:12]
+print("longest slices: dur(10ns) start end rounds queued inserts | phase cycles 0..7")
+for i in order:
+    print(f"  {int(t1s[i] - t0s[i]):6d} {int(t0s[i]):6d} {int(t1s[i]):6d} {int(nr[i]):3d} {int(queued[i]):6d} {int(ins[i]):5d} | "
+          + " ".join(f"{int(v):8d}" for v in out[i]))
+late = np.argsort(-t1s)[:12]
+print("last slices to finish:")
+for i in late:
+    print(f"  {int(t1s[i] - t0s[i]):6d} {int(t0s[i]):6d} {int(t1s[i]):6d} {int(nr[i]):3d} {int(queued[i]):6d} {int(ins[i]):5d} | "
+          + " ".join(f"{int(v):8d}" for v in out[i]))
+print("slices per XCC id", np.bincount(xcc, minlength=8).tolist())
+print("queued postings (shared docs + aliases)", int(queued.sum()), "=", float(queued.sum()) / info["n_postings"] * 100, "% of postings")
 tot = out.sum()
 print("inserts/slice mean", ins.mean(), "max", ins.max(), "p50", np.median(ins), "p90", np.percentile(ins, 90))
 print("slices", n, "postings", info["n_postings"], "mean cycles/slice", tot / n)

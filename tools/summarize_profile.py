@@ -10,18 +10,20 @@ import sys
 
 d = sys.argv[1]
 print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
-with open(os.path.join(d, "trace", "c2_kernel_stats.csv")) as f:
+with open(os.path.join(d, "trace", "run_kernel_stats.csv")) as f:
     for row in csv.DictReader(f):
         print(f'{row["Name"][:70]:70s} calls {row["Calls"]:>4s} avg_ns {float(row["AverageNs"]):12.1f} '
               f'pct {row["Percentage"]}')
 vals = {}
+kname = None
 for p in ("pmc_a", "pmc_b", "pmc_c", "pmc_d"):
-    path = os.path.join(d, p, "c2_counter_collection.csv")
+    path = os.path.join(d, p, "run_counter_collection.csv")
     if not os.path.exists(path):
         continue
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        if "score_rounds" in r["Kernel_Name"] or "score_uniform" in r["Kernel_Name"]:
+        if "score_multi" in r["Kernel_Name"] or "score_uniform" in r["Kernel_Name"]:
+            kname = r["Kernel_Name"].split("(")[0]
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
             vals["VGPR_Count"] = r.get("VGPR_Count")
             vals["SGPR_Count"] = r.get("SGPR_Count")
@@ -34,8 +36,8 @@ for k in sorted(vals):
 if "FETCH_SIZE" in vals:
     fetch = vals["FETCH_SIZE"] * 1024 * 2  # gfx950: FETCH_SIZE reports half of a wide stream
     write = vals.get("WRITE_SIZE", 0.0) * 1024
-    out = {"kernel": "score_uniform_kernel", "fetch_bytes_corrected": fetch, "write_bytes": write,
-           "hbm_bytes_per_launch": fetch + write,
+    out = {"kernel": kname, "fetch_bytes_corrected": fetch, "write_bytes": write,
+           "hbm_bytes_per_launch": fetch + write, "source": "profile (rocprofv3 --pmc, tools/profile.sh)",
            "note": "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB counters, "
                    "separate --pmc passes"}
     print("== HBM traffic per launch ==")
