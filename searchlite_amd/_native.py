@@ -65,6 +65,11 @@ _lib = None
 
 
 def lib_path() -> str:
+    """The product library; SLG_LIB_TAG=<tag> selects an experiment build
+    libsearchlite_gpu_<tag>.so (tools/build_variant.sh, A/B timing on one box)."""
+    tag = os.environ.get("SLG_LIB_TAG")
+    if tag:
+        return os.path.join(_build.LIBDIR, f"libsearchlite_gpu_{tag}.so")
     return _build.GPU_LIB
 
 

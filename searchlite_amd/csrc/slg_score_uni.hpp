@@ -76,8 +76,7 @@ __global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
   const uint32_t r_end = rfl(s.n_rounds) < r0 + rps ? rfl(s.n_rounds) : r0 + rps;
   const uint32_t n_r = r_end - r0;
   const SegDev sd = p.segs[s.seg];
-  const gu32_t gdocs = (gu32_t)sd.docs;
-  const gf32_t gimps = (gf32_t)sd.imps;
+  const gu64_t gpost = (gu64_t)sd.post;
   // accept(): tombstones, or the reject bitmap (deleted | ~filter) of the query's doc filter
   const uint32_t fid = rfl(s.filter);
   const gu32_t gdel = (gu32_t)(fid ? p.reject_table[(size_t)(fid - 1) * p.n_segs + s.seg] : sd.deleted);
@@ -124,7 +123,10 @@ __global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
     const bool anyneg = __ballot(lane < T && !(my_w >= 0.0f)) != 0ull;
     if (best > 0.0f && !anyneg) btop.set_floor(best);
   }
+  // distinct docs scored (QueryStats.scored_docs): every posting of the slice is one, except the
+  // queued ones, of which only the owners count (added in the join)
   uint32_t n_scored = 0;
+  for (uint32_t t = 0; t < T; t++) n_scored += rl(bflat, n_r * T + t) - rl(bflat, t);
 #ifdef SLG_STAMPS
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_ins = 0, st_queued = 0;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
@@ -211,8 +213,9 @@ __global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
 #pragma unroll
     for (int jj = 0; jj < NS; jj++) {
       const uint64_t base = ((uint64_t)rl(d.hi, dbase + jj) << 32) | rl(d.lo, dbase + jj);
-      r.doc[jj] = gdocs[base + lane];
-      r.imp[jj] = gimps[base + lane];
+      const uint64_t pd = gpost[base + lane];  // one 8-byte load per posting: 512 B per slot
+      r.doc[jj] = (uint32_t)pd;
+      r.imp[jj] = __uint_as_float((uint32_t)(pd >> 32));
     }
   };
   // ---- dst = the loaded round src, ready to accumulate: lanes beyond each slot's count become
@@ -256,13 +259,16 @@ __global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
   //      are kept as 64-bit wave masks (scalar registers), the per-slot code is branch-free. ----
   auto accumulate = [&](const URound &e) {
     SLG_STAMP(1);
-    uint64_t validm[NS], sharedm[NS];  // sharedm: my doc is (or aliases) a doc of another list
-    uint32_t n = 0;                    // queued postings
+    uint64_t sharedm[NS];  // lanes whose doc is (or aliases) a doc of another list
+    uint32_t n = 0;        // queued postings
+    // the cheap necessary condition of a top-k candidate, for all postings (independent of the
+    // filter: evaluated while its LDS traffic is in flight).  Idle lanes carry impact * w of
+    // whatever they loaded: masked by the doc test below.
+    const float thf = threshold_score();
+    uint64_t hotm[NS];
+    uint64_t anyhot = 0ull;
 #pragma unroll
-    for (int jj = 0; jj < NS; jj++) {
-      validm[jj] = __ballot(e.doc[jj] != kDocEnd);
-      sharedm[jj] = 0ull;
-    }
+    for (int jj = 0; jj < NS; jj++) sharedm[jj] = 0ull;
     if (T > 1) {
       // P0: clear the filter
       flt4[lane] = make_uint4(0u, 0u, 0u, 0u);
@@ -284,6 +290,11 @@ __global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
 #pragma unroll
       for (int jj = 0; jj < NS; jj++) fin[jj] = flt[e.doc[jj] & (kJoinWords - 1)];
       wave_fence();  // the queue below overlays the filter: all reads are issued before its writes
+#pragma unroll
+      for (int jj = 0; jj < NS; jj++) {
+        hotm[jj] = __ballot(0.0f + e.imp[jj] >= thf);
+        anyhot |= hotm[jj];
+      }
       SLG_STAMP(3);
       // P3: shared docs (and aliases) are queued, in slot = list order
 #pragma unroll
@@ -291,7 +302,7 @@ __global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
         const uint32_t tj = rl(e.st, e.dbase + jj);  // uniform
         const uint32_t others = 0xFu & ~(1u << tj);
         const uint32_t fld = (fin[jj] >> ((e.doc[jj] >> 8) & 0x1Cu)) & others;
-        const uint64_t m = __ballot(fld != 0u) & validm[jj];
+        const uint64_t m = __ballot((fld != 0u) & (e.doc[jj] != kDocEnd));
         sharedm[jj] = m;
         if (m != 0ull) {
           const uint32_t at = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
@@ -304,42 +315,39 @@ __global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
         }
       }
       wave_fence();
+      n_scored -= n;
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < NS; jj++) {
+        hotm[jj] = __ballot(0.0f + e.imp[jj] >= thf);
+        anyhot |= hotm[jj];
+      }
     }
     SLG_STAMP(4);
 #ifdef SLG_STAMPS
     st_queued += n;
 #endif
-    // singles: the doc occurs in this list only; score = 0.0 + w*impact (wand.rs:539)
-    {
-      const float thf = threshold_score();
-      uint64_t hotm[NS];
-      uint64_t anyhot = 0ull;
-#pragma unroll
-      for (int jj = 0; jj < NS; jj++) {
-        const uint64_t singles = validm[jj] & ~sharedm[jj];
-        n_scored += (uint32_t)__popcll(singles);
-        hotm[jj] = __ballot(0.0f + e.imp[jj] >= thf) & singles;
-        anyhot |= hotm[jj];
-      }
-      if (anyhot != 0ull) {  // rank-and-trim may be needed between slots: one site, the slot's
-                             // registers are selected at run time
+    // singles: the doc occurs in this list only; score = 0.0 + w*impact (wand.rs:539).  Rarely
+    // does any posting of a round reach the threshold at all.
+    if (anyhot != 0ull) {  // rank-and-trim may be needed between slots: one site, the slot's
+                           // registers are selected at run time
 #pragma unroll 1
-        for (uint32_t it = 0; it < (uint32_t)NS; it++) {
-          float x = e.imp[0];
-          uint32_t dc = e.doc[0];
-          uint64_t hm = hotm[0];
+      for (uint32_t it = 0; it < (uint32_t)NS; it++) {
+        float x = e.imp[0];
+        uint32_t dc = e.doc[0];
+        uint64_t hm = hotm[0] & ~sharedm[0];
 #pragma unroll
-          for (int j = 1; j < NS; j++) {
-            x = it == (uint32_t)j ? e.imp[j] : x;
-            dc = it == (uint32_t)j ? e.doc[j] : dc;
-            hm = it == (uint32_t)j ? hotm[j] : hm;
-          }
-          if (hm == 0ull) continue;
-#ifdef SLG_STAMPS
-          st_ins += (uint32_t)__popcll(hm);
-#endif
-          take_checked((hm >> lane) & 1ull, 0.0f + x, dc);
+        for (int j = 1; j < NS; j++) {
+          x = it == (uint32_t)j ? e.imp[j] : x;
+          dc = it == (uint32_t)j ? e.doc[j] : dc;
+          hm = it == (uint32_t)j ? hotm[j] & ~sharedm[j] : hm;
         }
+        hm &= __ballot(dc != kDocEnd);
+        if (hm == 0ull) continue;
+#ifdef SLG_STAMPS
+        st_ins += (uint32_t)__popcll(hm);
+#endif
+        take_checked((hm >> lane) & 1ull, 0.0f + x, dc);
       }
     }
     SLG_STAMP(5);
@@ -453,7 +461,7 @@ __global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
           chunk = rem < mslots * 64u ? rem : mslots * 64u;
         }
         uint32_t lastdoc = kDocEnd;
-        if (chunk < rem) lastdoc = gdocs[my_off + ocur + chunk - 1];
+        if (chunk < rem) lastdoc = (uint32_t)gpost[my_off + ocur + chunk - 1];
         describe_chunk(C, ocur, chunk);
         ew.nslots = C.nsl;
         issue(ew, C, 0);
