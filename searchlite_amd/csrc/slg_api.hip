@@ -181,7 +181,7 @@ struct SegHost {
   uint64_t n_postings = 0;
   std::vector<uint64_t> term_offsets;
   std::vector<float> champ;  // host mirror of d_champ [V * kChampions] (query planning)
-  DevBuf d_post, d_deleted, d_champ;  // d_post: {doc, impact} per posting, 8 bytes
+  DevBuf d_docs, d_imps, d_deleted, d_champ;
   // vectors
   uint32_t vec_dim = 0, vec_rows = 0;
   int32_t vec_metric = 0;
@@ -382,14 +382,11 @@ void stage_segment(slg_index *ix, SegHost &sh, const slg_segment_desc &d) {
 
   // + 64 entries: the scoring kernels load whole 64-lane slots (lanes past a slot's count are
   // masked after the load), so a slot that starts near the end of the arrays reads past P
-  sh.d_post.alloc((P + 64) * 8);
-  {
-    std::vector<uint2> pad(64, make_uint2(0xFFFFFFFFu, 0u));
-    SLG_HIP(hipMemcpyAsync(static_cast<char *>(sh.d_post.p) + P * 8, pad.data(), 64 * 8,
-                           hipMemcpyHostToDevice, st));
-    SLG_HIP(hipStreamSynchronize(st));  // pad is a local
-  }
-  ix->device_bytes += sh.d_post.bytes;
+  sh.d_docs.alloc((P + 64) * 4);
+  sh.d_imps.alloc((P + 64) * 4);
+  SLG_HIP(hipMemsetAsync(static_cast<char *>(sh.d_docs.p) + P * 4, 0xFF, 64 * 4, st));
+  SLG_HIP(hipMemsetAsync(static_cast<char *>(sh.d_imps.p) + P * 4, 0, 64 * 4, st));
+  ix->device_bytes += sh.d_docs.bytes + sh.d_imps.bytes;
   if (d.deleted) {
     const size_t words = ((size_t)d.n_docs + 31) / 32;
     std::vector<uint32_t> w(words ? words : 1, 0u);
@@ -400,11 +397,10 @@ void stage_segment(slg_index *ix, SegHost &sh, const slg_segment_desc &d) {
   }
   if (P > 0) {
     // temporaries used only by the staging kernel
-    DevBuf d_docs, d_tfs, d_offs, d_idf, d_tfield, d_avgdl, d_lenptrs;
+    DevBuf d_tfs, d_offs, d_idf, d_tfield, d_avgdl, d_lenptrs;
     std::vector<DevBuf> d_lens(d.n_fields);
-    d_docs.alloc(P * 4);
     d_tfs.alloc(P * 4);
-    SLG_HIP(hipMemcpyAsync(d_docs.p, d.doc_ids, P * 4, hipMemcpyHostToDevice, st));
+    SLG_HIP(hipMemcpyAsync(sh.d_docs.p, d.doc_ids, P * 4, hipMemcpyHostToDevice, st));
     SLG_HIP(hipMemcpyAsync(d_tfs.p, d.tfs, P * 4, hipMemcpyHostToDevice, st));
     d_offs.alloc(((size_t)d.n_terms + 1) * 8);
     SLG_HIP(hipMemcpyAsync(d_offs.p, sh.term_offsets.data(), ((size_t)d.n_terms + 1) * 8,
@@ -442,7 +438,7 @@ void stage_segment(slg_index *ix, SegHost &sh, const slg_segment_desc &d) {
     sp.n_terms = d.n_terms;
     sp.n_docs = d.n_docs;
     sp.term_offsets = d_offs.as<uint64_t>();
-    sp.docs = d_docs.as<uint32_t>();
+    sp.docs = sh.d_docs.as<uint32_t>();
     sp.tfs = d_tfs.as<uint32_t>();
     sp.term_idf = d_idf.as<float>();
     sp.term_field = d.term_field ? d_tfield.as<uint16_t>() : nullptr;
@@ -450,7 +446,7 @@ void stage_segment(slg_index *ix, SegHost &sh, const slg_segment_desc &d) {
     sp.field_avgdl = d_avgdl.as<float>();
     sp.k1 = d.k1;
     sp.b = d.b;
-    sp.post = sh.d_post.as<uint2>();
+    sp.imps = sh.d_imps.as<float>();
     const uint64_t want = (P + 255) / 256;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(want, 256ull * 32);
     hipLaunchKernelGGL(slg::stage_impacts_kernel, dim3(blocks), dim3(256), 0, st, sp);
@@ -460,7 +456,8 @@ void stage_segment(slg_index *ix, SegHost &sh, const slg_segment_desc &d) {
       ix->device_bytes += sh.d_champ.bytes;
       slg::ChampParams cp{};
       cp.term_offsets = d_offs.as<uint64_t>();
-      cp.post = sh.d_post.as<uint2>();
+      cp.imps = sh.d_imps.as<float>();
+      cp.docs = sh.d_docs.as<uint32_t>();
       cp.deleted = sh.d_deleted.as<uint32_t>();
       cp.champ = sh.d_champ.as<float>();
       cp.n_terms = d.n_terms;
@@ -578,7 +575,8 @@ slg_index *slg_index_create_tuned(const slg_segment_desc *segs, uint32_t n_segs,
     std::vector<slg::SegDev> sd(n_segs);
     std::vector<slg::VecSegDev> vd(n_segs);
     for (uint32_t s = 0; s < n_segs; s++) {
-      sd[s].post = ix->segs[s]->d_post.as<uint2>();
+      sd[s].docs = ix->segs[s]->d_docs.as<uint32_t>();
+      sd[s].imps = ix->segs[s]->d_imps.as<float>();
       sd[s].deleted = ix->segs[s]->d_deleted.as<uint32_t>();
       sd[s].champ = ix->segs[s]->d_champ.as<float>();
       sd[s].n_docs = ix->segs[s]->n_docs;

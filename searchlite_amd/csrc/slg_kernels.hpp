@@ -30,8 +30,8 @@ __host__ __device__ inline int champ_index(uint32_t k) {
 
 // ---- device-side descriptors (built on the host per batch) ---------------------------
 struct SegDev {
-  const uint2 *post;        // [P + 64] postings: .x doc id, .y bits of the precomputed bm25
-                            // impact (weight == 1); one 8-byte stream per list
+  const uint32_t *docs;     // [P] doc ids
+  const float *imps;        // [P] precomputed bm25 (weight == 1) per posting
   const uint32_t *deleted;  // bitmap words or nullptr
   const float *champ;       // [V * kChampions] per-term descending impact lower bounds
   uint32_t n_docs;
@@ -350,14 +350,14 @@ struct StageParams {
   uint32_t n_terms;
   uint32_t n_docs;
   const uint64_t *term_offsets;  // [V+1]
-  const uint32_t *docs;          // [P] (staging copy)
-  const uint32_t *tfs;           // [P] (staging copy)
+  const uint32_t *docs;          // [P]
+  const uint32_t *tfs;           // [P]
   const float *term_idf;         // [V]
   const uint16_t *term_field;    // [V] or nullptr
   const float *const *field_doc_len;  // [F] device pointers (or nullptr entries)
   const float *field_avgdl;           // [F]
   float k1, b;
-  uint2 *post;  // out [P]: {doc id, impact bits}
+  float *imps;  // out [P]
 };
 
 static __global__ void __launch_bounds__(256) stage_impacts_kernel(StageParams p) {
@@ -393,7 +393,7 @@ static __global__ void __launch_bounds__(256) stage_impacts_kernel(StageParams p
     float idf = p.term_idf[t];
     float norm_dl = avgdl > 0.0f ? norm_len / avgdl : 1.0f;
     float denom = tf + p.k1 * (1.0f - p.b + p.b * norm_dl);
-    p.post[i] = make_uint2(doc, __float_as_uint(idf * (tf * (p.k1 + 1.0f)) / fmaxf(denom, 1e-6f)));
+    p.imps[i] = idf * (tf * (p.k1 + 1.0f)) / fmaxf(denom, 1e-6f);
   }
 }
 
@@ -407,7 +407,8 @@ static __global__ void __launch_bounds__(256) stage_impacts_kernel(StageParams p
 // score is >= any one of its (non-negative) per-term contributions.
 struct ChampParams {
   const uint64_t *term_offsets;  // [V+1]
-  const uint2 *post;             // [P] {doc, impact bits}
+  const float *imps;             // [P]
+  const uint32_t *docs;          // [P]
   const uint32_t *deleted;       // bitmap words or nullptr: deleted docs never count (accept())
   float *champ;                  // [V * kChampions]
   uint32_t n_terms;
@@ -424,10 +425,9 @@ static __global__ void __launch_bounds__(256) stage_champions_kernel(ChampParams
     for (int r = 0; r < 16; r++) m[r] = 0.0f;
     for (uint64_t i0 = a; i0 < b; i0 += 64) {
       const uint64_t i = i0 + lane;
-      const uint2 pd = i < b ? p.post[i] : make_uint2(0u, 0u);
-      float x = i < b ? __uint_as_float(pd.y) : 0.0f;
+      float x = i < b ? p.imps[i] : 0.0f;
       if (p.deleted && i < b) {
-        const uint32_t d = pd.x;
+        const uint32_t d = p.docs[i];
         if ((p.deleted[d >> 5] >> (d & 31)) & 1u) x = 0.0f;
       }
       if (__ballot(x > m[15]) == 0ull) continue;  // nobody improves: the common case

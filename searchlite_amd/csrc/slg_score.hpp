@@ -50,13 +50,13 @@ static __global__ void __launch_bounds__(256) partition_rounds_kernel(RoundPartP
   const uint32_t sqi = p.bnd_sq[b];
   const RoundQuery s = p.sq[sqi];
   const uint32_t j = b - s.bnd_begin;
-  const uint2 *post = p.segs[s.seg].post;
+  const uint32_t *docs = p.segs[s.seg].docs;
   const TermRef L = p.terms[s.term_begin + s.longest];
   const uint32_t stride = (L.df + s.n_rounds - 1) / s.n_rounds;
   const uint64_t posL = (uint64_t)j * stride;
   const bool first = j == 0, last = j >= s.n_rounds || posL >= L.df;
   uint32_t target = 0;
-  if (!first && !last) target = post[L.off + posL].x;
+  if (!first && !last) target = docs[L.off + posL];
   for (uint32_t t = u; t < s.n_terms; t += 8) {
     const TermRef me = p.terms[s.term_begin + t];
     uint32_t out;
@@ -67,7 +67,7 @@ static __global__ void __launch_bounds__(256) partition_rounds_kernel(RoundPartP
     } else if (t == s.longest) {
       out = (uint32_t)posL;
     } else {
-      const uint2 *d = post + me.off;
+      const uint32_t *d = docs + me.off;
       uint32_t lo = 0, hi = me.df;  // first index with d[idx] >= target
       // bracket around the position a uniform doc-id distribution predicts (widened until it
       // holds the answer), then bisect: ~10 dependent loads instead of ~log2(df)
@@ -80,8 +80,8 @@ static __global__ void __launch_bounds__(256) partition_rounds_kernel(RoundPartP
         for (uint64_t w = 64; w < me.df; w <<= 3) {
           const uint32_t a = g > w ? (uint32_t)(g - w) : 0u;
           const uint32_t b = (uint64_t)g + w < me.df ? (uint32_t)(g + w) : me.df;
-          const bool lo_ok = a == 0u || d[a - 1].x < target;   // answer >= a
-          const bool hi_ok = b == me.df || d[b - 1].x >= target;  // answer <= b - 1 < b
+          const bool lo_ok = a == 0u || d[a - 1] < target;   // answer >= a
+          const bool hi_ok = b == me.df || d[b - 1] >= target;  // answer <= b - 1 < b
           if (lo_ok && hi_ok) {
             lo = a;
             hi = b == me.df ? me.df : b - 1;  // d[b-1] >= target: answer <= b-1
@@ -92,7 +92,7 @@ static __global__ void __launch_bounds__(256) partition_rounds_kernel(RoundPartP
       }
       while (lo < hi) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (d[mid].x < target)
+        if (d[mid] < target)
           lo = mid + 1;
         else
           hi = mid;
@@ -107,14 +107,14 @@ static __global__ void __launch_bounds__(256) partition_rounds_kernel(RoundPartP
       rd = 0xFFFFFFFFu;
       for (uint32_t t = 0; t < s.n_terms; t++) {
         const TermRef me = p.terms[s.term_begin + t];
-        const uint32_t d0 = post[me.off].x;
+        const uint32_t d0 = docs[me.off];
         rd = d0 < rd ? d0 : rd;
       }
     } else if (last) {  // one past the largest last doc
       rd = 0;
       for (uint32_t t = 0; t < s.n_terms; t++) {
         const TermRef me = p.terms[s.term_begin + t];
-        const uint32_t d1 = post[me.off + me.df - 1].x + 1u;
+        const uint32_t d1 = docs[me.off + me.df - 1] + 1u;
         rd = d1 > rd ? d1 : rd;
       }
     } else {
@@ -180,6 +180,5 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 
 typedef const __attribute__((address_space(1))) uint32_t *gu32_t;
 typedef const __attribute__((address_space(1))) float *gf32_t;
-typedef const __attribute__((address_space(1))) uint64_t *gu64_t;  // postings: doc | impact bits << 32
 
 }  // namespace slg

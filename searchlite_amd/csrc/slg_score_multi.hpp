@@ -79,7 +79,8 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
   const uint32_t r_end = rfl(s.n_rounds) < r0 + rps ? rfl(s.n_rounds) : r0 + rps;
   const uint32_t n_r = r_end - r0;
   const SegDev sd = p.segs[s.seg];
-  const gu64_t gpost = (gu64_t)sd.post;
+  const gu32_t gdocs = (gu32_t)sd.docs;
+  const gf32_t gimps = (gf32_t)sd.imps;
   const uint32_t fid = rfl(s.filter);
   const gu32_t gdel = (gu32_t)(fid ? p.reject_table[(size_t)(fid - 1) * p.n_segs + s.seg] : sd.deleted);
   const uint32_t k = p.k;
@@ -139,9 +140,8 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
 #pragma unroll
     for (int jj = 0; jj < NS; jj++) {
       const uint64_t base = ((uint64_t)rl(hi, b * 8u + jj) << 32) | rl(lo, b * 8u + jj);
-      const uint64_t pd = gpost[base + lane];
-      ndoc[jj] = (uint32_t)pd;
-      nimp[jj] = __uint_as_float((uint32_t)(pd >> 32));
+      ndoc[jj] = gdocs[base + lane];
+      nimp[jj] = gimps[base + lane];
     }
   };
   auto take_batch = [&](const uint32_t b, const uint32_t cnt, const uint32_t dhi) {
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
         c = c < 1u ? 1u : c;
         chunk = rem < c ? rem : c;
         uint32_t lastdoc = kDocEnd;
-        if (chunk < rem) lastdoc = (uint32_t)gpost[my_off + cur + chunk - 1];
+        if (chunk < rem) lastdoc = gdocs[my_off + cur + chunk - 1];
         const uint32_t bound = wave_min(lastdoc);
         dhi = bound == kDocEnd ? rdhi : bound + 1u;
         cut = true;
@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
       if (!cut) break;  // the whole rest of the round was in this chunk
       cur += consumed;
       uint32_t firstdoc = kDocEnd;  // next chunk starts at the smallest doc not yet scored
-      if (cur < end) firstdoc = (uint32_t)gpost[my_off + cur];
+      if (cur < end) firstdoc = gdocs[my_off + cur];
       dlo = wave_min(firstdoc);
       if (dlo == kDocEnd) break;
     }

@@ -45,16 +45,20 @@ constexpr int kUniCap = kUniSlots * 64;      // postings per round
 constexpr int kUniMaxLists = 4;              // lists per sub-query (one filter bit each)
 constexpr int kJoinWords = 1024;             // filter words = 8192 doc fields; also the join queue
 constexpr int kJoinPairs = 24;               // queue sizes up to this are joined all-pairs in registers
-static_assert(kJoinWords * 4 >= kUniCap * 8, "the join queue ({doc, list} per posting) overlays the filter");
+static_assert(kJoinWords * 4 >= kUniCap * 8, "the join queue ({doc, score} per posting) overlays the filter");
 // k <= 256 (KREGS <= 4): buffered top-k in LDS (BufTopK); larger k: every doc above the seed
 // threshold goes to the slice's candidate region and select_topk_kernel picks the k best
 constexpr bool uni_buffered(int kregs) { return kregs <= 4; }
-constexpr int uni_wave_lds(int kregs) {  // filter / queue keys, queue scores, top-k buffer
-  return kJoinWords * 4 + kUniCap * 4 + (uni_buffered(kregs) ? 128 * kregs * 8 : 0);
+constexpr int uni_wave_lds(int kregs) {  // filter / join queue, top-k buffer
+  return kJoinWords * 4 + (uni_buffered(kregs) ? 128 * kregs * 8 : 0);
 }
 
+#ifndef SLG_UNI_WAVES
+#define SLG_UNI_WAVES 5  // waves per SIMD the register allocation aims at
+#endif
 template <int KREGS>
-__global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLG_UNI_WAVES, SLG_UNI_WAVES)))
+score_uniform_kernel(RoundScoreParams p) {
   constexpr int NS = kUniSlots;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lane = threadIdx.x & 63;
@@ -65,8 +69,7 @@ __global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
   constexpr bool BUF = uni_buffered(KREGS);
   uint32_t *flt = reinterpret_cast<uint32_t *>(smem);
   uint4 *flt4 = reinterpret_cast<uint4 *>(smem);
-  uint2 *qkey = reinterpret_cast<uint2 *>(smem);   // {doc, list} of queued postings; overlays flt (see P4)
-  float *qx = reinterpret_cast<float *>(smem + kJoinWords * 4);  // their scores
+  uint2 *queue = reinterpret_cast<uint2 *>(smem);  // {doc, score} of queued postings; overlays flt (P4)
 
   const uint32_t sqi = rfl(p.slice_sq[slice]);
   const RoundQuery s = p.sq[sqi];
@@ -76,7 +79,8 @@ __global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
   const uint32_t r_end = rfl(s.n_rounds) < r0 + rps ? rfl(s.n_rounds) : r0 + rps;
   const uint32_t n_r = r_end - r0;
   const SegDev sd = p.segs[s.seg];
-  const gu64_t gpost = (gu64_t)sd.post;
+  const gu32_t gdocs = (gu32_t)sd.docs;
+  const gf32_t gimps = (gf32_t)sd.imps;
   // accept(): tombstones, or the reject bitmap (deleted | ~filter) of the query's doc filter
   const uint32_t fid = rfl(s.filter);
   const gu32_t gdel = (gu32_t)(fid ? p.reject_table[(size_t)(fid - 1) * p.n_segs + s.seg] : sd.deleted);
@@ -99,7 +103,7 @@ __global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
   const uint32_t dcnt = __shfl(bflat, (lane + T) & 63u, 64) - bflat;
 
   BufTopK<BUF ? KREGS : 1> btop;  // k <= 256; for larger k only its threshold is used
-  btop.init(reinterpret_cast<uint64_t *>(smem + kJoinWords * 4 + kUniCap * 4));
+  btop.init(reinterpret_cast<uint64_t *>(smem + kJoinWords * 4));
   // k > 256: the slice's candidate region starts at (sub-query base) + (postings of all lists
   // before the slice's first round) and can hold one entry per posting of the slice
   uint32_t ccur = 0;
@@ -213,9 +217,8 @@ __global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
 #pragma unroll
     for (int jj = 0; jj < NS; jj++) {
       const uint64_t base = ((uint64_t)rl(d.hi, dbase + jj) << 32) | rl(d.lo, dbase + jj);
-      const uint64_t pd = gpost[base + lane];  // one 8-byte load per posting: 512 B per slot
-      r.doc[jj] = (uint32_t)pd;
-      r.imp[jj] = __uint_as_float((uint32_t)(pd >> 32));
+      r.doc[jj] = gdocs[base + lane];
+      r.imp[jj] = gimps[base + lane];
     }
   };
   // ---- dst = the loaded round src, ready to accumulate: lanes beyond each slot's count become
@@ -259,16 +262,13 @@ __global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
   //      are kept as 64-bit wave masks (scalar registers), the per-slot code is branch-free. ----
   auto accumulate = [&](const URound &e) {
     SLG_STAMP(1);
-    uint64_t sharedm[NS];  // lanes whose doc is (or aliases) a doc of another list
-    uint32_t n = 0;        // queued postings
-    // the cheap necessary condition of a top-k candidate, for all postings (independent of the
-    // filter: evaluated while its LDS traffic is in flight).  Idle lanes carry impact * w of
-    // whatever they loaded: masked by the doc test below.
-    const float thf = threshold_score();
-    uint64_t hotm[NS];
-    uint64_t anyhot = 0ull;
+    uint64_t validm[NS], sharedm[NS];  // sharedm: my doc is (or aliases) a doc of another list
+    uint32_t n = 0;                    // queued postings
 #pragma unroll
-    for (int jj = 0; jj < NS; jj++) sharedm[jj] = 0ull;
+    for (int jj = 0; jj < NS; jj++) {
+      validm[jj] = __ballot(e.doc[jj] != kDocEnd);
+      sharedm[jj] = 0ull;
+    }
     if (T > 1) {
       // P0: clear the filter
       flt4[lane] = make_uint4(0u, 0u, 0u, 0u);
@@ -290,11 +290,6 @@ __global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
 #pragma unroll
       for (int jj = 0; jj < NS; jj++) fin[jj] = flt[e.doc[jj] & (kJoinWords - 1)];
       wave_fence();  // the queue below overlays the filter: all reads are issued before its writes
-#pragma unroll
-      for (int jj = 0; jj < NS; jj++) {
-        hotm[jj] = __ballot(0.0f + e.imp[jj] >= thf);
-        anyhot |= hotm[jj];
-      }
       SLG_STAMP(3);
       // P3: shared docs (and aliases) are queued, in slot = list order
 #pragma unroll
@@ -302,101 +297,119 @@ __global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
         const uint32_t tj = rl(e.st, e.dbase + jj);  // uniform
         const uint32_t others = 0xFu & ~(1u << tj);
         const uint32_t fld = (fin[jj] >> ((e.doc[jj] >> 8) & 0x1Cu)) & others;
-        const uint64_t m = __ballot((fld != 0u) & (e.doc[jj] != kDocEnd));
+        const uint64_t m = __ballot(fld != 0u) & validm[jj];
         sharedm[jj] = m;
         if (m != 0ull) {
           const uint32_t at = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
                                                             __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-          if ((m >> lane) & 1ull) {
-            qkey[at] = make_uint2(e.doc[jj], tj);
-            qx[at] = e.imp[jj];
-          }
+          if ((m >> lane) & 1ull) queue[at] = make_uint2(e.doc[jj], __float_as_uint(e.imp[jj]));
           n += (uint32_t)__popcll(m);
         }
       }
       wave_fence();
       n_scored -= n;
-    } else {
-#pragma unroll
-      for (int jj = 0; jj < NS; jj++) {
-        hotm[jj] = __ballot(0.0f + e.imp[jj] >= thf);
-        anyhot |= hotm[jj];
-      }
     }
     SLG_STAMP(4);
 #ifdef SLG_STAMPS
     st_queued += n;
 #endif
-    // singles: the doc occurs in this list only; score = 0.0 + w*impact (wand.rs:539).  Rarely
-    // does any posting of a round reach the threshold at all.
-    if (anyhot != 0ull) {  // rank-and-trim may be needed between slots: one site, the slot's
-                           // registers are selected at run time
-#pragma unroll 1
-      for (uint32_t it = 0; it < (uint32_t)NS; it++) {
-        float x = e.imp[0];
-        uint32_t dc = e.doc[0];
-        uint64_t hm = hotm[0] & ~sharedm[0];
+    // singles: the doc occurs in this list only; score = 0.0 + w*impact (wand.rs:539)
+    {
+      const float thf = threshold_score();
+      uint64_t hotm[NS];
+      uint64_t anyhot = 0ull;
 #pragma unroll
-        for (int j = 1; j < NS; j++) {
-          x = it == (uint32_t)j ? e.imp[j] : x;
-          dc = it == (uint32_t)j ? e.doc[j] : dc;
-          hm = it == (uint32_t)j ? hotm[j] & ~sharedm[j] : hm;
-        }
-        hm &= __ballot(dc != kDocEnd);
-        if (hm == 0ull) continue;
+      for (int jj = 0; jj < NS; jj++) {
+        const uint64_t singles = validm[jj] & ~sharedm[jj];
+        hotm[jj] = __ballot(0.0f + e.imp[jj] >= thf) & singles;
+        anyhot |= hotm[jj];
+      }
+      if (anyhot != 0ull) {  // rank-and-trim may be needed between slots: one site, the slot's
+                             // registers are selected at run time
+#pragma unroll 1
+        for (uint32_t it = 0; it < (uint32_t)NS; it++) {
+          float x = e.imp[0];
+          uint32_t dc = e.doc[0];
+          uint64_t hm = hotm[0];
+#pragma unroll
+          for (int j = 1; j < NS; j++) {
+            x = it == (uint32_t)j ? e.imp[j] : x;
+            dc = it == (uint32_t)j ? e.doc[j] : dc;
+            hm = it == (uint32_t)j ? hotm[j] : hm;
+          }
+          if (hm == 0ull) continue;
 #ifdef SLG_STAMPS
-        st_ins += (uint32_t)__popcll(hm);
+          st_ins += (uint32_t)__popcll(hm);
 #endif
-        take_checked((hm >> lane) & 1ull, 0.0f + x, dc);
+          take_checked((hm >> lane) & 1ull, 0.0f + x, dc);
+        }
       }
     }
     SLG_STAMP(5);
     // P4: join.  The queue is sorted by (list, doc): slots are in list order and a list's
     // postings in doc order.  A doc's sum is ((0.0 + x_a) + x_b) + ... over the lists that hold it,
     // in list order (= the reference's term order); its entry in the lowest list owns the result.
-    // Receivers in blocks of 64 lanes.
-    for (uint32_t rb = 0; rb < n; rb += 64) {
-      const uint32_t idx = rb + lane;
-      const bool have = idx < n;
-      const uint2 me = have ? qkey[idx] : make_uint2(kDocEnd, 0u);
-      const float mx = have ? qx[idx] : 0.0f;
+    if (n != 0u && n <= (uint32_t)kJoinPairs) {
+      // few entries (the usual case): all pairs, the senders read from registers lane by lane
+      const bool have = lane < n;
+      const uint2 me = have ? queue[lane] : make_uint2(kDocEnd, 0u);
       float acc = 0.0f;
-      bool lower = false;  // a lower list holds my doc
-      if (n <= (uint32_t)kJoinPairs) {
-        // few entries (the usual case): all pairs, the senders read from registers lane by lane
-        for (uint32_t l = 0; l < n; l++) {
-          const uint32_t dl = rl(me.x, l);
-          const float xl = __uint_as_float(rl(__float_as_uint(mx), l));
-          const bool hit = dl == me.x;
-          acc = hit ? acc + xl : acc;
-          lower = lower || (hit && l < lane);
-        }
-      } else {
-        // many entries (dense lists): for every list u in order, a binary search of (u, my doc)
-        const uint32_t steps = 32u - (uint32_t)__builtin_clz(n);  // halvings that empty [0, n)
-        for (uint32_t u = 0; u < T; u++) {
-          const uint64_t want = ((uint64_t)u << 32) | me.x;
-          uint32_t lo = 0, hi = n;
-          for (uint32_t st = 0; st < steps; st++) {
-            const uint32_t mid = (lo + hi) >> 1;  // < n while lo < hi
-            const uint2 kk = qkey[mid < n ? mid : n - 1u];
-            const bool less = ((((uint64_t)kk.y) << 32) | kk.x) < want;
-            const bool open = lo < hi;
-            lo = open && less ? mid + 1u : lo;
-            hi = open && !less ? mid : hi;
-          }
-          const uint32_t at = lo < n ? lo : n - 1u;
-          const uint2 kk = qkey[at];
-          const float xu = qx[at];
-          const bool mine = me.y == u;
-          const bool hit = have && (mine || (lo < n && kk.x == me.x && kk.y == u));
-          acc = hit ? acc + (mine ? mx : xu) : acc;
-          lower = lower || (hit && u < me.y);
-        }
+      bool lower = false;  // an earlier entry (= a lower list) holds my doc
+      for (uint32_t l = 0; l < n; l++) {
+        const uint32_t dl = rl(me.x, l);
+        const float xl = __uint_as_float(rl(me.y, l));
+        const bool hit = dl == me.x;
+        acc = hit ? acc + xl : acc;
+        lower = lower || (hit && l < lane);
       }
       const uint64_t ownerm = __ballot(have && !lower);
       n_scored += (uint32_t)__popcll(ownerm);
       if ((__ballot(acc >= threshold_score()) & ownerm) != 0ull) take_checked((ownerm >> lane) & 1ull, acc, me.x);
+    } else if (n != 0u) {
+      // many entries (dense lists): binary search of my doc in the queue segment of every list,
+      // in list order.  qe[u] = entries of the lists <= u (segment u = [qe[u-1], qe[u])).
+      uint32_t qe0 = 0, qe1 = 0, qe2 = 0, qe3 = 0;
+#pragma unroll
+      for (int jj = 0; jj < NS; jj++) {
+        const uint32_t tj = rl(e.st, e.dbase + jj);
+        const uint32_t c = (uint32_t)__popcll(sharedm[jj]);  // (0 for unused slots)
+        qe0 += tj <= 0u ? c : 0u;
+        qe1 += tj <= 1u ? c : 0u;
+        qe2 += tj <= 2u ? c : 0u;
+        qe3 += c;
+      }
+      for (uint32_t rb = 0; rb < n; rb += 64) {  // receivers in blocks of 64 lanes
+        const uint32_t idx = rb + lane;
+        const bool have = idx < n;
+        const uint2 me = have ? queue[idx] : make_uint2(kDocEnd, 0u);
+        const uint32_t ml = (idx >= qe0 ? 1u : 0u) + (idx >= qe1 ? 1u : 0u) + (idx >= qe2 ? 1u : 0u);
+        float acc = 0.0f;
+        bool lower = false;
+        uint32_t seg_lo = 0;
+        for (uint32_t u = 0; u < T; u++) {
+          const uint32_t seg_hi = u == 0u ? qe0 : (u == 1u ? qe1 : (u == 2u ? qe2 : qe3));
+          uint32_t lo = seg_lo, hi = seg_hi;
+          const uint32_t len = seg_hi - seg_lo;
+          const uint32_t steps = len ? 32u - (uint32_t)__builtin_clz(len) : 0u;  // halvings that empty it
+          for (uint32_t st = 0; st < steps; st++) {
+            const uint32_t mid = (lo + hi) >> 1;  // < seg_hi while lo < hi
+            const uint32_t dk = queue[mid < seg_hi ? mid : seg_lo].x;
+            const bool less = dk < me.x;
+            const bool open = lo < hi;
+            lo = open && less ? mid + 1u : lo;
+            hi = open && !less ? mid : hi;
+          }
+          const uint2 kk = queue[lo < seg_hi ? lo : seg_lo];  // (an empty segment reads a neighbour: ignored)
+          const bool mine = ml == u;
+          const bool hit = have && (mine || (lo < seg_hi && kk.x == me.x));
+          acc = hit ? acc + (mine ? __uint_as_float(me.y) : __uint_as_float(kk.y)) : acc;
+          lower = lower || (hit && u < ml);
+          seg_lo = seg_hi;
+        }
+        const uint64_t ownerm = __ballot(have && !lower);
+        n_scored += (uint32_t)__popcll(ownerm);
+        if ((__ballot(acc >= threshold_score()) & ownerm) != 0ull) take_checked((ownerm >> lane) & 1ull, acc, me.x);
+      }
     }
     wave_fence();
     SLG_STAMP(6);
@@ -461,7 +474,7 @@ __global__ void __launch_bounds__(64) score_uniform_kernel(RoundScoreParams p) {
           chunk = rem < mslots * 64u ? rem : mslots * 64u;
         }
         uint32_t lastdoc = kDocEnd;
-        if (chunk < rem) lastdoc = (uint32_t)gpost[my_off + ocur + chunk - 1];
+        if (chunk < rem) lastdoc = gdocs[my_off + ocur + chunk - 1];
         describe_chunk(C, ocur, chunk);
         ew.nslots = C.nsl;
         issue(ew, C, 0);
