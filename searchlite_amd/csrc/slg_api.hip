@@ -234,7 +234,7 @@ struct slg_batch {
   const uint32_t *d_slice_order = nullptr;
   const uint32_t *d_bnd_sq = nullptr;
   const slg::QueryRef *d_queries = nullptr;
-  DevBuf d_bounds, d_rdoc, d_slice_tk, d_slice_doc, d_q_scored;
+  DevBuf d_bounds, d_rdoc, d_slice_tk, d_slice_doc, d_q_scored, d_slice_desc;
   DevBuf d_q_filter;       // [nq] 0 = none, f + 1 (select_topk_kernel); empty when unfiltered
   bool cand_mode = false;  // uniform kernel, k > 256: candidates + select_topk_kernel
   DevBuf d_cand, d_slice_cbeg, d_slice_ccnt;
@@ -608,7 +608,7 @@ namespace {
 // free everything a batch holds on the device; with `to_pool` false the blocks go straight back
 // to the runtime (the index and its pool are going away)
 void release_batch_buffers(slg_batch *b, bool to_pool) {
-  DevBuf *bufs[] = {&b->d_desc, &b->d_bounds, &b->d_rdoc, &b->d_slice_tk, &b->d_slice_doc,
+  DevBuf *bufs[] = {&b->d_desc, &b->d_bounds, &b->d_rdoc, &b->d_slice_desc, &b->d_slice_tk, &b->d_slice_doc,
                     &b->d_q_scored, &b->d_q_filter, &b->d_cand, &b->d_slice_cbeg, &b->d_slice_ccnt,
                     &b->d_out, &b->d_stamps, &b->d_blk_skip};
   for (DevBuf *d : bufs) {
@@ -914,6 +914,21 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
           sq.n_leaves = n_leaves;
           if (sq.plan) any_plan = true;
         }
+        // ---- threshold seed (kernels: RoundQuery::theta0) = max_t w_t * champ[t][rank(k)]: an
+        // exact lower bound of the k-th best score whenever no weight is negative (a doc's total
+        // is then >= each of its contributions) and no doc filter can reject the champions ----
+        float seed = 0.0f;
+        if (!sh.champ.empty() && k <= 1024u && fq == 0) {
+          bool nonneg = true;
+          for (uint32_t i = 0; i < sq.n_terms; i++) {
+            const slg::TermRef &tr = terms[sq.term_begin + i];
+            if (!(tr.weight >= 0.0f)) nonneg = false;
+            if (tr.weight > 0.0f)
+              seed = std::max(seed, tr.weight * sh.champ[(size_t)tr.term * slg::kChampions + slg::champ_index(k)]);
+          }
+          if (!nonneg) seed = 0.0f;
+        }
+        sq.theta0 = seed;
         // ---- MaxScore classification (strategies Wand / Bmw; exact).  On by default for batches
         // that run on the multi kernel (a query with >= 5 terms), where probing the non-essential
         // lists is cheaper than scoring them; SLG_MAXSCORE=1 / 0 forces it on / off ----
@@ -922,19 +937,14 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
         // their maximum contribution ub_t = w_t * champ[t][0] are non-essential while the running
         // sum of ub stays below theta0: a doc found only in them totals < theta0.
         uint32_t ess_mask = sq.n_terms >= 32 ? 0xFFFFFFFFu : ((1u << sq.n_terms) - 1u);
-        if (strategy != SLG_STRATEGY_BM25 && !sh.champ.empty() && k >= 1 && k <= 1024u && fq == 0 && !plans_requested &&
-            sq.n_terms > 1 && maxscore_on) {
-          bool ok = true;
-          float theta0 = 0.0f;
+        if (strategy != SLG_STRATEGY_BM25 && seed > 0.0f && !plans_requested && sq.n_terms > 1 && maxscore_on) {
+          const float theta0 = seed;
           std::vector<std::pair<float, uint32_t>> ub(sq.n_terms);
           for (uint32_t i = 0; i < sq.n_terms; i++) {
             const slg::TermRef &tr = terms[sq.term_begin + i];
-            if (!(tr.weight >= 0.0f)) ok = false;
-            const float *c = &sh.champ[(size_t)tr.term * slg::kChampions];
-            theta0 = std::max(theta0, tr.weight * c[slg::champ_index(k)]);
-            ub[i] = {tr.weight * c[0], i};
+            ub[i] = {tr.weight * sh.champ[(size_t)tr.term * slg::kChampions], i};
           }
-          if (ok && theta0 > 0.0f) {
+          {
             std::sort(ub.begin(), ub.end());
             double acc = 0.0;
             for (uint32_t i = 0; i + 1 < sq.n_terms; i++) {  // at least one list stays essential
@@ -1135,6 +1145,7 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
 
     b->d_bounds.alloc_pooled(&ix->pool, (size_t)n_bounds * 4);
     b->d_rdoc.alloc_pooled(&ix->pool, (size_t)n_bnd * 4);
+    b->d_slice_desc.alloc_pooled(&ix->pool, (size_t)b->n_slices * sizeof(slg::SliceDesc));
     if (b->cand_mode) {
       b->d_cand.alloc_pooled(&ix->pool, (size_t)(cand_total + 1) * 8);
       b->d_slice_cbeg.alloc_pooled(&ix->pool, (size_t)b->n_slices * 8);
@@ -1194,9 +1205,13 @@ int slg_batch_run(slg_batch *b) {
       pp.bounds = b->d_bounds.as<uint32_t>();
       pp.rdoc = b->d_rdoc.as<uint32_t>();
       pp.q_scored = b->d_q_scored.as<uint32_t>();
+      pp.slice_sq = b->d_slice_sq;
+      pp.slice_order = b->d_slice_order;
+      pp.slice_desc = b->d_slice_desc.as<slg::SliceDesc>();
       pp.nq = b->nq;
       pp.n_boundaries = b->n_boundaries;
-      const uint64_t pthreads = std::max<uint64_t>((uint64_t)b->n_boundaries * 8, b->nq);
+      pp.n_slices = b->n_slices;
+      const uint64_t pthreads = std::max<uint64_t>(std::max<uint64_t>((uint64_t)b->n_boundaries * 8, b->nq), b->n_slices);
       hipLaunchKernelGGL(slg::partition_rounds_kernel, dim3((uint32_t)((pthreads + 255) / 256)),
                          dim3(256), 0, st, pp);
       SLG_HIP(hipGetLastError());
@@ -1206,6 +1221,7 @@ int slg_batch_run(slg_batch *b) {
       sp.terms = b->d_terms;
       sp.slice_sq = b->d_slice_sq;
       sp.slice_order = b->d_slice_order;
+      sp.slice_desc = b->d_slice_desc.as<slg::SliceDesc>();
       sp.reject_table = ix->d_reject_table.as<const uint32_t *>();
       sp.n_segs = (uint32_t)ix->segs.size();
       sp.plan_batch = b->plan_batch ? 1u : 0u;

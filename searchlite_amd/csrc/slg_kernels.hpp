@@ -65,6 +65,25 @@ struct RoundQuery {  // sub-query = (query, segment) pair with >= 1 non-empty te
   float tie;       // DisMax tie breaker
   float max_init;  // DisMax: 0.0 if some leaf of the plan has no term in this segment, else -inf
   uint32_t n_leaves;  // leaves of the plan (a DisMax counts every one, absent ones as 0.0)
+  // threshold seed (0: none): theta0 = max_t w_t * champ[t][rank(k)].  At least k live docs have
+  // a single contribution >= theta0 and a doc's total is >= any one of its non-negative
+  // contributions (Sum, or DisMax with tie in [0, 1]), so nothing below theta0 reaches the top-k.
+  // Set by the host planner from its mirror of the champion table; never with a doc filter (it
+  // may reject the champions) or a negative weight.
+  float theta0;
+};
+
+// What a scoring wave needs to start its slice, gathered in one record per launch position by
+// partition_rounds_kernel (a wave then starts with ONE dependent load instead of a chain of four).
+struct SliceDesc {
+  uint32_t slice;       // slice index (candidate output arrays)
+  uint32_t term_begin;  // first TermRef of the sub-query
+  uint32_t bounds_off;  // bounds[] index of the slice's first cut points
+  uint32_t rdoc_off;    // rdoc[] index of the slice's first round
+  uint32_t n_terms, n_rounds, seg, filter;
+  uint32_t q;
+  float theta0;
+  uint32_t cand_lo, cand_hi;
 };
 
 struct QueryRef {

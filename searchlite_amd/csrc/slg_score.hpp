@@ -37,14 +37,37 @@ struct RoundPartParams {
   uint32_t *bounds;
   uint32_t *rdoc;
   uint32_t *q_scored;  // [nq] zeroed here (saves a memset node per batch)
+  const uint32_t *slice_sq;     // [n_slices]
+  const uint32_t *slice_order;  // [n_slices] launch position -> slice
+  SliceDesc *slice_desc;        // [n_slices] out, by launch position
   uint32_t nq;
   uint32_t n_boundaries;
+  uint32_t n_slices;
 };
 
 // 8 threads per boundary: thread u handles lists u, u+8, ...
 static __global__ void __launch_bounds__(256) partition_rounds_kernel(RoundPartParams p) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid < p.nq) p.q_scored[gid] = 0;
+  if (gid < p.n_slices) {  // the slice record of launch position gid
+    const uint32_t slice = p.slice_order[gid];
+    const RoundQuery s = p.sq[p.slice_sq[slice]];
+    const uint32_t r0 = (slice - s.slice_begin) * s.rounds_per_slice;
+    SliceDesc d;
+    d.slice = slice;
+    d.term_begin = s.term_begin;
+    d.bounds_off = s.bounds_begin + r0 * s.n_terms;
+    d.rdoc_off = s.rdoc_begin + r0;
+    d.n_terms = s.n_terms;
+    d.n_rounds = s.n_rounds - r0 < s.rounds_per_slice ? s.n_rounds - r0 : s.rounds_per_slice;
+    d.seg = s.seg;
+    d.filter = s.filter;
+    d.q = s.q;
+    d.theta0 = s.theta0;
+    d.cand_lo = s.cand_lo;
+    d.cand_hi = s.cand_hi;
+    p.slice_desc[gid] = d;
+  }
   const uint32_t b = gid >> 3, u = gid & 7;
   if (b >= p.n_boundaries) return;
   const uint32_t sqi = p.bnd_sq[b];
@@ -130,6 +153,7 @@ struct RoundScoreParams {
   const TermRef *terms;
   const uint32_t *slice_sq;
   const uint32_t *slice_order;  // [n_slices] wave w runs slice slice_order[w] (most rounds first)
+  const SliceDesc *slice_desc;  // [n_slices] by launch position (partition_rounds_kernel)
   const SegDev *segs;
   const uint32_t *bounds;
   const uint32_t *rdoc;

@@ -88,12 +88,11 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
   // lane t < T: list t's posting offset, weight, term id
   uint64_t my_off = 0;
   float my_w = 0.0f;
-  uint32_t my_term = 0, my_leaf = 0;
+  uint32_t my_leaf = 0;
   if (lane < T) {
     const TermRef tr = p.terms[s.term_begin + lane];
     my_off = tr.off;
     my_w = tr.weight;
-    my_term = tr.term;
     my_leaf = tr.leaf;
   }
   const uint32_t my_off_lo = (uint32_t)my_off, my_off_hi = (uint32_t)(my_off >> 32);
@@ -118,15 +117,9 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
     cbeg = (((uint64_t)rfl(s.cand_hi) << 32) | rfl(s.cand_lo)) + wave_sum(b0);
   }
   uint2 *const creg = BUF ? nullptr : p.cand + cbeg;
-  if (sd.champ != nullptr && k <= 1024u && fid == 0) {  // threshold seed (see slg_score.hpp)
-    float f = 0.0f;
-    if (lane < T && my_w > 0.0f)
-      f = my_w * ((const gf32_t)sd.champ)[(size_t)my_term * kChampions + champ_index(k)];
-    float best = 0.0f;
-    for (uint32_t t = 0; t < T; t++)
-      best = fmaxf(best, __int_as_float((int)rl((uint32_t)__float_as_int(f), t)));
-    const bool anyneg = __ballot(lane < T && !(my_w >= 0.0f)) != 0ull;
-    if (best > 0.0f && !anyneg) btop.set_floor(best);
+  {  // threshold seed (RoundQuery::theta0, set by the host planner)
+    const float th0 = __uint_as_float(rfl(__float_as_uint(s.theta0)));
+    if (th0 > 0.0f) btop.set_floor(th0);
   }
   uint32_t n_scored = 0;
 

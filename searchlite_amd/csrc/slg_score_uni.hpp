@@ -64,41 +64,35 @@ score_uniform_kernel(RoundScoreParams p) {
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t widx = blockIdx.x;
   if (widx >= p.n_slices) return;  // waves are independent: no workgroup barrier anywhere
-  const uint32_t slice = rfl(p.slice_order[widx]);
+  const SliceDesc sl = p.slice_desc[widx];  // one scalar load; everything below hangs off it in parallel
+  const uint32_t slice = rfl(sl.slice);
 
   constexpr bool BUF = uni_buffered(KREGS);
   uint32_t *flt = reinterpret_cast<uint32_t *>(smem);
   uint4 *flt4 = reinterpret_cast<uint4 *>(smem);
   uint2 *queue = reinterpret_cast<uint2 *>(smem);  // {doc, score} of queued postings; overlays flt (P4)
 
-  const uint32_t sqi = rfl(p.slice_sq[slice]);
-  const RoundQuery s = p.sq[sqi];
-  const uint32_t T = rfl(s.n_terms);
-  const uint32_t rps = rfl(s.rounds_per_slice);
-  const uint32_t r0 = (slice - rfl(s.slice_begin)) * rps;
-  const uint32_t r_end = rfl(s.n_rounds) < r0 + rps ? rfl(s.n_rounds) : r0 + rps;
-  const uint32_t n_r = r_end - r0;
-  const SegDev sd = p.segs[s.seg];
+  const uint32_t T = rfl(sl.n_terms);
+  const uint32_t n_r = rfl(sl.n_rounds);
+  const SegDev sd = p.segs[sl.seg];
   const gu32_t gdocs = (gu32_t)sd.docs;
   const gf32_t gimps = (gf32_t)sd.imps;
   // accept(): tombstones, or the reject bitmap (deleted | ~filter) of the query's doc filter
-  const uint32_t fid = rfl(s.filter);
-  const gu32_t gdel = (gu32_t)(fid ? p.reject_table[(size_t)(fid - 1) * p.n_segs + s.seg] : sd.deleted);
+  const uint32_t fid = rfl(sl.filter);
+  const gu32_t gdel = (gu32_t)(fid ? p.reject_table[(size_t)(fid - 1) * p.n_segs + sl.seg] : sd.deleted);
   const uint32_t k = p.k;
 
-  // lane t < T: list t's posting offset, weight, term id
+  // lane t < T: list t's posting offset and weight
   uint64_t my_off = 0;
   float my_w = 0.0f;
-  uint32_t my_term = 0;
   if (lane < T) {
-    const TermRef tr = p.terms[s.term_begin + lane];
+    const TermRef tr = p.terms[sl.term_begin + lane];
     my_off = tr.off;
     my_w = tr.weight;
-    my_term = tr.term;
   }
   const uint32_t my_off_lo = (uint32_t)my_off, my_off_hi = (uint32_t)(my_off >> 32);
-  // all cut points of the slice in one register (lane i: bounds[r0*T + i])
-  const uint32_t bflat = lane < (n_r + 1) * T ? p.bounds[s.bounds_begin + r0 * T + lane] : 0u;
+  // all cut points of the slice in one register (lane i: its i-th cut point)
+  const uint32_t bflat = lane < (n_r + 1) * T ? p.bounds[sl.bounds_off + lane] : 0u;
   // lane i = r*T + t: postings of list t in round r
   const uint32_t dcnt = __shfl(bflat, (lane + T) & 63u, 64) - bflat;
 
@@ -111,21 +105,12 @@ score_uniform_kernel(RoundScoreParams p) {
   if (!BUF) {
     uint32_t before = 0;
     for (uint32_t t = 0; t < T; t++) before += rl(bflat, t);
-    cbeg = (((uint64_t)rfl(s.cand_hi) << 32) | rfl(s.cand_lo)) + before;
+    cbeg = (((uint64_t)rfl(sl.cand_hi) << 32) | rfl(sl.cand_lo)) + before;
   }
   uint2 *const creg = BUF ? nullptr : p.cand + cbeg;
-  // threshold seed: theta0 = max_t w_t * champ[t][rank(k)].  At least k live docs have a single
-  // contribution >= theta0, and a doc's total is >= any one of its (non-negative) contributions,
-  // so nothing below theta0 can reach the top-k.  (A doc filter may reject the champions.)
-  if (sd.champ != nullptr && k <= 1024u && fid == 0) {
-    float f = 0.0f;
-    if (lane < T && my_w > 0.0f)
-      f = my_w * ((const gf32_t)sd.champ)[(size_t)my_term * kChampions + champ_index(k)];
-    float best = 0.0f;
-    for (uint32_t t = 0; t < T; t++)
-      best = fmaxf(best, __int_as_float((int)rl((uint32_t)__float_as_int(f), t)));
-    const bool anyneg = __ballot(lane < T && !(my_w >= 0.0f)) != 0ull;
-    if (best > 0.0f && !anyneg) btop.set_floor(best);
+  {  // threshold seed (RoundQuery::theta0)
+    const float th0 = __uint_as_float(rfl(__float_as_uint(sl.theta0)));
+    if (th0 > 0.0f) btop.set_floor(th0);
   }
   // distinct docs scored (QueryStats.scored_docs): every posting of the slice is one, except the
   // queued ones, of which only the owners count (added in the join)
@@ -508,7 +493,7 @@ score_uniform_kernel(RoundScoreParams p) {
     p.slice_cbeg[slice] = cbeg;
     p.slice_ccnt[slice] = ccur;
   }
-  if (p.q_scored && lane == 0 && n_scored) atomicAdd(&p.q_scored[s.q], n_scored);
+  if (p.q_scored && lane == 0 && n_scored) atomicAdd(&p.q_scored[sl.q], n_scored);
 #ifdef SLG_STAMPS
   const unsigned long long st_extra = st_ins | (st_queued << 32);
   if (p.stamps && lane == 0) {
