@@ -2,6 +2,7 @@
 
 * lib/libsearchlite_gpu.so — the product: HIP kernels + C ABI for gfx950 (hipcc).
 * lib/libslg_corpus.so     — harness tool: synthetic Zipf corpus generator (g++, host only).
+* lib/libslg_segfile.so    — host-only decoder of searchlite's segment files (g++).
 
 hipcc cross-compiles gfx950 without a GPU, so this runs in the build container; the built
 .so files travel to the GPU box with the repo snapshot.
@@ -17,6 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 GPU_LIB = os.path.join(LIBDIR, "libsearchlite_gpu.so")
 CORPUS_LIB = os.path.join(LIBDIR, "libslg_corpus.so")
+SEGFILE_LIB = os.path.join(LIBDIR, "libslg_segfile.so")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off",  # f32 ops rounded one by one, as the Rust reference does
@@ -90,9 +92,21 @@ def build_corpus_tool(force: bool = False) -> str:
     return CORPUS_LIB
 
 
+def build_segfile(force: bool = False) -> str:
+    """Host-only decoder of searchlite's segment files (include/searchlite_segfile.h)."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    src = os.path.join(CSRC, "slg_segfile.cpp")
+    hdr = os.path.join(_HERE, "..", "include", "searchlite_segfile.h")
+    if force or _newer(SEGFILE_LIB, [src, hdr]):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall",
+                               "-o", SEGFILE_LIB, src])
+    return SEGFILE_LIB
+
+
 def build_all(force: bool = False, verbose: bool = False) -> None:
     build_gpu(force, verbose)
     build_corpus_tool(force)
+    build_segfile(force)
 
 
 if __name__ == "__main__":

@@ -153,3 +153,14 @@ def test_tuning_defaults_come_from_the_environment_once(lib, monkeypatch):
     arr = (N.SegmentDesc * 1)(_seg_desc(4, [0, 1], [1], [1], keep))
     assert lib.slg_index_create_tuned(arr, 1, 0, C.addressof(bad)) is None
     assert b"struct_size" in lib.slg_last_error()
+
+
+def test_segfile_library_exports_its_header():
+    """include/searchlite_segfile.h (host-only decoder of searchlite's segment files)."""
+    from searchlite_amd import index_files as IF
+    text = open(os.path.join(ROOT, "include", "searchlite_segfile.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(slf_[a-z0-9_]+)\s*\(", text)))
+    assert "slf_postings_decode" in names and "slf_postings_scan" in names
+    L = IF._load()
+    assert not [n for n in names if not hasattr(L, n)]

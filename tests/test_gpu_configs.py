@@ -216,3 +216,21 @@ def test_index_closed_before_its_batches(gpu):
     ix2.close()
     assert b2._h is None
     b2.close()
+
+
+# ---- N2: a searchlite index directory loaded from its files, through the GPU --------------------------
+def test_recipes_index_files_reproduce_the_goldens(gpu, tmp_path):
+    """BASELINE config 1: the recipes corpus written in searchlite's on-disk formats (restated
+    writer, oracle/segfile_writer.py), loaded by the product loader (MANIFEST -> .terms -> .post ->
+    _len: columns) and searched on the GPU: the committed golden top-10 lists, bit for bit."""
+    from oracle import segfile_writer as W
+    from searchlite_amd import index_files as IF
+    from tests.test_segfile import golden_recipes_with_dictionary
+    from tests.util import golden_expected
+    seg, z = golden_recipes_with_dictionary()
+    W.write_index(str(tmp_path), [seg], keep_positions=True)
+    li = IF.load_index(str(tmp_path), k1=0.9, b=0.4)
+    with gpu.GpuIndex(li.segments) as ix:
+        for strat in (gpu.Bm25, gpu.Wand, gpu.Bmw):
+            got = ix.search_batch(z["q_offsets"], z["q_terms"], z["q_weights"], int(z["k"]), strat)
+            assert_same_hits(got, golden_expected(z), 0.0, f"recipes from index files, strategy {strat}")
