@@ -37,7 +37,9 @@ extern "C" {
 #define SLG_NO_VECTOR 0xFFFFFFFFu    /* vectors/mod.rs:65-67 (u32::MAX offset) */
 #define SLG_MAX_QUERY_TERMS 32u      /* scored terms per query per segment */
 #define SLG_MAX_K 20001u             /* k = min(max(candidate_size, limit), 20000) + 1 (api/reader.rs:2615-2619) */
-#define SLG_MAX_MERGE_K 1024u        /* largest k of slg_merge_shards_device / k_out of slg_rerank_batch */
+#define SLG_MAX_RERANK_K 1024u       /* largest k_out of slg_rerank_*: the reference's own cap on a vector
+                                        clause's k (MAX_VECTOR_K, api/reader.rs:136) */
+#define SLG_MAX_VECTOR_CLAUSES 8u    /* MAX_VECTOR_CLAUSES, api/reader.rs:134 */
 #define SLG_BLOCK_SIZE 128u          /* index/postings.rs:11 DEFAULT_BLOCK_SIZE */
 
 /* return codes (searchlite-ffi/src/lib.rs returns NULL / -1..-5 / 0) */
@@ -278,6 +280,7 @@ void slg_batch_destroy(slg_batch *batch);
  * by slg_batch_device_results and concatenated shard-major: [n_shards][nq*k]) into the
  * global top-k by (score desc, shard_ord asc, segment asc, doc asc).  out_seg receives
  * shard_ord * seg_stride + seg.  All pointers are device pointers on `index`'s device.
+ * k up to SLG_MAX_K, as the scorer (an index-sharded request with limit = 20 000 merges too).
  */
 int slg_merge_shards_device(slg_index *index, uint32_t n_shards, uint32_t nq, uint32_t k,
                             const uint32_t *d_doc, const uint32_t *d_seg, const float *d_score,
@@ -317,6 +320,28 @@ int slg_rerank_batch_device(slg_index *index, uint32_t nq, const float *d_qvecs,
                             const uint32_t *d_cand_count, uint32_t max_cand, uint32_t k_out,
                             uint32_t *d_out_doc, uint32_t *d_out_seg, float *d_out_score,
                             float *d_out_vec_score, uint32_t *d_out_count);
+
+/*
+ * Hybrid rerank with several vector clauses over one candidate set (api/reader.rs:225-254;
+ * n_clauses <= SLG_MAX_VECTOR_CLAUSES): qvecs[q][c][dim], alpha[q][c], boost[q][c] (NULL: 1.0; the
+ * clause's similarity is multiplied by it, api/reader.rs:2421).  Blended score = mean over the
+ * clauses of blend(alpha_c, bm25, vec_c); a candidate without a vector counts as -1.0 / f32::MIN in
+ * every clause (:217-223); out_vec_score = sum of the clause similarities (:236-238).  All clauses
+ * use the index's one vector field.  The [candidates x clauses] cosine products run on the f32
+ * matrix cores (v_mfma_f32_16x16x4_f32).  n_clauses * (dim + 4 + max_cand) + 2 * max_cand floats
+ * must fit the kernel's LDS budget (36 Ki floats), else SLG_ERR_UNSUPPORTED.
+ */
+int slg_rerank_multi_batch(slg_index *index, uint32_t nq, uint32_t n_clauses, const float *qvecs,
+                           const float *alpha, const float *boost, const uint32_t *cand_doc,
+                           const uint32_t *cand_seg, const float *cand_bm25, const uint32_t *cand_count,
+                           uint32_t max_cand, uint32_t k_out, uint32_t *out_doc, uint32_t *out_seg,
+                           float *out_score, float *out_vec_score, uint32_t *out_count);
+int slg_rerank_multi_batch_device(slg_index *index, uint32_t nq, uint32_t n_clauses, const float *d_qvecs,
+                                  const float *d_alpha, const float *d_boost, const uint32_t *d_cand_doc,
+                                  const uint32_t *d_cand_seg, const float *d_cand_bm25,
+                                  const uint32_t *d_cand_count, uint32_t max_cand, uint32_t k_out,
+                                  uint32_t *d_out_doc, uint32_t *d_out_seg, float *d_out_score,
+                                  float *d_out_vec_score, uint32_t *d_out_count);
 
 #ifdef __cplusplus
 }

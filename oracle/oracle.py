@@ -99,6 +99,10 @@ def lib():
         L.slo_rerank.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
                                  C.c_void_p, f32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                  C.c_void_p, C.c_void_p, C.c_void_p]
+        L.slo_rerank_multi.restype = C.c_int
+        L.slo_rerank_multi.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -287,4 +291,23 @@ def rerank(metric, vec_offsets, vec_values, qvec, alpha, cand_doc, cand_bm25, k_
     n = lib().slo_rerank(metric, dim, _ptr(vec_offsets), len(vec_offsets), _ptr(vec_values),
                          _ptr(qvec), alpha, _ptr(cand_doc), _ptr(cand_bm25), len(cand_doc), k_out,
                          _ptr(out_doc), _ptr(out_score), _ptr(out_vec))
+    return out_doc[:n].copy(), out_score[:n].copy(), out_vec[:n].copy()
+
+
+def rerank_multi(metric, vec_offsets, vec_values, qvecs, alpha, cand_doc, cand_bm25, k_out, boost=None):
+    """compute_hybrid_score with several clauses (qvecs [n_clauses, dim], alpha [n_clauses])."""
+    vec_offsets = np.ascontiguousarray(vec_offsets, dtype=np.uint32)
+    vec_values = np.ascontiguousarray(vec_values, dtype=np.float32)
+    qvecs = np.ascontiguousarray(qvecs, dtype=np.float32)
+    nc, dim = qvecs.shape
+    alpha = np.ascontiguousarray(alpha, dtype=np.float32)
+    bst = None if boost is None else np.ascontiguousarray(boost, dtype=np.float32)
+    cand_doc = np.ascontiguousarray(cand_doc, dtype=np.uint32)
+    cand_bm25 = np.ascontiguousarray(cand_bm25, dtype=np.float32)
+    out_doc = np.zeros(max(k_out, 1), dtype=np.uint32)
+    out_score = np.zeros(max(k_out, 1), dtype=np.float32)
+    out_vec = np.zeros(max(k_out, 1), dtype=np.float32)
+    n = lib().slo_rerank_multi(metric, dim, _ptr(vec_offsets), len(vec_offsets), _ptr(vec_values), nc,
+                               _ptr(qvecs), _ptr(alpha), _ptr(bst), _ptr(cand_doc), _ptr(cand_bm25),
+                               len(cand_doc), k_out, _ptr(out_doc), _ptr(out_score), _ptr(out_vec))
     return out_doc[:n].copy(), out_score[:n].copy(), out_vec[:n].copy()

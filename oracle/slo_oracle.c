@@ -912,3 +912,52 @@ int slo_rerank(int metric, uint32_t dim, const uint32_t *vec_offsets, uint32_t n
   free(hits);
   return (int)keep;
 }
+
+
+/* api/reader.rs:225-254 compute_hybrid_score with n_clauses vector clauses over one candidate set
+ * (one vector field): per clause vec = boost * metric_similarity (api/reader.rs:2421), missing
+ * vector => missing_vector_score for every clause; blended mean; vector_sum reported. */
+int slo_rerank_multi(int metric, uint32_t dim, const uint32_t *vec_offsets, uint32_t n_docs,
+                     const float *vec_values, uint32_t n_clauses, const float *qvecs, const float *alpha,
+                     const float *boost, const uint32_t *cand_doc, const float *cand_bm25,
+                     uint32_t n_cand, uint32_t k_out, uint32_t *out_doc, float *out_score,
+                     float *out_vec_score) {
+  rr_hit *hits = (rr_hit *)malloc((n_cand ? n_cand : 1) * sizeof(rr_hit));
+  for (uint32_t i = 0; i < n_cand; i++) {
+    uint32_t doc = cand_doc[i];
+    int has = doc < n_docs && vec_offsets[doc] != 0xFFFFFFFFu;
+    float blended_sum = 0.0f, vector_sum = 0.0f;
+    for (uint32_t c = 0; c < n_clauses; c++) {
+      float vs;
+      if (has) {
+        vs = slo_metric_similarity(metric, qvecs + (size_t)c * dim,
+                                   vec_values + (size_t)vec_offsets[doc] * dim, dim);
+        vs *= boost ? boost[c] : 1.0f;
+        vector_sum += vs;
+      } else {
+        vs = slo_missing_vector_score(metric);
+      }
+      float blended;
+      if (alpha[c] >= 1.0f)
+        blended = cand_bm25[i];
+      else if (alpha[c] <= 0.0f)
+        blended = vs;
+      else
+        blended = slo_blend_scores(cand_bm25[i], vs, alpha[c], 1);
+      blended_sum += blended;
+    }
+    float denom = (float)(n_clauses > 1 ? n_clauses : 1);
+    hits[i].score = blended_sum / denom;
+    hits[i].vec = has ? vector_sum : slo_missing_vector_score(metric);
+    hits[i].doc = doc;
+  }
+  qsort(hits, n_cand, sizeof(rr_hit), rr_cmp);
+  uint32_t keep = n_cand < k_out ? n_cand : k_out;
+  for (uint32_t i = 0; i < keep; i++) {
+    out_doc[i] = hits[i].doc;
+    out_score[i] = hits[i].score;
+    if (out_vec_score) out_vec_score[i] = hits[i].vec;
+  }
+  free(hits);
+  return (int)keep;
+}

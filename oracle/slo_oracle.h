@@ -157,4 +157,10 @@ int slo_rerank(int metric, uint32_t dim, const uint32_t *vec_offsets, uint32_t n
 #ifdef __cplusplus
 }
 #endif
+int slo_rerank_multi(int metric, uint32_t dim, const uint32_t *vec_offsets, uint32_t n_docs,
+                     const float *vec_values, uint32_t n_clauses, const float *qvecs, const float *alpha,
+                     const float *boost, const uint32_t *cand_doc, const float *cand_bm25,
+                     uint32_t n_cand, uint32_t k_out, uint32_t *out_doc, float *out_score,
+                     float *out_vec_score);
+
 #endif

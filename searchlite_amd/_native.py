@@ -14,7 +14,8 @@ NO_TERM = 0xFFFFFFFF
 NO_VECTOR = 0xFFFFFFFF
 MAX_QUERY_TERMS = 32
 MAX_K = 20001
-MAX_MERGE_K = 1024
+MAX_RERANK_K = 1024
+MAX_VECTOR_CLAUSES = 8
 
 OK, ERR_INVALID, ERR_DEVICE, ERR_OOM, ERR_UNSUPPORTED, ERR_INTERNAL = 0, -1, -2, -3, -4, -5
 STRATEGY_BM25, STRATEGY_WAND, STRATEGY_BMW = 0, 1, 2
@@ -130,6 +131,10 @@ def load():
         "slg_rerank_batch": (i32, [vp, u32, vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp, vp, vp]),
         "slg_rerank_batch_device": (i32, [vp, u32, vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp,
                                           vp, vp]),
+        "slg_rerank_multi_batch": (i32, [vp, u32, u32, vp, vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp,
+                                         vp, vp]),
+        "slg_rerank_multi_batch_device": (i32, [vp, u32, u32, vp, vp, vp, vp, vp, vp, vp, u32, u32, vp,
+                                                vp, vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)  # AttributeError if the symbol is not exported

@@ -321,6 +321,11 @@ void launch_shard_merge_t(const slg::ShardMergeParams &mp, hipStream_t st) {
   hipLaunchKernelGGL((slg::merge_shards_kernel<KREGS>), dim3(blocks), dim3(256), 0, st, mp);
 }
 void launch_shard_merge(const slg::ShardMergeParams &mp, hipStream_t st) {
+  if (mp.k > 1024u) {  // beyond the register top-k: rank every entry by binary searches
+    hipLaunchKernelGGL(slg::merge_shards_large_kernel, dim3(mp.nq), dim3(256), 0, st, mp);
+    SLG_HIP(hipGetLastError());
+    return;
+  }
   switch (kregs_for(mp.k)) {
     case 1: launch_shard_merge_t<1>(mp, st); break;
     case 2: launch_shard_merge_t<2>(mp, st); break;
@@ -1465,8 +1470,9 @@ int slg_merge_shards_device(slg_index *ix, uint32_t n_shards, uint32_t nq, uint3
                             uint32_t *d_out_seg, float *d_out_score, uint32_t *d_out_count) {
   return guarded([&] {
     SLG_REQUIRE(ix != nullptr, "index is NULL");
-    if (k > SLG_MAX_MERGE_K) throw SlgError(SLG_ERR_UNSUPPORTED, "k > SLG_MAX_MERGE_K");
+    if (k > SLG_MAX_K) throw SlgError(SLG_ERR_UNSUPPORTED, "k > SLG_MAX_K");
     if (nq == 0) return;
+    SLG_REQUIRE(n_shards >= 1, "n_shards == 0");
     SLG_REQUIRE(d_count && d_out_count, "count arrays are NULL");
     SLG_REQUIRE(k == 0 || (d_doc && d_seg && d_score && d_out_doc && d_out_seg && d_out_score),
                 "device arrays are NULL");
@@ -1527,7 +1533,7 @@ int slg_rerank_batch_device(slg_index *ix, uint32_t nq, const float *d_qvecs, co
                             uint32_t *d_out_count) {
   return guarded([&] {
     SLG_REQUIRE(ix != nullptr, "index is NULL");
-    if (k_out > SLG_MAX_MERGE_K) throw SlgError(SLG_ERR_UNSUPPORTED, "k_out > SLG_MAX_MERGE_K");
+    if (k_out > SLG_MAX_RERANK_K) throw SlgError(SLG_ERR_UNSUPPORTED, "k_out > SLG_MAX_RERANK_K");
     if (nq == 0) return;
     SLG_REQUIRE(d_qvecs && d_alpha && d_cand_count && d_out_count, "device arrays are NULL");
     SLG_REQUIRE(max_cand == 0 || (d_cand_doc && d_cand_seg && d_cand_bm25), "candidate arrays are NULL");
@@ -1561,8 +1567,138 @@ int slg_rerank_batch_device(slg_index *ix, uint32_t nq, const float *d_qvecs, co
     rp.out_vec = d_out_vec_score;
     rp.out_count = d_out_count;
     rp.nq = nq;
-    slg::launch_rerank(rp, kregs_for(k_out ? k_out : 1), ix->stream);
-    SLG_HIP(hipGetLastError());
+    SLG_HIP(slg::launch_rerank(rp, kregs_for(k_out ? k_out : 1), ix->stream));
+  });
+}
+
+int slg_rerank_multi_batch_device(slg_index *ix, uint32_t nq, uint32_t n_clauses, const float *d_qvecs,
+                                  const float *d_alpha, const float *d_boost, const uint32_t *d_cand_doc,
+                                  const uint32_t *d_cand_seg, const float *d_cand_bm25,
+                                  const uint32_t *d_cand_count, uint32_t max_cand, uint32_t k_out,
+                                  uint32_t *d_out_doc, uint32_t *d_out_seg, float *d_out_score,
+                                  float *d_out_vec_score, uint32_t *d_out_count) {
+  if (n_clauses == 1 && d_boost == nullptr)  // one clause: the GEMV-shaped VALU kernel
+    return slg_rerank_batch_device(ix, nq, d_qvecs, d_alpha, d_cand_doc, d_cand_seg, d_cand_bm25,
+                                   d_cand_count, max_cand, k_out, d_out_doc, d_out_seg, d_out_score,
+                                   d_out_vec_score, d_out_count);
+  return guarded([&] {
+    SLG_REQUIRE(ix != nullptr, "index is NULL");
+    if (n_clauses < 1 || n_clauses > SLG_MAX_VECTOR_CLAUSES)
+      throw SlgError(SLG_ERR_UNSUPPORTED, "n_clauses outside 1..SLG_MAX_VECTOR_CLAUSES");
+    if (k_out > SLG_MAX_RERANK_K) throw SlgError(SLG_ERR_UNSUPPORTED, "k_out > SLG_MAX_RERANK_K");
+    if (nq == 0) return;
+    SLG_REQUIRE(d_qvecs && d_alpha && d_cand_count && d_out_count, "device arrays are NULL");
+    SLG_REQUIRE(max_cand == 0 || (d_cand_doc && d_cand_seg && d_cand_bm25), "candidate arrays are NULL");
+    SLG_REQUIRE(k_out == 0 || (d_out_doc && d_out_seg && d_out_score), "output arrays are NULL");
+    uint32_t dim = 0;
+    int32_t metric = -1;
+    for (auto &s : ix->segs) {
+      if (!s->vec_dim) continue;
+      SLG_REQUIRE(dim == 0 || dim == s->vec_dim, "segments disagree on vec_dim");
+      SLG_REQUIRE(metric < 0 || metric == s->vec_metric, "segments disagree on the vector metric");
+      dim = s->vec_dim;
+      metric = s->vec_metric;
+    }
+    if (dim == 0) throw SlgError(SLG_ERR_UNSUPPORTED, "index has no vector field");
+    for (auto &s : ix->segs)
+      if (!s->vec_dim) throw SlgError(SLG_ERR_UNSUPPORTED, "multi-clause rerank needs the vector field in every segment");
+    if (slg::rerank_multi_lds_floats(n_clauses, dim, max_cand) > slg::kRerankMultiLdsFloats)
+      throw SlgError(SLG_ERR_UNSUPPORTED, "n_clauses * (dim + max_cand) exceeds the LDS budget of the multi-clause rerank");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    slg::RerankMultiParams mp{};
+    slg::RerankParams &rp = mp.base;
+    rp.vsegs = ix->d_vsegs.as<slg::VecSegDev>();
+    rp.n_segs = (uint32_t)ix->segs.size();
+    rp.dim = dim;
+    rp.qvecs = d_qvecs;
+    rp.alpha = d_alpha;
+    rp.cand_doc = d_cand_doc;
+    rp.cand_seg = d_cand_seg;
+    rp.cand_bm25 = d_cand_bm25;
+    rp.cand_count = d_cand_count;
+    rp.max_cand = max_cand;
+    rp.k_out = k_out;
+    rp.out_doc = d_out_doc;
+    rp.out_seg = d_out_seg;
+    rp.out_score = d_out_score;
+    rp.out_vec = d_out_vec_score;
+    rp.out_count = d_out_count;
+    rp.nq = nq;
+    mp.boost = d_boost;
+    mp.n_clauses = n_clauses;
+    mp.q_stride = dim + 4;
+    SLG_HIP(slg::launch_rerank_multi(mp, kregs_for(k_out ? k_out : 1), ix->stream));
+  });
+}
+
+int slg_rerank_multi_batch(slg_index *ix, uint32_t nq, uint32_t n_clauses, const float *qvecs,
+                           const float *alpha, const float *boost, const uint32_t *cand_doc,
+                           const uint32_t *cand_seg, const float *cand_bm25, const uint32_t *cand_count,
+                           uint32_t max_cand, uint32_t k_out, uint32_t *out_doc, uint32_t *out_seg,
+                           float *out_score, float *out_vec_score, uint32_t *out_count) {
+  int rc = guarded([&] {
+    SLG_REQUIRE(ix != nullptr, "index is NULL");
+    if (n_clauses < 1 || n_clauses > SLG_MAX_VECTOR_CLAUSES)
+      throw SlgError(SLG_ERR_UNSUPPORTED, "n_clauses outside 1..SLG_MAX_VECTOR_CLAUSES");
+    if (nq == 0) return;
+    SLG_REQUIRE(qvecs && alpha && cand_count && out_count, "host arrays are NULL");
+    SLG_REQUIRE(max_cand == 0 || (cand_doc && cand_seg && cand_bm25), "candidate arrays are NULL");
+    SLG_REQUIRE(k_out == 0 || (out_doc && out_seg && out_score), "output arrays are NULL");
+  });
+  if (rc != SLG_OK || nq == 0) return rc;
+  uint32_t dim = 0;
+  for (auto &s : ix->segs)
+    if (s->vec_dim) dim = s->vec_dim;
+  if (dim == 0) {
+    g_last_error = "index has no vector field";
+    g_last_code = SLG_ERR_UNSUPPORTED;
+    return SLG_ERR_UNSUPPORTED;
+  }
+  DevBuf dq, da, db, dcd, dcs, dcb, dcc, dod, dos, dosc, dov, doc_;
+  const size_t nc = (size_t)nq * max_cand, no = (size_t)nq * k_out, nqc = (size_t)nq * n_clauses;
+  rc = guarded([&] {
+    DeviceGuard g(ix->device);
+    hipStream_t st = ix->stream;
+    dq.alloc(nqc * dim * 4);
+    da.alloc(nqc * 4);
+    if (boost) db.alloc(nqc * 4);
+    dcd.alloc(nc * 4);
+    dcs.alloc(nc * 4);
+    dcb.alloc(nc * 4);
+    dcc.alloc((size_t)nq * 4);
+    dod.alloc(no * 4);
+    dos.alloc(no * 4);
+    dosc.alloc(no * 4);
+    dov.alloc(no * 4);
+    doc_.alloc((size_t)nq * 4);
+    SLG_HIP(hipMemcpyAsync(dq.p, qvecs, nqc * dim * 4, hipMemcpyHostToDevice, st));
+    SLG_HIP(hipMemcpyAsync(da.p, alpha, nqc * 4, hipMemcpyHostToDevice, st));
+    if (boost) SLG_HIP(hipMemcpyAsync(db.p, boost, nqc * 4, hipMemcpyHostToDevice, st));
+    if (nc) {
+      SLG_HIP(hipMemcpyAsync(dcd.p, cand_doc, nc * 4, hipMemcpyHostToDevice, st));
+      SLG_HIP(hipMemcpyAsync(dcs.p, cand_seg, nc * 4, hipMemcpyHostToDevice, st));
+      SLG_HIP(hipMemcpyAsync(dcb.p, cand_bm25, nc * 4, hipMemcpyHostToDevice, st));
+    }
+    SLG_HIP(hipMemcpyAsync(dcc.p, cand_count, (size_t)nq * 4, hipMemcpyHostToDevice, st));
+  });
+  if (rc != SLG_OK) return rc;
+  rc = slg_rerank_multi_batch_device(ix, nq, n_clauses, dq.as<float>(), da.as<float>(),
+                                     boost ? db.as<float>() : nullptr, dcd.as<uint32_t>(), dcs.as<uint32_t>(),
+                                     dcb.as<float>(), dcc.as<uint32_t>(), max_cand, k_out, dod.as<uint32_t>(),
+                                     dos.as<uint32_t>(), dosc.as<float>(), dov.as<float>(), doc_.as<uint32_t>());
+  if (rc != SLG_OK) return rc;
+  return guarded([&] {
+    DeviceGuard g(ix->device);
+    hipStream_t st = ix->stream;
+    if (no) {
+      SLG_HIP(hipMemcpyAsync(out_doc, dod.p, no * 4, hipMemcpyDeviceToHost, st));
+      SLG_HIP(hipMemcpyAsync(out_seg, dos.p, no * 4, hipMemcpyDeviceToHost, st));
+      SLG_HIP(hipMemcpyAsync(out_score, dosc.p, no * 4, hipMemcpyDeviceToHost, st));
+      if (out_vec_score) SLG_HIP(hipMemcpyAsync(out_vec_score, dov.p, no * 4, hipMemcpyDeviceToHost, st));
+    }
+    SLG_HIP(hipMemcpyAsync(out_count, doc_.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    SLG_HIP(hipStreamSynchronize(st));
   });
 }
 

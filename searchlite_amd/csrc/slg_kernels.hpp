@@ -595,6 +595,56 @@ __global__ void __launch_bounds__(256) merge_shards_kernel(ShardMergeParams p) {
 }
 
 
+// ---- the same merge for k beyond the register top-k (k up to 20 001, api/reader.rs:2615-2619) --
+// Every shard's row is already sorted by (score desc, segment asc, doc asc) and keys are unique,
+// so the global rank of an entry = its own index + the number of better entries in every other
+// shard's row (a binary search each); entries ranked below k write themselves to out[rank].
+// One workgroup per query.
+static __global__ void __launch_bounds__(256) merge_shards_large_kernel(ShardMergeParams p) {
+  const uint32_t q = blockIdx.x;
+  if (q >= p.nq) return;
+  const uint32_t k = p.k;
+  uint32_t total = 0;
+  for (uint32_t sh = 0; sh < p.n_shards; sh++) {
+    const uint32_t c = p.count[(size_t)sh * p.nq + q];
+    total += c < k ? c : k;
+  }
+  const uint32_t nout = total < k ? total : k;
+  for (uint32_t e = threadIdx.x; e < p.n_shards * k; e += blockDim.x) {
+    const uint32_t sh = e / k, i = e % k;
+    const uint32_t cnt_s = p.count[(size_t)sh * p.nq + q] < k ? p.count[(size_t)sh * p.nq + q] : k;
+    if (i >= cnt_s) continue;
+    const size_t row = ((size_t)sh * p.nq + q) * k;
+    const int32_t tk = total_key(p.score[row + i]);
+    const uint32_t doc = p.doc[row + i], seg = sh * p.seg_stride + p.seg[row + i];
+    uint32_t rank = i;
+    for (uint32_t t = 0; t < p.n_shards; t++) {
+      if (t == sh) continue;
+      const size_t rt = ((size_t)t * p.nq + q) * k;
+      uint32_t lo = 0, hi = p.count[(size_t)t * p.nq + q] < k ? p.count[(size_t)t * p.nq + q] : k;
+      while (lo < hi) {  // first entry of shard t that is NOT better than mine
+        const uint32_t mid = (lo + hi) >> 1;
+        if (better<true>(total_key(p.score[rt + mid]), t * p.seg_stride + p.seg[rt + mid], p.doc[rt + mid], tk, seg, doc))
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      rank += lo;
+    }
+    if (rank < k) {
+      p.out_doc[(size_t)q * k + rank] = doc;
+      p.out_seg[(size_t)q * k + rank] = seg;
+      p.out_score[(size_t)q * k + rank] = p.score[row + i];
+    }
+  }
+  for (uint32_t i = nout + threadIdx.x; i < k; i += blockDim.x) {
+    p.out_doc[(size_t)q * k + i] = 0u;
+    p.out_seg[(size_t)q * k + i] = 0u;
+    p.out_score[(size_t)q * k + i] = 0.0f;
+  }
+  if (threadIdx.x == 0) p.out_count[q] = nout;
+}
+
 // ---- doc filters (accept = !deleted && filter, api/reader.rs:3009-3018) -----------
 // A filter is kept per segment as a REJECT bitmap (deleted | ~filter, bit d of word d/32) so the
 // scoring kernels use it exactly like the tombstone bitmap.

@@ -6,7 +6,9 @@
 //
 // The path is an HBM row gather (one D-float row per candidate, 0.5 flop/byte): each wave
 // streams whole rows with 16-byte lane loads, reduces in-register, and a wave-wide sorted
-// top-k (slg_kernels.hpp) picks the k_out best blended scores.
+// top-k (slg_kernels.hpp) picks the k_out best blended scores.  One clause: rerank_kernel
+// (VALU; the contraction is a GEMV).  Several clauses sharing a candidate set:
+// rerank_multi_kernel, whose [candidates x clauses] products run on v_mfma_f32_16x16x4_f32.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -228,15 +230,233 @@ __global__ void __launch_bounds__(256) rerank_kernel(RerankParams p) {
   if (lane == 0) p.out_count[q] = top.count;
 }
 
-inline void launch_rerank(const RerankParams &rp, int kregs, hipStream_t st) {
-  const size_t lds = (size_t)rp.max_cand * 8 + 16;
-  dim3 grid(rp.nq), block(256);
+// ---- hybrid rerank with several vector clauses (api/reader.rs:225-254, MAX_VECTOR_CLAUSES = 8) ----
+// score(doc) = mean over clauses c of blend(alpha_c, bm25, vec_c), vec_c = boost_c * similarity
+// (api/reader.rs:2421 `vscore *= clause.boost`), a missing vector counts as -1.0 / f32::MIN per
+// clause (:217-223); the vector score reported is the sum over the clauses (:236-238).
+// All clauses of a query share its candidate set, so the [candidates x clauses] similarities are
+// a small GEMM: for cosine (= dot of pre-normalized vectors, vectors/mod.rs:107-117) it runs on
+// the f32 matrix cores, one v_mfma_f32_16x16x4_f32 tile = 16 candidates x 16 clause columns
+// (<= 8 live) per wave.  Lane l feeds A[cand l&15][k-group l>>4] and B[k-group l>>4][clause l&15]
+// with one float4 each per 16 k values (four MFMAs: component c of every lane is one k-step, the
+// same k permutation on both operands), so a candidate row is read as four 16-byte lanes = whole
+// 64-byte sectors.  D[row 4*(l>>4)+r][col l&15] = the dot of candidate row / clause col.
+// L2 (-sqrt sum (x - y)^2, vectors/mod.rs:98-105,118) and dimensions that are not a multiple of 16
+// take the VALU path.  The path is an HBM row gather either way.
+struct RerankMultiParams {
+  RerankParams base;       // qvecs: [nq][n_clauses][dim]; alpha: [nq][n_clauses]
+  const float *boost;      // [nq][n_clauses] or nullptr (1.0)
+  uint32_t n_clauses;      // 1..8
+  uint32_t q_stride;       // padded LDS row of one clause vector (floats): dim + 4
+};
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t kRerankMultiLdsFloats = 36 * 1024;  // clause vectors + per-clause scores + blends
+
+template <int KREGS>
+__global__ void __launch_bounds__(256) rerank_multi_kernel(RerankMultiParams mp) {
+  const RerankParams &p = mp.base;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t q = blockIdx.x;
+  const uint32_t NC = mp.n_clauses, dim = p.dim, qs = mp.q_stride;
+  uint32_t n = p.cand_count[q];
+  n = n < p.max_cand ? n : p.max_cand;
+  float *s_q = reinterpret_cast<float *>(smem);     // [NC][qs]
+  float *s_vs = s_q + NC * qs;                      // [NC][max_cand] similarity (boost applied)
+  float *s_blend = s_vs + NC * p.max_cand;          // [max_cand]
+  float *s_vsum = s_blend + p.max_cand;             // [max_cand]
+  const uint32_t *cdoc = p.cand_doc + (size_t)q * p.max_cand;
+  const uint32_t *cseg = p.cand_seg + (size_t)q * p.max_cand;
+  const float *cbm = p.cand_bm25 + (size_t)q * p.max_cand;
+  const int32_t metric = p.vsegs[0].metric;  // one vector field: the same metric in every segment
+
+  for (uint32_t i = threadIdx.x; i < NC * dim; i += 256)
+    s_q[(i / dim) * qs + (i % dim)] = p.qvecs[(size_t)q * NC * dim + i];
+  __syncthreads();
+
+  // row of candidate c, or nullptr (missing vector / out of range)
+  auto row_of = [&](const uint32_t c) -> const float * {
+    if (c >= n) return nullptr;
+    const uint32_t doc = cdoc[c], seg = cseg[c];
+    if (seg >= p.n_segs) return nullptr;
+    const VecSegDev vd = p.vsegs[seg];
+    if (vd.dim != dim || doc >= vd.n_docs) return nullptr;
+    const uint32_t off = vd.offsets[doc];
+    return off == 0xFFFFFFFFu ? nullptr : vd.values + (size_t)off * dim;
+  };
+
+  if (metric == 0 && (dim & 15u) == 0) {
+    // ---- cosine on the matrix cores: tiles of 16 candidates, round-robin over the 4 waves ----
+    const uint32_t g = lane >> 4, cl = lane & 15u;
+    for (uint32_t t0 = wave * 16; t0 < n; t0 += 64) {
+      const float *row = row_of(t0 + cl);
+      const float *qrow = cl < NC ? s_q + cl * qs : nullptr;
+      f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
+      for (uint32_t kb = 4 * g; kb < dim; kb += 16) {
+        const float4 a = row ? *reinterpret_cast<const float4 *>(row + kb) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 b = qrow ? *reinterpret_cast<const float4 *>(qrow + kb) : make_float4(0.f, 0.f, 0.f, 0.f);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+      }
+      if (cl < NC) {  // lane holds D[candidate t0 + 4g + r][clause cl]
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const uint32_t c = t0 + 4 * g + r;
+          const float d = acc[r];
+          if (c < n) s_vs[cl * p.max_cand + c] = d != d ? 0.0f : d;  // vectors/mod.rs:112-116 NaN -> 0
+        }
+      }
+    }
+  } else {
+    // ---- VALU path: one candidate per wave at a time, every clause against the same row ----
+    for (uint32_t c = wave; c < n; c += 4) {
+      const float *row = row_of(c);
+      for (uint32_t cc = 0; cc < NC; cc++) {
+        float acc = 0.0f;
+        if (row)
+          for (uint32_t i = lane; i < dim; i += 64) {
+            const float a = s_q[cc * qs + i], bb = row[i];
+            if (metric == 0) {
+              acc += a * bb;
+            } else {
+              const float d = a - bb;
+              acc += d * d;
+            }
+          }
+        const float sum = wave_sum_f(acc);
+        if (lane == 0) s_vs[cc * p.max_cand + c] = metric == 0 ? (sum != sum ? 0.0f : sum) : -sqrtf(sum);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- compute_hybrid_score (api/reader.rs:225-254) per candidate, clauses in order ----
+  for (uint32_t c = threadIdx.x; c < n; c += 256) {
+    const bool has = row_of(c) != nullptr;
+    const float bm = cbm[c];
+    float blended_sum = 0.0f, vector_sum = 0.0f;
+    for (uint32_t cc = 0; cc < NC; cc++) {
+      const float alpha = p.alpha[(size_t)q * NC + cc];
+      float vs;
+      if (has) {
+        vs = s_vs[cc * p.max_cand + c] * (mp.boost ? mp.boost[(size_t)q * NC + cc] : 1.0f);
+        vector_sum += vs;
+      } else {
+        vs = metric == 0 ? -1.0f : -3.40282347e+38f;  // missing_vector_score
+      }
+      float blended;
+      if (alpha >= 1.0f)
+        blended = bm;
+      else if (alpha <= 0.0f)
+        blended = vs;
+      else
+        blended = alpha * bm + (1.0f - alpha) * vs;
+      blended_sum += blended;
+    }
+    s_blend[c] = blended_sum / (float)NC;
+    s_vsum[c] = has ? vector_sum : (metric == 0 ? -1.0f : -3.40282347e+38f);
+  }
+  __syncthreads();
+  if (wave != 0) return;
+
+  const uint32_t k = p.k_out;
+  if (k == 0) {
+    if (lane == 0) p.out_count[q] = 0;
+    return;
+  }
+  WaveTopK<KREGS, true> top;
+  top.init();
+  for (uint32_t base = 0; base < n; base += 64) {
+    const uint32_t i = base + lane;
+    int32_t ctk = kSentinelTk;
+    uint32_t d = 0xFFFFFFFFu, sg = 0xFFFFFFFFu;
+    if (i < n) {
+      ctk = total_key(s_blend[i]);
+      d = cdoc[i];
+      sg = cseg[i];
+    }
+    uint64_t m = __ballot(i < n && top.passes(ctk, sg, d));
+    while (m) {
+      const uint32_t l = (uint32_t)__builtin_ctzll(m);
+      top.insert((int32_t)rl((uint32_t)ctk, l), rl(sg, l), rl(d, l), k, lane);
+      m &= m - 1;
+      m &= __ballot(top.passes(ctk, sg, d));
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < KREGS; r++) {
+    const uint32_t pos = lane * KREGS + r;
+    if (pos < k) {
+      const bool real = pos < top.count;
+      p.out_doc[(size_t)q * k + pos] = real ? top.doc[r] : 0u;
+      p.out_seg[(size_t)q * k + pos] = real ? top.seg[r] : 0u;
+      p.out_score[(size_t)q * k + pos] = real ? key_to_float(top.tk[r]) : 0.0f;
+    }
+  }
+  if (p.out_vec) {
+    const uint32_t nout = top.count < k ? top.count : k;
+    for (uint32_t pos = 0; pos < nout; pos++) {
+      const uint32_t pl = pos / KREGS, pr = pos % KREGS;
+      uint32_t wd = top.doc[0], ws = top.seg[0];
+#pragma unroll
+      for (int r = 1; r < KREGS; r++) {
+        wd = pr == (uint32_t)r ? top.doc[r] : wd;
+        ws = pr == (uint32_t)r ? top.seg[r] : ws;
+      }
+      wd = rl(wd, pl);
+      ws = rl(ws, pl);
+      for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + lane;
+        const bool match = i < n && cdoc[i] == wd && cseg[i] == ws;
+        const uint64_t mm = __ballot(match);
+        if (mm) {
+          if (lane == (uint32_t)__builtin_ctzll(mm)) p.out_vec[(size_t)q * k + pos] = s_vsum[i];
+          break;
+        }
+      }
+    }
+    for (uint32_t pos = nout + lane; pos < k; pos += 64) p.out_vec[(size_t)q * k + pos] = 0.0f;
+  }
+  if (lane == 0) p.out_count[q] = top.count;
+}
+
+inline size_t rerank_multi_lds_floats(uint32_t n_clauses, uint32_t dim, uint32_t max_cand) {
+  return (size_t)n_clauses * (dim + 4) + (size_t)n_clauses * max_cand + 2 * (size_t)max_cand;
+}
+
+template <typename K, typename P>
+inline hipError_t launch_with_lds(K kernel, const P &params, uint32_t nq, size_t lds, hipStream_t st) {
+  if (lds > 48 * 1024) {  // above the default dynamic-LDS limit: opt in (up to the CU's 160 KiB)
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kernel, dim3(nq), dim3(256), lds, st, params);
+  return hipGetLastError();
+}
+
+inline hipError_t launch_rerank_multi(const RerankMultiParams &mp, int kregs, hipStream_t st) {
+  const size_t lds = rerank_multi_lds_floats(mp.n_clauses, mp.base.dim, mp.base.max_cand) * 4 + 16;
   switch (kregs) {
-    case 1: hipLaunchKernelGGL((rerank_kernel<1>), grid, block, lds, st, rp); break;
-    case 2: hipLaunchKernelGGL((rerank_kernel<2>), grid, block, lds, st, rp); break;
-    case 4: hipLaunchKernelGGL((rerank_kernel<4>), grid, block, lds, st, rp); break;
-    case 8: hipLaunchKernelGGL((rerank_kernel<8>), grid, block, lds, st, rp); break;
-    default: hipLaunchKernelGGL((rerank_kernel<16>), grid, block, lds, st, rp); break;
+    case 1: return launch_with_lds(rerank_multi_kernel<1>, mp, mp.base.nq, lds, st);
+    case 2: return launch_with_lds(rerank_multi_kernel<2>, mp, mp.base.nq, lds, st);
+    case 4: return launch_with_lds(rerank_multi_kernel<4>, mp, mp.base.nq, lds, st);
+    case 8: return launch_with_lds(rerank_multi_kernel<8>, mp, mp.base.nq, lds, st);
+    default: return launch_with_lds(rerank_multi_kernel<16>, mp, mp.base.nq, lds, st);
+  }
+}
+
+inline hipError_t launch_rerank(const RerankParams &rp, int kregs, hipStream_t st) {
+  const size_t lds = (size_t)rp.max_cand * 8 + 16;
+  switch (kregs) {
+    case 1: return launch_with_lds(rerank_kernel<1>, rp, rp.nq, lds, st);
+    case 2: return launch_with_lds(rerank_kernel<2>, rp, rp.nq, lds, st);
+    case 4: return launch_with_lds(rerank_kernel<4>, rp, rp.nq, lds, st);
+    case 8: return launch_with_lds(rerank_kernel<8>, rp, rp.nq, lds, st);
+    default: return launch_with_lds(rerank_kernel<16>, rp, rp.nq, lds, st);
   }
 }
 

@@ -252,6 +252,31 @@ class GpuIndex:
                                            _ptr(out_score), _ptr(out_vec), _ptr(out_count)))
         return out_doc, out_seg, out_score, out_vec, out_count
 
+    def rerank_multi_batch(self, qvecs, alpha, cand_doc, cand_seg, cand_bm25, cand_count, k_out: int,
+                           boost=None):
+        """Hybrid rerank with several vector clauses (compute_hybrid_score, api/reader.rs:225-254):
+        qvecs [nq, n_clauses, dim], alpha / boost [nq, n_clauses]."""
+        qvecs = np.ascontiguousarray(qvecs, dtype=np.float32)
+        nq, nc = qvecs.shape[0], qvecs.shape[1]
+        alpha = np.ascontiguousarray(np.broadcast_to(np.asarray(alpha, dtype=np.float32), (nq, nc)))
+        bst = None if boost is None else \
+            np.ascontiguousarray(np.broadcast_to(np.asarray(boost, dtype=np.float32), (nq, nc)))
+        cand_doc = np.ascontiguousarray(cand_doc, dtype=np.uint32).reshape(nq, -1)
+        max_cand = cand_doc.shape[1]
+        cand_seg = np.ascontiguousarray(cand_seg, dtype=np.uint32).reshape(nq, max_cand)
+        cand_bm25 = np.ascontiguousarray(cand_bm25, dtype=np.float32).reshape(nq, max_cand)
+        cand_count = np.ascontiguousarray(cand_count, dtype=np.uint32)
+        out_doc = np.zeros((nq, k_out), dtype=np.uint32)
+        out_seg = np.zeros((nq, k_out), dtype=np.uint32)
+        out_score = np.zeros((nq, k_out), dtype=np.float32)
+        out_vec = np.zeros((nq, k_out), dtype=np.float32)
+        out_count = np.zeros(nq, dtype=np.uint32)
+        N.check(self._lib.slg_rerank_multi_batch(
+            self._h, nq, nc, _ptr(qvecs), _ptr(alpha), _ptr(bst), _ptr(cand_doc), _ptr(cand_seg),
+            _ptr(cand_bm25), _ptr(cand_count), max_cand, k_out, _ptr(out_doc), _ptr(out_seg),
+            _ptr(out_score), _ptr(out_vec), _ptr(out_count)))
+        return out_doc, out_seg, out_score, out_vec, out_count
+
     def rerank_batch_device(self, nq, d_qvecs, d_alpha, d_cand_doc, d_cand_seg, d_cand_bm25,
                             d_cand_count, max_cand, k_out, d_out_doc, d_out_seg, d_out_score,
                             d_out_vec, d_out_count) -> None:

@@ -234,3 +234,41 @@ def test_recipes_index_files_reproduce_the_goldens(gpu, tmp_path):
         for strat in (gpu.Bm25, gpu.Wand, gpu.Bmw):
             got = ix.search_batch(z["q_offsets"], z["q_terms"], z["q_weights"], int(z["k"]), strat)
             assert_same_hits(got, golden_expected(z), 0.0, f"recipes from index files, strategy {strat}")
+
+
+@pytest.mark.parametrize("k", [1025, 3000])
+def test_merge_shards_beyond_the_register_top_k(gpu, oracle, k):
+    """slg_merge_shards_device for k > 1024 (an index-sharded request with limit up to 20 000,
+    api/reader.rs:2595-2619): three shards scored alone, merged on the device, against the oracle
+    run on the three shards as three segments (ties across shards included: small vocabulary)."""
+    import torch
+    from searchlite_amd import dist as sdist
+    rng = np.random.default_rng(77)
+    segs = [random_segment(rng, 4000 + 500 * i, 12, 8, zipf=False) for i in range(3)]
+    nq = 6
+    offs, terms, w = random_queries(rng, nq, 3, 12, n_segs=3)
+    want = oracle.search_batch(segs, offs, terms, w, k, strategy=oracle.BM25)
+    blocks, keep = [], []
+    for i, seg in enumerate(segs):
+        ix = gpu.GpuIndex([seg])
+        ix.set_stream(torch.cuda.current_stream().cuda_stream)
+        b = ix.prepare(offs, terms[:, i:i + 1].copy(), w, k)
+        b.run()
+        blocks.append(sdist.batch_result_block(b).clone())
+        keep.append((ix, b))
+    g = torch.stack(blocks)
+    g_doc, g_seg, g_score, g_count = [x.contiguous() for x in sdist.split_result_block(g, nq, k)]
+    m_doc = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+    m_seg = torch.empty_like(m_doc)
+    m_score = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    m_count = torch.empty((nq,), dtype=torch.int32, device="cuda")
+    keep[0][0].merge_shards_device(3, nq, k, g_doc.data_ptr(), g_seg.data_ptr(), g_score.data_ptr(),
+                                   g_count.data_ptr(), 1, m_doc.data_ptr(), m_seg.data_ptr(),
+                                   m_score.data_ptr(), m_count.data_ptr())
+    torch.cuda.synchronize()
+    got = (m_doc.cpu().numpy().view(np.uint32), m_seg.cpu().numpy().view(np.uint32),
+           m_score.cpu().numpy(), m_count.cpu().numpy().view(np.uint32))
+    assert_same_hits(got, want, 0.0, f"merge_shards_device k={k}")
+    for ix, b in keep:
+        b.close()
+        ix.close()

@@ -104,3 +104,80 @@ def test_hybrid_blends_text_and_vector_gpu(oracle):
                                                 np.zeros_like(d), sc, np.array([2]), 2)
     assert seg.ext_ids[int(od[0, 0])] == "short"
     assert osc[0, 0] == np.float32(np.float32(0.2) * np.float32(1.1046511) + np.float32(0.8))
+
+
+@pytest.mark.parametrize("n_clauses", [1, 2, 8])
+@pytest.mark.parametrize("metric", [0, 1])
+def test_rerank_multi_clause(oracle, n_clauses, metric):
+    """compute_hybrid_score (api/reader.rs:225-254) with 1 / 2 / 8 vector clauses over one
+    candidate set, at the config-5 shape (768-d, 1001 candidates -> 10): mean of the per-clause
+    blends, clause boosts, missing vectors as -1.0 / f32::MIN.  Cosine runs on the f32 matrix
+    cores (v_mfma_f32_16x16x4_f32: an fmaf chain, the reference sums products left to right), so
+    the tolerance is the single-clause one, 1e-5."""
+    import searchlite_amd as sa
+    from searchlite_amd import corpus
+    rng = np.random.default_rng(100 + n_clauses)
+    n, dim, ncand, k_out, nq = 4000, 768, 1001, 10, 5
+    vals = corpus.unit_vectors(n, dim, seed=21)
+    offsets = np.arange(n, dtype=np.uint32)
+    offsets[rng.choice(n, size=300, replace=False)] = 0xFFFFFFFF
+    q = corpus.unit_vectors(nq * n_clauses, dim, seed=22).reshape(nq, n_clauses, dim)
+    cand = np.stack([rng.choice(n, size=ncand, replace=False) for _ in range(nq)]).astype(np.uint32)
+    bm = (rng.random((nq, ncand)) * 20).astype(np.float32)
+    cnt = np.full(nq, ncand, np.uint32)
+    cnt[2] = 333
+    alpha = rng.choice(np.array([0.0, 0.2, 0.5, 0.8, 1.0], np.float32), size=(nq, n_clauses))
+    boost = (rng.random((nq, n_clauses)) * 1.5 + 0.5).astype(np.float32)
+    seg = _segment_with_vectors(n, offsets, vals, metric)
+    with sa.GpuIndex([seg]) as ix:
+        for bst in (None, boost):
+            got = ix.rerank_multi_batch(q, alpha, cand, np.zeros_like(cand), bm, cnt, k_out, boost=bst)
+            wd, ws, wv = [], [], []
+            for i in range(nq):
+                d_, s_, v_ = oracle.rerank_multi(metric, offsets, vals, q[i], alpha[i], cand[i, :cnt[i]],
+                                                 bm[i, :cnt[i]], k_out, boost=None if bst is None else bst[i])
+                wd.append(d_)
+                ws.append(s_)
+                wv.append(v_)
+            global TOL
+            tol_save = TOL
+            TOL = 1e-5 * max(1, n_clauses // 2)  # the reported vector score is a SUM over the clauses
+            try:
+                _check(got, wd, ws, wv, f"{n_clauses} clauses metric {metric} boost {bst is not None}")
+            finally:
+                TOL = tol_save
+
+
+def test_rerank_multi_matches_single_clause_kernel():
+    """One clause through the multi-clause entry (with a boost of 1.0, which takes the MFMA kernel)
+    agrees with the GEMV-shaped single-clause kernel."""
+    import searchlite_amd as sa
+    from searchlite_amd import corpus
+    rng = np.random.default_rng(5)
+    n, dim, ncand, nq = 2000, 64, 200, 4
+    vals = corpus.unit_vectors(n, dim, seed=3)
+    offsets = np.arange(n, dtype=np.uint32)
+    q = corpus.unit_vectors(nq, dim, seed=4)
+    cand = np.stack([rng.choice(n, size=ncand, replace=False) for _ in range(nq)]).astype(np.uint32)
+    bm = (rng.random((nq, ncand)) * 5).astype(np.float32)
+    cnt = np.full(nq, ncand, np.uint32)
+    seg = _segment_with_vectors(n, offsets, vals, 0)
+    with sa.GpuIndex([seg]) as ix:
+        a = ix.rerank_batch(q, 0.5, cand, np.zeros_like(cand), bm, cnt, 20)
+        b = ix.rerank_multi_batch(q[:, None, :], np.full((nq, 1), 0.5, np.float32), cand, np.zeros_like(cand),
+                                  bm, cnt, 20, boost=np.ones((nq, 1), np.float32))
+    assert np.abs(a[2] - b[2]).max() <= TOL and np.abs(a[3] - b[3]).max() <= TOL
+    assert (a[4] == b[4]).all()
+
+
+def test_rerank_multi_limits():
+    import searchlite_amd as sa
+    from searchlite_amd import _native as N
+    vals = np.eye(8, dtype=np.float32)
+    seg = _segment_with_vectors(8, np.arange(8, dtype=np.uint32), vals, 0)
+    with sa.GpuIndex([seg]) as ix:
+        c = np.zeros((1, 4), np.uint32)
+        with pytest.raises(N.SlgError) as e:
+            ix.rerank_multi_batch(np.zeros((1, 9, 8), np.float32), 0.5, c, c, np.zeros((1, 4), np.float32),
+                                  np.array([4], np.uint32), 2)
+        assert e.value.code == N.ERR_UNSUPPORTED  # > MAX_VECTOR_CLAUSES (api/reader.rs:134)
