@@ -1,0 +1,399 @@
+//! searchlite-core/src/gpu/mod.rs — the `gpu` cargo feature (searchlite-core/Cargo.toml:13,
+//! src/lib.rs:11-12): MI355X batched BM25 top-k scorer + vector rerank behind IndexReader::search.
+//!
+//! UNVERIFIED SOURCE (no Rust toolchain in the build image of the GPU library; never compiled).
+//! Written against these items of the surveyed snapshot:
+//!   index/segment.rs:1328-1390   SegmentReader::{postings, avg_field_length, live_docs, is_deleted,
+//!                                fast_fields, terms_with_prefix, vector_components}, `meta.doc_count`
+//!   index/postings.rs:133-228    PostingsReader::{entries, len}, PostingEntry{doc_id, term_freq}
+//!   index/fastfields.rs:683,1162 FastFieldsReader::i64_value, doc_length_key
+//!   vectors/mod.rs:35-61         VectorStore::{dim, metric, offsets, values}
+//!   api/reader.rs:904-910        QualifiedTerm{field, term, key, weight, leaf}
+//!   api/reader.rs:2539-2906      IndexReader::search (call site, k = effective_limit + 1)
+//!   api/reader.rs:2971-3000      term folding + ScoredTerm construction this module replaces
+//!   api/reader.rs:3009-3036      accept = !deleted && matcher && filter && cursor
+//!   query/planner.rs:88-165,207-213  QueryMatcher, QueryStringMatcher, ScoreExpr, ScorePlan, QueryPlan
+//!   query/sort.rs:220-237        SortPlan::{is_score_only, primary_order}
+//!   api/types.rs:396-439         SearchRequest
+//!
+//! Everything that is not eligible (below) keeps running on the CPU scorer; a non-zero return code
+//! of the library also falls back to it — the GPU path never substitutes results silently.
+
+pub mod ffi;
+pub mod rerank;
+
+use std::collections::HashMap;
+use std::ffi::CStr;
+use std::sync::Mutex;
+
+use anyhow::{anyhow, bail, Result};
+
+use crate::api::types::{ExecutionStrategy, Filter, SearchRequest, SortOrder};
+use crate::index::fastfields::doc_length_key;
+use crate::index::segment::SegmentReader;
+use crate::query::filters::passes_filter;
+use crate::query::planner::{QueryMatcher, QueryPlan, ScoreExpr};
+use crate::query::sort::SortPlan;
+use crate::DocId;
+
+/// SLG_MAX_QUERY_TERMS / SLG_MAX_K of include/searchlite_gpu.h.
+const MAX_QUERY_TERMS: usize = 32;
+const MAX_K: usize = 20_001;
+
+fn last_error() -> anyhow::Error {
+  let msg = unsafe { CStr::from_ptr(ffi::slg_last_error()) }.to_string_lossy().into_owned();
+  anyhow!("searchlite_gpu: {msg}")
+}
+
+/// All segments of one IndexReader staged in HBM (slg_index_create).  Segments are immutable;
+/// build it when the reader opens and again after a commit / compaction, or when live_docs changes
+/// (idf uses `docs = seg.live_docs()`, api/reader.rs:2985).
+pub struct GpuSegments {
+  handle: *mut ffi::slg_index,
+  /// per segment: "field:term" key -> term id (rank of the key in the sorted dictionary)
+  dict: Vec<HashMap<String, u32>>,
+  /// filters already registered: serialized Filter -> filter id (slg_index_add_filter)
+  filters: Mutex<HashMap<String, i32>>,
+}
+
+// The library serialises launches internally and planning takes no lock.
+unsafe impl Send for GpuSegments {}
+unsafe impl Sync for GpuSegments {}
+
+impl Drop for GpuSegments {
+  fn drop(&mut self) {
+    unsafe { ffi::slg_index_destroy(self.handle) }
+  }
+}
+
+/// Host copies of one segment's arrays; they only have to outlive slg_index_create.
+struct StagedSegment {
+  term_offsets: Vec<u64>,
+  doc_ids: Vec<u32>,
+  tfs: Vec<u32>,
+  term_field: Vec<u16>,
+  field_lens: Vec<Option<Vec<f32>>>,
+  field_len_ptrs: Vec<*const f32>,
+  field_avgdl: Vec<f32>,
+  deleted: Vec<u8>,
+  vec_offsets: Vec<u32>,
+  vec_values: std::sync::Arc<Vec<f32>>,
+  vec_dim: u32,
+  vec_metric: i32,
+}
+
+impl GpuSegments {
+  /// `fields`: every field that owns "field:term" keys (schema text fields, then keyword
+  /// fields); `vector_field`: the field slg_rerank_* serves, if any.
+  pub fn stage(
+    segments: &[SegmentReader],
+    fields: &[String],
+    vector_field: Option<&str>,
+    k1: f32,
+    b: f32,
+    device: i32,
+  ) -> Result<Self> {
+    let field_id: HashMap<&str, u16> =
+      fields.iter().enumerate().map(|(i, f)| (f.as_str(), i as u16)).collect();
+    let mut staged: Vec<StagedSegment> = Vec::with_capacity(segments.len());
+    let mut dict: Vec<HashMap<String, u32>> = Vec::with_capacity(segments.len());
+    for seg in segments {
+      let n_docs = seg.meta.doc_count as usize;
+      let mut s = StagedSegment {
+        term_offsets: vec![0],
+        doc_ids: Vec::new(),
+        tfs: Vec::new(),
+        term_field: Vec::new(),
+        field_lens: Vec::new(),
+        field_len_ptrs: Vec::new(),
+        field_avgdl: Vec::new(),
+        deleted: vec![0u8; n_docs.div_ceil(8)],
+        vec_offsets: Vec::new(),
+        vec_values: std::sync::Arc::new(Vec::new()),
+        vec_dim: 0,
+        vec_metric: ffi::SLG_METRIC_COSINE,
+      };
+      let mut ids = HashMap::new();
+      // the dictionary iterates in sorted key order (TinyFst is a BTreeMap, util/fst.rs:4-31)
+      for key in seg.terms_with_prefix("") {
+        let Some((field, _)) = key.split_once(':') else { continue };
+        let Some(&fid) = field_id.get(field) else { continue };
+        let Some(postings) = seg.postings(key) else { continue };
+        ids.insert(key.clone(), s.term_field.len() as u32);
+        s.term_field.push(fid);
+        for e in postings.entries() {
+          s.doc_ids.push(e.doc_id);
+          s.tfs.push(e.term_freq);
+        }
+        s.term_offsets.push(s.doc_ids.len() as u64);
+      }
+      dict.push(ids);
+      for f in fields {
+        // field_lengths_for, api/reader.rs:3604-3621: absent -> 0 -> the scorer's max(avgdl, 1)
+        let key = doc_length_key(f);
+        let lens: Vec<f32> = (0..n_docs as DocId)
+          .map(|d| seg.fast_fields().i64_value(&key, d).unwrap_or(0) as f32)
+          .collect();
+        s.field_avgdl.push(seg.avg_field_length(f));
+        s.field_lens.push(Some(lens));
+      }
+      for d in 0..n_docs as DocId {
+        if seg.is_deleted(d) {
+          s.deleted[(d >> 3) as usize] |= 1u8 << (d & 7);
+        }
+      }
+      #[cfg(feature = "vectors")]
+      if let Some((_, store)) = vector_field.and_then(|vf| seg.vector_components(vf)) {
+        s.vec_dim = store.dim() as u32;
+        s.vec_metric = match store.metric() {
+          crate::vectors::VectorMetric::Cosine => ffi::SLG_METRIC_COSINE,
+          crate::vectors::VectorMetric::L2 => ffi::SLG_METRIC_L2,
+        };
+        s.vec_offsets = store.offsets().to_vec();
+        s.vec_values = store.values();
+      }
+      staged.push(s);
+    }
+    for s in staged.iter_mut() {
+      s.field_len_ptrs =
+        s.field_lens.iter().map(|l| l.as_ref().map_or(std::ptr::null(), |v| v.as_ptr())).collect();
+    }
+    let descs: Vec<ffi::slg_segment_desc> = segments
+      .iter()
+      .zip(staged.iter())
+      .map(|(seg, s)| ffi::slg_segment_desc {
+        n_docs: seg.meta.doc_count,
+        n_terms: s.term_field.len() as u32,
+        term_offsets: s.term_offsets.as_ptr(),
+        doc_ids: s.doc_ids.as_ptr(),
+        tfs: s.tfs.as_ptr(),
+        term_field: s.term_field.as_ptr(),
+        n_fields: fields.len() as u32,
+        field_doc_len: s.field_len_ptrs.as_ptr(),
+        field_avgdl: s.field_avgdl.as_ptr(),
+        docs: seg.live_docs() as f32, // api/reader.rs:2985
+        k1,
+        b,
+        deleted: s.deleted.as_ptr(),
+        vec_dim: s.vec_dim,
+        vec_metric: s.vec_metric,
+        vec_offsets: if s.vec_dim > 0 { s.vec_offsets.as_ptr() } else { std::ptr::null() },
+        vec_values: if s.vec_dim > 0 { s.vec_values.as_ptr() } else { std::ptr::null() },
+        vec_rows: if s.vec_dim > 0 { (s.vec_values.len() / s.vec_dim as usize) as u32 } else { 0 },
+      })
+      .collect();
+    let handle = unsafe { ffi::slg_index_create(descs.as_ptr(), descs.len() as u32, device) };
+    if handle.is_null() {
+      return Err(last_error());
+    }
+    Ok(Self { handle, dict, filters: Mutex::new(HashMap::new()) })
+  }
+
+  pub(crate) fn raw(&self) -> *mut ffi::slg_index {
+    self.handle
+  }
+
+  /// `req.filter` as a doc bitmap per segment (accept = !deleted && filter, api/reader.rs:
+  /// 3009-3018), evaluated once with the reference's own passes_filter and cached by the filter's
+  /// serialized form.
+  fn filter_id(&self, segments: &[SegmentReader], filter: &Filter) -> Result<i32> {
+    let key = serde_json::to_string(filter)?;
+    if let Some(id) = self.filters.lock().unwrap().get(&key) {
+      return Ok(*id);
+    }
+    let bitmaps: Vec<Vec<u8>> = segments
+      .iter()
+      .map(|seg| {
+        let n = seg.meta.doc_count as usize;
+        let mut bm = vec![0u8; n.div_ceil(8)];
+        for d in 0..n as DocId {
+          if passes_filter(seg.fast_fields(), d, filter) {
+            bm[(d >> 3) as usize] |= 1u8 << (d & 7);
+          }
+        }
+        bm
+      })
+      .collect();
+    let ptrs: Vec<*const u8> = bitmaps.iter().map(|b| b.as_ptr()).collect();
+    let id = unsafe { ffi::slg_index_add_filter(self.handle, ptrs.as_ptr()) };
+    if id < 0 {
+      return Err(last_error());
+    }
+    self.filters.lock().unwrap().insert(key, id);
+    Ok(id)
+  }
+}
+
+/// One scored term of a request, folded as search_segment does (api/reader.rs:2971-2983):
+/// identical keys collapse, weights add, the first occurrence fixes the leaf.
+pub(crate) struct FoldedTerm {
+  pub key: String,
+  pub weight: f32,
+  pub leaf: u32,
+}
+
+pub(crate) fn fold_terms<'a>(qualified: impl Iterator<Item = (&'a str, f32, usize)>) -> Vec<FoldedTerm> {
+  let mut order: Vec<FoldedTerm> = Vec::new();
+  let mut pos: HashMap<&'a str, usize> = HashMap::new();
+  for (key, weight, leaf) in qualified {
+    match pos.get(key) {
+      Some(&i) => order[i].weight += weight,
+      None => {
+        pos.insert(key, order.len());
+        order.push(FoldedTerm { key: key.to_string(), weight, leaf: leaf as u32 });
+      }
+    }
+  }
+  order
+}
+
+/// The shape of ScorePlan the device evaluates (query/planner.rs:113-153).
+pub(crate) enum GpuScorePlan {
+  /// no plan, `Leaf`, or `Sum` of leaves: per-leaf sums added in leaf order
+  Sum,
+  /// `DisMax { children: leaves, tie_breaker }`
+  DisMax { tie_breaker: f32 },
+}
+
+fn flat_plan(plan: &QueryPlan) -> Option<(GpuScorePlan, u32)> {
+  let Some(sp) = plan.scorer.as_ref() else { return Some((GpuScorePlan::Sum, 0)) };
+  let all_leaves = |cs: &[ScoreExpr]| cs.iter().all(|c| matches!(c, ScoreExpr::Leaf(_)));
+  match &sp.root {
+    ScoreExpr::Leaf(_) => Some((GpuScorePlan::Sum, sp.leaf_count as u32)),
+    ScoreExpr::Sum(cs) if all_leaves(cs) => Some((GpuScorePlan::Sum, sp.leaf_count as u32)),
+    ScoreExpr::DisMax { children, tie_breaker } if all_leaves(children) && !children.is_empty() => {
+      Some((GpuScorePlan::DisMax { tie_breaker: *tie_breaker }, sp.leaf_count as u32))
+    }
+    _ => None, // nested expressions stay on the CPU scorer
+  }
+}
+
+/// is this request one the GPU scorer reproduces exactly?
+/// `needs_score_hook` = has_custom_scoring(&compiled_score) (api/reader.rs:376-387, :2628).
+pub(crate) fn gpu_eligible(
+  req: &SearchRequest,
+  sort_plan: &SortPlan,
+  plan: &QueryPlan,
+  needs_score_hook: bool,
+  top_k: usize,
+  n_folded_terms: usize,
+) -> Option<(GpuScorePlan, u32)> {
+  // score_fast_path (api/reader.rs:2550-2551): sort = _score desc only => ScoreMode::Score and
+  // the scorer is handed rank_limit = top_k (:2702-2703)
+  let score_fast_path =
+    sort_plan.is_score_only() && matches!(sort_plan.primary_order(), Some(SortOrder::Desc));
+  if !score_fast_path || !req.return_hits || req.limit == 0 || top_k == 0 || top_k > MAX_K {
+    return None;
+  }
+  // no collector: agg_ref stays None only without aggregations (api/reader.rs:2694-2699)
+  if !req.aggs.is_empty() || req.explain || needs_score_hook || req.cursor.is_some() {
+    return None;
+  }
+  if req.collapse.is_some() {
+    return None; // collapse needs every hit of a group, not just the top k
+  }
+  if n_folded_terms == 0 || n_folded_terms > MAX_QUERY_TERMS {
+    return None;
+  }
+  // the matcher must be implied by "the doc has a posting of some scored term":
+  // a pure disjunction (QueryEvaluator::matches, api/reader.rs:1486-1518)
+  let pure_disjunction = match &plan.matcher {
+    QueryMatcher::Term(_) => true,
+    QueryMatcher::QueryString(m) => {
+      !m.term_groups.is_empty()
+        && m.phrase_groups.is_empty()
+        && m.not_term_groups.is_empty()
+        && m.minimum_should_match.unwrap_or(1) <= 1
+    }
+    _ => false,
+  };
+  if !pure_disjunction || !plan.phrase_specs.is_empty() {
+    return None;
+  }
+  // every matching term group must also score, else a doc could match without a scored posting
+  if plan.term_groups.iter().any(|g| !g.score) {
+    return None;
+  }
+  flat_plan(plan)
+}
+
+/// Replaces the per-segment loop + cross-segment sort of IndexReader::search
+/// (api/reader.rs:2670-2778) for ONE eligible request: (segment_ord, doc_id, score) in final order,
+/// at most `top_k` of them, plus the number of distinct docs scored.
+pub(crate) fn gpu_top_k(
+  gpu: &GpuSegments,
+  segments: &[SegmentReader],
+  folded: &[FoldedTerm],
+  score_plan: &GpuScorePlan,
+  n_leaves: u32,
+  filter: Option<&Filter>,
+  execution: &ExecutionStrategy,
+  top_k: usize,
+) -> Result<(Vec<(u32, DocId, f32)>, u64)> {
+  let n_segs = segments.len();
+  let mut term_ids = Vec::with_capacity(folded.len() * n_segs);
+  for t in folded {
+    for d in gpu.dict.iter() {
+      term_ids.push(d.get(&t.key).copied().unwrap_or(ffi::SLG_NO_TERM));
+    }
+  }
+  let weights: Vec<f32> = folded.iter().map(|t| t.weight).collect();
+  let leaves: Vec<u32> = folded.iter().map(|t| t.leaf).collect();
+  let offsets = [0u32, folded.len() as u32];
+  let (plan_kind, tie) = match score_plan {
+    GpuScorePlan::Sum => (ffi::SLG_PLAN_SUM, 0.0f32),
+    GpuScorePlan::DisMax { tie_breaker } => (ffi::SLG_PLAN_DISMAX, *tie_breaker),
+  };
+  let filter_id = match filter {
+    Some(f) => gpu.filter_id(segments, f)?,
+    None => -1,
+  };
+  let strategy = match execution {
+    ExecutionStrategy::Bm25 => ffi::SLG_STRATEGY_BM25,
+    ExecutionStrategy::Wand => ffi::SLG_STRATEGY_WAND,
+    ExecutionStrategy::Bmw => ffi::SLG_STRATEGY_BMW,
+  };
+  let k = top_k as u32;
+  let batch = unsafe {
+    ffi::slg_batch_prepare_plan(
+      gpu.raw(),
+      1,
+      offsets.as_ptr(),
+      term_ids.as_ptr(),
+      weights.as_ptr(),
+      leaves.as_ptr(),
+      &plan_kind,
+      &tie,
+      if n_leaves > 0 { &n_leaves } else { std::ptr::null() },
+      &filter_id,
+      k,
+      strategy,
+    )
+  };
+  if batch.is_null() {
+    return Err(last_error());
+  }
+  let (mut doc, mut seg, mut score) = (vec![0u32; top_k], vec![0u32; top_k], vec![0f32; top_k]);
+  let mut count = 0u32;
+  let mut stats = ffi::slg_stats { scored_docs: 0, candidates_examined: 0, postings_advanced: 0 };
+  let rc = unsafe {
+    let mut rc = ffi::slg_batch_run(batch);
+    if rc == 0 {
+      rc = ffi::slg_batch_fetch(
+        batch,
+        doc.as_mut_ptr(),
+        seg.as_mut_ptr(),
+        score.as_mut_ptr(),
+        &mut count,
+        &mut stats,
+      );
+    }
+    ffi::slg_batch_destroy(batch);
+    rc
+  };
+  if rc != 0 {
+    bail!("searchlite_gpu returned {rc}");
+  }
+  let hits = (0..count as usize).map(|i| (seg[i], doc[i] as DocId, score[i])).collect();
+  Ok((hits, stats.scored_docs))
+}

@@ -32,11 +32,25 @@ def test_header_declares_expected_surface():
         assert must in names
 
 
-def test_integration_doc_binds_every_declared_function():
-    """INTEGRATION.md's Rust `extern "C"` block (the reference-side binding) lists the whole ABI."""
-    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    missing = [n for n in declared_functions() if f"pub fn {n}(" not in md]
-    assert not missing, f"not bound in INTEGRATION.md: {missing}"
+def test_rust_ffi_binds_every_declared_function():
+    """integration/searchlite-core/src/gpu/ffi.rs (the reference-side `extern "C"` block a
+    maintainer adds behind the `gpu` feature) lists the whole ABI."""
+    rs = open(os.path.join(ROOT, "integration", "searchlite-core", "src", "gpu", "ffi.rs")).read()
+    missing = [n for n in declared_functions() if f"pub fn {n}(" not in rs]
+    assert not missing, f"not bound in gpu/ffi.rs: {missing}"
+
+
+def test_rust_shim_uses_only_bound_items():
+    """Every ffi:: item the shim sources use exists in ffi.rs."""
+    base = os.path.join(ROOT, "integration", "searchlite-core", "src")
+    ffi = open(os.path.join(base, "gpu", "ffi.rs")).read()
+    for rel in ("gpu/mod.rs", "gpu/rerank.rs"):
+        src = open(os.path.join(base, rel)).read()
+        used = set(re.findall(r"ffi::(slg_[a-z_]+|SLG_[A-Z0-9_]+)", src))
+        assert used, rel
+        for name in used:
+            assert re.search(r"\b" + re.escape(name) + r"\b", ffi), \
+                f"{rel} uses ffi::{name}, which ffi.rs does not declare"
 
 
 def test_library_exports_every_declared_symbol(lib):
