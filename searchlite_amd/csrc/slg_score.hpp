@@ -32,8 +32,8 @@ constexpr uint32_t kSpan = kSpanWords * 32;  // docs per window
 struct RoundPartParams {
   const RoundQuery *sq;
   const TermRef *terms;
-  const uint32_t *bnd_sq;  // [n_boundaries] sub-query of each boundary task
   const SegDev *segs;
+  uint32_t n_sq;
   uint32_t *bounds;
   uint32_t *rdoc;
   uint32_t *q_scored;  // [nq] zeroed here (saves a memset node per batch)
@@ -70,7 +70,20 @@ static __global__ void __launch_bounds__(256) partition_rounds_kernel(RoundPartP
   }
   const uint32_t b = gid >> 3, u = gid & 7;
   if (b >= p.n_boundaries) return;
-  const uint32_t sqi = p.bnd_sq[b];
+  // the sub-query that owns boundary b: the last one whose first boundary is <= b (bnd_begin
+  // ascends) — found here rather than uploaded as a per-boundary table (most of the descriptors)
+  uint32_t sqi = 0;
+  {
+    uint32_t lo = 0, hi = p.n_sq;
+    while (hi - lo > 1) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      if (p.sq[mid].bnd_begin <= b)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    sqi = lo;
+  }
   const RoundQuery s = p.sq[sqi];
   const uint32_t j = b - s.bnd_begin;
   const uint32_t *docs = p.segs[s.seg].docs;
