@@ -154,7 +154,7 @@ typedef struct {
   uint32_t multi_round_target;   /* SLG_MULTI_ROUND_TARGET (448) */
   uint32_t probe_target;         /* SLG_PROBE_TARGET (2048): postings per round incl. probed lists */
   uint32_t rounds_per_slice;     /* SLG_ROUNDS_PER_SLICE (0 = auto) */
-  uint32_t max_rounds_per_slice; /* SLG_MAX_ROUNDS_PER_SLICE (16) */
+  uint32_t max_rounds_per_slice; /* SLG_MAX_ROUNDS_PER_SLICE (0 = auto: 8 few-term kernel, 16 many-term) */
   uint32_t slices_per_subquery;  /* SLG_SLICES_PER_SUBQUERY (16) */
   int32_t cand_mode;             /* !SLG_NO_CAND_MODE (1): 256 < k <= 1024 via candidates + select */
   int32_t slice_order;           /* !SLG_NO_SLICE_ORDER (1): longest slices launch first */

@@ -530,7 +530,7 @@ void slg_tuning_default(slg_tuning *t) {
   t->multi_round_target = env_u32("SLG_MULTI_ROUND_TARGET", slg::kMultiTarget);
   t->probe_target = env_u32("SLG_PROBE_TARGET", 2048);
   t->rounds_per_slice = env_u32("SLG_ROUNDS_PER_SLICE", 0);
-  t->max_rounds_per_slice = env_u32("SLG_MAX_ROUNDS_PER_SLICE", slg::kMaxRoundsPerSlice);
+  t->max_rounds_per_slice = env_u32("SLG_MAX_ROUNDS_PER_SLICE", 0);
   t->slices_per_subquery = env_u32("SLG_SLICES_PER_SUBQUERY", 16);
   t->cand_mode = env_i32("SLG_NO_CAND_MODE", 0) == 0;
   t->slice_order = env_i32("SLG_NO_SLICE_ORDER", 0) == 0;
@@ -554,7 +554,7 @@ slg_index *slg_index_create_tuned(const slg_segment_desc *segs, uint32_t n_segs,
       slg_tuning_default(&tune);
     }
     tune.uniform_max_terms = std::min<uint32_t>(tune.uniform_max_terms, slg::kUniMaxLists);
-    tune.max_rounds_per_slice = std::max<uint32_t>(1, std::min<uint32_t>(tune.max_rounds_per_slice, slg::kMaxRoundsPerSlice));
+    tune.max_rounds_per_slice = std::min<uint32_t>(tune.max_rounds_per_slice, slg::kMaxRoundsPerSlice);
     tune.slices_per_subquery = std::max<uint32_t>(1, tune.slices_per_subquery);
     for (uint32_t s = 0; s < n_segs; s++) validate_segment(segs[s], s, tune.validate != 0);
     int ndev = 0;
@@ -1016,7 +1016,11 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
         rps_pinned ? tn.rounds_per_slice
                    : (b->uniform && k <= 64 ? slg::kUniRoundsPerSlice : slg::kDefaultRoundsPerSlice),
         slg::kMaxRoundsPerSlice));
-    const uint32_t rps_cap = std::max<uint32_t>(max_rps, tn.max_rounds_per_slice);
+    // longest slices: 8 rounds on the few-term kernel (measured on config 2: the heaviest
+    // sub-queries' 16-round slices were the tail of the launch), 16 on the many-term kernel
+    const uint32_t rps_cap = std::max<uint32_t>(
+        max_rps, tn.max_rounds_per_slice ? tn.max_rounds_per_slice
+                                         : (b->uniform ? 8u : (uint32_t)slg::kMaxRoundsPerSlice));
     const uint32_t slices_per_sq = tn.slices_per_subquery;
     for (size_t i = 0; i < sqs.size(); i++) {
       slg::RoundQuery &sq = sqs[i];

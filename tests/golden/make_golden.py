@@ -9,6 +9,8 @@ each other and against accidental change, not against the Rust binary.  Inputs:
     source) indexed by searchlite_amd.segment.SegmentBuilder (default tokenizer, ids sorted),
     fields title/description/instructions, product BM25 defaults k1=0.9 b=0.4 (README.md:15);
     10 two-term OR queries, limit 10 (k = 11), "execution": wand  -> BASELINE config 1.
+  * recipes_default.npz : the same corpus with all four text fields (incl. `text`), queries on the
+    DEFAULT fields (multi-field leaves, Sum plan) -> BASELINE config 1 as an unmodified request.
   * pruning40.npz : a 40-doc / 7-word corpus in the shape of tests/pruning.rs:44-104
     (k1=1.2, b=0.75, bmw_block_size 4), 5 three-term queries, limit 5.
   * two_segments.npz : tests/smoke.rs:853-950 — equal scores across two segments.
@@ -86,6 +88,57 @@ def recipes():
           meta["top10"][0][:3])
 
 
+def recipes_default_fields():
+    """BASELINE config 1 on DEFAULT fields: `fields: None` means every text field of the schema
+    (api/reader.rs:2576-2586; examples/recipes/schema.json: text, title, description,
+    instructions).  A query string's word w becomes ONE ScorePlan leaf fed by the terms
+    `<field>:w` of all four fields (query/planner.rs:300-360, weight = group boost x field boost =
+    1.0), the leaves are summed (`Sum([Leaf(0..n)])`).  10 two-word queries, limit 10 (k = 11)."""
+    from searchlite_amd.segment import default_tokenize, plan_query_string, resolve_plan
+    fields = ["text", "title", "description", "instructions"]
+    b = SegmentBuilder(fields, k1=0.9, b=0.4)
+    with open(REF) as f:
+        for line in f:
+            doc = json.loads(line)
+            b.add_document(doc["doc_id"], {k: doc.get(k) for k in fields})
+    seg = b.build()
+    queries = ["tomato basil", "quick weeknight", "chicken soup", "orzo spinach", "simmer garlic",
+               "bake oven", "vegan chili", "shrimp curry", "whisk butter", "salad lemon"]
+    offs, ids, ws, leaves, nl, keys = [0], [], [], [], [], []
+    for q in queries:
+        words = [t for raw in q.split() for t in default_tokenize(raw)]
+        planned, plan, n_leaves = plan_query_string(words, [(f, 1.0) for f in fields])
+        i, w, lf = resolve_plan([seg], planned)
+        ids.append(i)
+        ws.append(w)
+        leaves.append(lf)
+        nl.append(n_leaves)
+        keys.append([p_[0] for p_ in planned])
+        offs.append(offs[-1] + len(planned))
+    ids, ws, leaves = np.concatenate(ids), np.concatenate(ws), np.concatenate(leaves)
+    offs = np.array(offs, dtype=np.uint32)
+    nl = np.array(nl, dtype=np.uint32)
+    k = 11
+    kw = dict(q_leaf=leaves, q_plan=np.zeros(len(queries), np.int32), q_nleaves=nl)
+    want = O.search_batch([seg], offs, ids, ws, k, strategy=O.BM25, **kw)
+    # Wand adds a leaf's terms in cursor-heap pop order (wand.rs:835-839), Bm25 in term order: with
+    # several terms per leaf the f32 sums may differ in the last ulps (the reference's own tests
+    # allow 1e-5, tests/pruning.rs:96-101) — the fixture holds the exhaustive (Bm25) result
+    wand = O.search_batch([seg], offs, ids, ws, k, strategy=O.WAND, **kw)
+    assert np.array_equal(want[3], wand[3]) and np.abs(want[2] - wand[2]).max() < 1e-5
+    same_docs = float((want[0] == wand[0]).mean())
+    print("recipes (default fields): Wand vs Bm25 identical doc positions:", same_docs,
+          "max |dscore|", float(np.abs(want[2] - wand[2]).max()))
+    np.savez_compressed(os.path.join(HERE, "recipes_default.npz"), **seg_arrays(seg), q_offsets=offs,
+                        q_terms=ids, q_weights=ws, q_leaf=leaves, q_nleaves=nl, k=np.uint32(k),
+                        exp_doc=want[0], exp_seg=want[1], exp_score=want[2], exp_count=want[3])
+    meta = {"fields": fields, "queries": [{"query": q, "keys": ks} for q, ks in zip(queries, keys)],
+            "top10": [[(seg.ext_ids[int(want[0][qi, i])], float(want[2][qi, i]))
+                       for i in range(min(int(want[3][qi]), 10))] for qi in range(len(queries))]}
+    json.dump(meta, open(os.path.join(HERE, "recipes_default.json"), "w"), indent=1)
+    print("recipes (default fields):", seg.n_terms, "terms; first query top-3:", meta["top10"][0][:3])
+
+
 def pruning40():
     rng = np.random.default_rng(42)
     seg = random_segment(rng, 40, 7, 6, k1=1.2, b=0.75, zipf=False)
@@ -152,6 +205,7 @@ def rerank16():
 
 if __name__ == "__main__":
     recipes()
+    recipes_default_fields()
     pruning40()
     two_segments()
     rerank16()

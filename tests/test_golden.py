@@ -57,3 +57,22 @@ def test_oracle_reproduces_rerank_golden(oracle, metric, name):
                                 float(z["alpha"][i]), z["cand_doc"][i], z["cand_bm25"][i], 10)
         assert np.array_equal(d, z[f"exp_doc_{name}"][i])
         assert np.array_equal(s.view(np.uint32), z[f"exp_score_{name}"][i].view(np.uint32))
+
+
+def test_oracle_reproduces_recipes_on_default_fields(oracle):
+    """BASELINE config 1 as an unmodified request: `fields: None` = all four text fields of the
+    recipes schema (api/reader.rs:2576-2586), one ScorePlan leaf per query word fed by its
+    `<field>:word` terms, leaves summed.  Bm25 bit-exact; Wand (heap pop order inside a leaf) within
+    the reference's own 1e-5."""
+    segs, z = load_golden("recipes_default.npz")
+    assert len(segs[0].field_doc_len) == 4 and segs[0].n_docs == 300
+    kw = dict(q_leaf=z["q_leaf"], q_plan=np.zeros(len(z["q_nleaves"]), np.int32), q_nleaves=z["q_nleaves"])
+    got = oracle.search_batch(segs, z["q_offsets"], z["q_terms"], z["q_weights"], int(z["k"]),
+                              strategy=oracle.BM25, **kw)
+    assert_same_hits(got, golden_expected(z), 0.0, "recipes default fields, Bm25")
+    wand = oracle.search_batch(segs, z["q_offsets"], z["q_terms"], z["q_weights"], int(z["k"]),
+                               strategy=oracle.WAND, **kw)
+    assert_same_hits(wand, golden_expected(z), 1e-5, "recipes default fields, Wand")
+    meta = json.load(open(os.path.join(GOLDEN, "recipes_default.json")))
+    assert meta["fields"] == ["text", "title", "description", "instructions"]
+    assert all(len(q["keys"]) == 8 for q in meta["queries"])  # 2 words x 4 fields

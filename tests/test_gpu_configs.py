@@ -272,3 +272,17 @@ def test_merge_shards_beyond_the_register_top_k(gpu, oracle, k):
     for ix, b in keep:
         b.close()
         ix.close()
+
+
+def test_recipes_default_fields_golden(gpu):
+    """BASELINE config 1 on default fields (all four text fields incl. `text`, multi-field leaves,
+    Sum plan; tests/golden/recipes_default.npz): the GPU returns the exhaustive result bit for bit
+    for every strategy (8 scored terms per query => many-term kernel with leaf close)."""
+    from tests.util import golden_expected, load_golden
+    segs, z = load_golden("recipes_default.npz")
+    nq = len(z["q_nleaves"])
+    with gpu.GpuIndex(segs) as ix:
+        for strat in (gpu.Bm25, gpu.Wand, gpu.Bmw):
+            got = ix.search_plan(z["q_offsets"], z["q_terms"], z["q_weights"], int(z["k"]), q_leaf=z["q_leaf"],
+                                 q_plan=np.zeros(nq, np.int32), q_nleaves=z["q_nleaves"], strategy=strat)
+            assert_same_hits(got, golden_expected(z), 0.0, f"recipes default fields, strategy {strat}")
