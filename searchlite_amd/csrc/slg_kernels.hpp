@@ -23,6 +23,8 @@ constexpr int kWavesPerBlock = 4;
 constexpr uint32_t kMaxTerms = 32;
 constexpr int kChampSorted = 64;  // exact-rank lower bounds (sorted lane maxima)
 constexpr int kChampions = 68;    // + bounds for ranks 128, 256, 512, 1024
+// LDS bytes of the buffered top-k of a scoring wave (BufTopK<KREGS>::kEntries 64-bit keys)
+constexpr int buftopk_lds(int kregs) { return 64 * (kregs + 1) * 8; }
 // index of the champion entry that bounds the k-th largest impact of a term from below
 __host__ __device__ inline int champ_index(uint32_t k) {
   return k <= 64 ? (int)k - 1 : k <= 128 ? 64 : k <= 256 ? 65 : k <= 512 ? 66 : 67;
@@ -251,8 +253,9 @@ __device__ __forceinline__ uint64_t cand_key(float score, uint32_t doc) {
 
 template <int KREGS>
 struct BufTopK {
-  static constexpr uint32_t kEntries = 128u * KREGS;  // >= k + 64 for k <= 64 * KREGS
-  static constexpr int E = 2 * KREGS;                 // entries per lane while ranking
+  static constexpr uint32_t kEntries = 64u * (KREGS + 1);  // >= k + 64 for k <= 64 * KREGS: after a
+                                                          // ranking a whole slot of candidates fits
+  static constexpr int E = KREGS + 1;                      // entries per lane while ranking
   uint64_t *buf;   // LDS [kEntries]
   uint32_t count;  // uniform: entries held
   uint64_t th;     // uniform: a candidate passes iff key > th

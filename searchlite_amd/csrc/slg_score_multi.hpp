@@ -44,7 +44,7 @@ constexpr int kMultiTarget = 448;    // planned postings per round (host; measur
 constexpr int kMultiFill = 448;      // postings taken when a round has to be cut
 constexpr int multi_wave_lds(int kregs) {
   return kSpanWords * 4 + kSpanWords * 4 + (kMultiCap + 64) * 4 + kMultiCap * 4 +
-         (uni_buffered(kregs) ? 128 * kregs * 8 : 0);
+         (uni_buffered(kregs) ? buftopk_lds(kregs) : 0);
 }
 constexpr int kMultiPlanLds = 2 * kMultiCap * 4;  // acc[] and max[] of the leaf close
 

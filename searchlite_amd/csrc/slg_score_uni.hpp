@@ -50,7 +50,7 @@ static_assert(kJoinWords * 4 >= kUniCap * 8, "the join queue ({doc, score} per p
 // threshold goes to the slice's candidate region and select_topk_kernel picks the k best
 constexpr bool uni_buffered(int kregs) { return kregs <= 4; }
 constexpr int uni_wave_lds(int kregs) {  // filter / join queue, top-k buffer
-  return kJoinWords * 4 + (uni_buffered(kregs) ? 128 * kregs * 8 : 0);
+  return kJoinWords * 4 + (uni_buffered(kregs) ? buftopk_lds(kregs) : 0);
 }
 
 #ifndef SLG_UNI_WAVES
