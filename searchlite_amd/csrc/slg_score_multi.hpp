@@ -122,6 +122,11 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
     if (th0 > 0.0f) btop.set_floor(th0);
   }
   uint32_t n_scored = 0;
+#ifdef SLG_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+  const unsigned long long st_begin = wall_clock64();
+#endif
 
   // slot descriptors of the current chunk: lane G = global slot G (list, count, 64-bit index)
   uint32_t d_st = 0, d_cnt = 0, d_lo = 0, d_hi = 0;
@@ -172,15 +177,26 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
     return S;
   };
 
+  // cut points and doc starts of rounds rr / rr + 1 (lane t: list t); the pair for the round after
+  // is loaded while this round is processed
+  uint32_t cutA = 0, cutB = 0;
+  if (lane < T) {
+    cutA = gbounds[lane];
+    cutB = gbounds[T + lane];
+  }
+  uint32_t rdA = grdoc[0], rdB = grdoc[1];
   for (uint32_t rr = 0; rr < n_r; rr++) {
     // lane t: this round's range [cur, end) of list t; the round's doc range [dlo, rdhi)
-    uint32_t cur = 0, end = 0;
-    if (lane < T) {
-      cur = gbounds[rr * T + lane];
-      end = gbounds[(rr + 1) * T + lane];
+    uint32_t cur = cutA;
+    const uint32_t end = cutB;
+    uint32_t dlo = rfl(rdA);
+    const uint32_t rdhi = rfl(rdB);
+    cutA = cutB;
+    rdA = rdB;
+    if (rr + 1 < n_r) {
+      if (lane < T) cutB = gbounds[(rr + 2) * T + lane];
+      rdB = grdoc[rr + 2];
     }
-    uint32_t dlo = rfl(grdoc[rr]);
-    const uint32_t rdhi = rfl(grdoc[rr + 1]);
 
     for (uint32_t guard = 0; guard < (1u << 22); guard++) {  // chunks of the round (usually one)
       const uint32_t rem = end - cur;
@@ -220,6 +236,7 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
       const uint32_t nb_a = (S_a + 7u) >> 3;
       const uint32_t nb = (S + 7u) >> 3;
       const uint32_t wspan = dhi - wbase;
+      SLG_STAMP(0);
 
       // ---- P0: clear bitmap and accumulators ----
       bm4[lane] = make_uint4(0u, 0u, 0u, 0u);
@@ -235,17 +252,39 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
         mx4[lane + 64] = make_uint4(max_init, max_init, max_init, max_init);
       }
       wave_fence();
-      // ---- sweep A: one bit per posting of the essential lists ----
-      if (nb_a) issue_batch(0, a_lo, a_hi);
-      for (uint32_t b = 0; b < nb_a; b++) {
-        take_batch(b, a_cnt, dhi);
-        if (b + 1 < nb_a) issue_batch(b + 1, a_lo, a_hi);
+      SLG_STAMP(1);
+      // ---- sweep A: one bit per posting of the essential lists.  Only the doc ids are needed
+      //      here (the impacts are read once, in sweep C), so the loads are half as wide and two
+      //      batches are kept in flight in the registers sweep C uses for doc ids + impacts ----
+      {
+        uint32_t da[NS], db[NS];
+        auto issue_docs = [&](uint32_t (&dst)[NS], const uint32_t bb) {
 #pragma unroll
-        for (int jj = 0; jj < NS; jj++) {
-          const uint32_t rel = doc[jj] - wbase;
-          if (rel < wspan) atomicOr(&bm[rel & (kSpanWords - 1)], 1u << (rel >> 9));
+          for (int jj = 0; jj < NS; jj++) {
+            const uint64_t base = ((uint64_t)rl(a_hi, bb * 8u + jj) << 32) | rl(a_lo, bb * 8u + jj);
+            dst[jj] = gdocs[base + lane];
+          }
+        };
+        auto set_bits = [&](const uint32_t (&src)[NS], const uint32_t bb) {
+#pragma unroll
+          for (int jj = 0; jj < NS; jj++) {
+            const bool live = lane < rl(a_cnt, bb * 8u + jj) && src[jj] < dhi;
+            const uint32_t rel = src[jj] - wbase;
+            if (live && rel < wspan) atomicOr(&bm[rel & (kSpanWords - 1)], 1u << (rel >> 9));
+          }
+        };
+        if (nb_a > 0) issue_docs(da, 0);
+        if (nb_a > 1) issue_docs(db, 1);
+        for (uint32_t bb = 0; bb < nb_a; bb += 2) {
+          set_bits(da, bb);
+          if (bb + 2 < nb_a) issue_docs(da, bb + 2);
+          if (bb + 1 < nb_a) {
+            set_bits(db, bb + 1);
+            if (bb + 3 < nb_a) issue_docs(db, bb + 3);
+          }
         }
       }
+      SLG_STAMP(2);
       issue_batch(0, d_lo, d_hi);  // sweep C's first batch
       wave_fence();
       // ---- P2: exclusive prefix popcount (lane l owns words 4l..4l+3 and 256+4l..256+4l+3) ----
@@ -286,6 +325,7 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
         wave_fence();
       };
       uint32_t cur_leaf = 0xFFFFFFFFu;
+      SLG_STAMP(3);
       // ---- sweep C: rank every posting, accumulate slot by slot (= in list order) ----
       uint32_t consumed = 0;  // what every list consumes: its postings below the cut
       for (uint32_t b = 0; b < nb; b++) {
@@ -329,7 +369,9 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
               cur_leaf = lf;
             }
           }
-          // score_tf: impact * weight (query/wand.rs:285); the slot's list weight is a scalar
+          // score_tf: impact * weight (query/wand.rs:285); the slot's list weight is a scalar.
+          // (Pairing the read-modify-writes of two consecutive slots of one list — distinct docs, so
+          // independent — was measured: +5 % on config 3, and the plan variant spills.)
           const float w = __int_as_float((int)rl((uint32_t)__float_as_int(my_w), lst));
           const uint32_t at = in[jj] ? rank[jj] : (uint32_t)kMultiCap + lane;
           const uint32_t old = vals[at];
@@ -339,6 +381,7 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
         }
       }
       wave_fence();
+      SLG_STAMP(4);
       if (plan) close_leaf(true);
       // ---- P4: the docs of the chunk in rank order -> top-k ----
       for (uint32_t base = 0; base < ndocs; base += 64) {
@@ -361,6 +404,7 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
         }
       }
       wave_fence();
+      SLG_STAMP(5);
       // ---- advance ----
       if (!cut) break;  // the whole rest of the round was in this chunk
       cur += consumed;
@@ -380,6 +424,16 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
     p.slice_ccnt[slice] = ccur;
   }
   if (p.q_scored && lane == 0 && n_scored) atomicAdd(&p.q_scored[s.q], n_scored);
+#ifdef SLG_STAMPS
+  SLG_STAMP(6);
+  if (p.stamps && lane == 0) {
+    for (int i = 0; i < 8; i++) p.stamps[(size_t)slice * 12 + i] = st_acc[i];
+    p.stamps[(size_t)slice * 12 + 8] = 0;
+    p.stamps[(size_t)slice * 12 + 9] = st_begin;
+    p.stamps[(size_t)slice * 12 + 10] = wall_clock64();
+    p.stamps[(size_t)slice * 12 + 11] = ((unsigned long long)n_r << 32) | (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+  }
+#endif
 }
 
 }  // namespace slg
