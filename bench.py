@@ -573,6 +573,11 @@ def main():
             O.search_batch([seg], offs[:nf + 1], terms[:nf * T], w[:nf * T], k, strategy=ostrat,
                            n_threads=cores, cache_min_len=False)
             faithful = nf / (time.perf_counter() - tc)
+            # BASELINE.md "Baseline A" (context): + per-query varint decode of every list (twice) and
+            # the O(N) doc-length rebuild IndexReader::search does around the scorer
+            na = min(ncpu, 4 * cores)
+            _, secs_a = O.search_batch_faithful([seg], offs[:na + 1], terms[:na * T], w[:na * T], k,
+                                                strategy=ostrat, n_threads=cores)
             out["cpu_baseline"] = {
                 "value": round(strict, 1), "unit": "queries/s", "cores": cores, "kind": "port",
                 "sample": f"{ncpu} queries of query set 0 x {reps_c} reps, oracle "
@@ -582,6 +587,10 @@ def main():
                 "faithful_value": round(faithful, 1),
                 "faithful_note": "same, but with the reference's per-term O(N) min_doc_len scan "
                                  f"(wand.rs:111-125) on {nf} queries",
+                "baseline_a_value": round(na / secs_a, 1),
+                "baseline_a_note": "BASELINE.md Baseline A on the same cores: per query every term's list is "
+                                   "varint-decoded twice from its serialized form and the dense doc-length "
+                                   f"vector is rebuilt (api/reader.rs:1732-1735, 3604-3621), then wand; {na} queries",
                 "gpu_over_cpu": round(value / strict, 1)}
 
     for b in batches:

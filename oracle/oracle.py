@@ -99,6 +99,10 @@ def lib():
         L.slo_rerank.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
                                  C.c_void_p, f32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                  C.c_void_p, C.c_void_p, C.c_void_p]
+        L.slo_search_batch_faithful.restype = C.c_double
+        L.slo_search_batch_faithful.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_void_p]
         L.slo_rerank_multi.restype = C.c_int
         L.slo_rerank_multi.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -311,3 +315,21 @@ def rerank_multi(metric, vec_offsets, vec_values, qvecs, alpha, cand_doc, cand_b
                                _ptr(qvecs), _ptr(alpha), _ptr(bst), _ptr(cand_doc), _ptr(cand_bm25),
                                len(cand_doc), k_out, _ptr(out_doc), _ptr(out_score), _ptr(out_vec))
     return out_doc[:n].copy(), out_score[:n].copy(), out_vec[:n].copy()
+
+
+def search_batch_faithful(segments, q_offsets, q_terms, q_weights, k, strategy=WAND, n_threads=1):
+    """BASELINE.md "Baseline A": scorer + the reference's per-query posting decode (twice) and
+    doc-length rebuild.  -> ((doc, seg, score, count), seconds of the query phase)."""
+    segs, keep = _pack_segments(segments)
+    q_offsets = np.ascontiguousarray(q_offsets, dtype=np.uint32)
+    q_terms = np.ascontiguousarray(q_terms, dtype=np.uint32).reshape(-1, len(segments))
+    q_weights = np.ascontiguousarray(q_weights, dtype=np.float32)
+    nq = len(q_offsets) - 1
+    out_doc = np.zeros((nq, k), dtype=np.uint32)
+    out_seg = np.zeros((nq, k), dtype=np.uint32)
+    out_score = np.zeros((nq, k), dtype=np.float32)
+    out_count = np.zeros(nq, dtype=np.uint32)
+    secs = lib().slo_search_batch_faithful(segs, len(segments), nq, _ptr(q_offsets), _ptr(q_terms),
+                                           _ptr(q_weights), k, strategy, n_threads, _ptr(out_doc),
+                                           _ptr(out_seg), _ptr(out_score), _ptr(out_count))
+    return (out_doc, out_seg, out_score, out_count), float(secs)

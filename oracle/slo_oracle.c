@@ -961,3 +961,241 @@ int slo_rerank_multi(int metric, uint32_t dim, const uint32_t *vec_offsets, uint
   free(hits);
   return (int)keep;
 }
+
+
+/* ------------------------------------------------------------------------------------ */
+/* BASELINE.md "Baseline A": the per-query cost IndexReader::search pays around the scorer —   */
+/* modelled for context only (it is what a searchlite user experiences at scale).  Per query and */
+/* segment, for every term: its posting list is varint-decoded from the serialized layout TWICE  */
+/* (matcher doc lists, api/reader.rs:1732-1735; scorer postings, index/segment.rs:1328 ->        */
+/* index/postings.rs:142-212, one byte at a time, util/varint.rs:31-48); per field the dense      */
+/* doc-length vector is rebuilt with one keyed lookup per doc (field_lengths_for,                */
+/* api/reader.rs:3604-3621: `fast_fields.i64_value(&key, doc)` hashes the column name each time); */
+/* TermState::new rescans it for min_doc_len (wand.rs:111-125).  Favourable to the CPU where the */
+/* reference does more (no Vec growth, FNV instead of SipHash, no RefCell / RwLock per byte).    */
+/* Returns the seconds spent in the query phase (serialization of the lists is setup).           */
+/* ------------------------------------------------------------------------------------ */
+#include <time.h>
+
+typedef struct {
+  uint8_t *bytes;      /* concatenated serialized lists of one segment */
+  uint64_t *off;       /* [n_terms] offset of a term's list, UINT64_MAX if not serialized */
+} enc_seg;
+
+static size_t put_var(uint8_t *o, uint32_t v) {
+  size_t n = 0;
+  while (v >= 0x80) {
+    o[n++] = (uint8_t)((v & 0x7F) | 0x80);
+    v >>= 7;
+  }
+  o[n++] = (uint8_t)v;
+  return n;
+}
+
+static inline uint32_t get_var(const uint8_t **pp) { /* util/varint.rs:31-48, byte at a time */
+  const uint8_t *p = *pp;
+  uint32_t value = 0, shift = 0;
+  for (;;) {
+    uint8_t b = *p++;
+    value |= (uint32_t)(b & 0x7F) << shift;
+    if (!(b & 0x80)) break;
+    shift += 7;
+  }
+  *pp = p;
+  return value;
+}
+
+typedef struct {
+  batch_ctx base;
+  const enc_seg *enc;
+} faithful_ctx;
+
+static uint64_t fnv1a(const char *s) {
+  uint64_t h = 1469598103934665603ull;
+  while (*s) {
+    h ^= (uint8_t)*s++;
+    h *= 1099511628211ull;
+  }
+  return h;
+}
+
+static void *faithful_worker(void *arg) {
+  const faithful_ctx *fc = (const faithful_ctx *)arg;
+  const batch_ctx *c = &fc->base;
+  uint32_t max_terms = 1;
+  for (uint32_t q = 0; q < c->nq; q++) {
+    uint32_t nt = c->q_offsets[q + 1] - c->q_offsets[q];
+    if (nt > max_terms) max_terms = nt;
+  }
+  slo_term *terms = (slo_term *)malloc(max_terms * sizeof(slo_term));
+  uint32_t *tmp_doc = (uint32_t *)malloc((c->k ? c->k : 1) * sizeof(uint32_t));
+  float *tmp_score = (float *)malloc((c->k ? c->k : 1) * sizeof(float));
+  seg_hit *hits = (seg_hit *)malloc(((size_t)c->k * c->n_segs + 1) * sizeof(seg_hit));
+  uint32_t **dbuf = (uint32_t **)calloc(max_terms * 3, sizeof(uint32_t *));
+  volatile uint64_t sink = 0;
+  for (uint32_t q = (uint32_t)c->tid; q < c->nq; q += (uint32_t)c->n_threads) {
+    uint32_t t0 = c->q_offsets[q], nt = c->q_offsets[q + 1] - t0, n_hits = 0;
+    for (uint32_t s = 0; s < c->n_segs; s++) {
+      const slo_segment *seg = &c->segs[s];
+      float *lens_by_field[64] = {0};
+      uint32_t n = 0;
+      for (uint32_t i = 0; i < nt; i++) {
+        uint32_t tid = c->q_terms[(size_t)(t0 + i) * c->n_segs + s];
+        if (tid == SLO_NO_TERM || tid >= seg->n_terms || fc->enc[s].off[tid] == UINT64_MAX) continue;
+        uint32_t field = seg->term_field ? seg->term_field[tid] : 0;
+        /* decode #1: matcher doc list */
+        const uint8_t *p = fc->enc[s].bytes + fc->enc[s].off[tid];
+        uint32_t df;
+        memcpy(&df, p, 4);
+        p += 4 + 1 + 4 + 4 + 4; /* doc_freq, flag, blocks, max_doc, max_tf (no block arrays kept here) */
+        uint32_t *m_docs = (uint32_t *)malloc((df ? df : 1) * sizeof(uint32_t));
+        {
+          const uint8_t *r = p;
+          for (uint32_t j = 0; j < df; j++) {
+            m_docs[j] = get_var(&r);
+            (void)get_var(&r);
+          }
+        }
+        sink += m_docs[df ? df - 1 : 0];
+        /* decode #2: scorer postings */
+        uint32_t *docs = (uint32_t *)malloc((df ? df : 1) * sizeof(uint32_t));
+        uint32_t *tfs = (uint32_t *)malloc((df ? df : 1) * sizeof(uint32_t));
+        {
+          const uint8_t *r = p;
+          for (uint32_t j = 0; j < df; j++) {
+            docs[j] = get_var(&r);
+            tfs[j] = get_var(&r);
+          }
+        }
+        dbuf[n * 3] = m_docs;
+        dbuf[n * 3 + 1] = docs;
+        dbuf[n * 3 + 2] = tfs;
+        /* field_lengths_for: rebuilt once per field per (query, segment) */
+        if (field < 64 && lens_by_field[field] == NULL && seg->field_doc_len[field]) {
+          float *lens = (float *)malloc((seg->n_docs ? seg->n_docs : 1) * sizeof(float));
+          const float *col = seg->field_doc_len[field];
+          uint64_t h = 0;
+          for (uint32_t d = 0; d < seg->n_docs; d++) {
+            h += fnv1a("_len:body"); /* the keyed column lookup of every i64_value call */
+            lens[d] = col[d];
+          }
+          sink += h;
+          lens_by_field[field] = lens;
+        }
+        slo_term *t = &terms[n];
+        t->doc_ids = docs;
+        t->tfs = tfs;
+        t->len = df;
+        t->weight = c->q_weights[t0 + i];
+        t->avgdl = seg->field_avgdl[field];
+        t->docs = seg->docs;
+        t->k1 = seg->k1;
+        t->b = seg->b;
+        t->leaf = i;
+        t->doc_lengths = field < 64 ? lens_by_field[field] : NULL;
+        t->n_doc_lengths = t->doc_lengths ? seg->n_docs : 0;
+        n++;
+      }
+      if (n) {
+        int got = slo_execute_top_k_plan(terms, n, c->k, c->strategy, c->block_size, SLO_PLAN_SUM, 0.0f, nt,
+                                         seg->deleted, NULL /* min_doc_len rescanned */, tmp_doc, tmp_score, NULL);
+        for (int i = 0; i < got; i++) {
+          hits[n_hits].score = tmp_score[i];
+          hits[n_hits].seg = s;
+          hits[n_hits].doc = tmp_doc[i];
+          n_hits++;
+        }
+      }
+      for (uint32_t i = 0; i < n * 3; i++) free(dbuf[i]);
+      for (int f = 0; f < 64; f++) free(lens_by_field[f]);
+    }
+    qsort(hits, n_hits, sizeof(seg_hit), seg_hit_cmp);
+    uint32_t keep = n_hits < c->k ? n_hits : c->k;
+    for (uint32_t i = 0; i < keep; i++) {
+      c->out_doc[(size_t)q * c->k + i] = hits[i].doc;
+      c->out_seg[(size_t)q * c->k + i] = hits[i].seg;
+      c->out_score[(size_t)q * c->k + i] = hits[i].score;
+    }
+    c->out_count[q] = keep;
+  }
+  free(terms);
+  free(tmp_doc);
+  free(tmp_score);
+  free(hits);
+  free(dbuf);
+  return NULL;
+}
+
+double slo_search_batch_faithful(const slo_segment *segs, uint32_t n_segs, uint32_t nq,
+                                 const uint32_t *q_offsets, const uint32_t *q_terms, const float *q_weights,
+                                 uint32_t k, int strategy, int n_threads, uint32_t *out_doc,
+                                 uint32_t *out_seg, float *out_score, uint32_t *out_count) {
+  if (n_threads < 1) n_threads = 1;
+  /* setup (untimed): serialize every distinct query term's list as PostingsWriter::write_term
+   * does (header without block arrays; absolute varint doc ids, varint tf) */
+  enc_seg *enc = (enc_seg *)calloc(n_segs, sizeof(enc_seg));
+  uint32_t total_terms = nq ? q_offsets[nq] : 0;
+  for (uint32_t s = 0; s < n_segs; s++) {
+    const slo_segment *seg = &segs[s];
+    enc[s].off = (uint64_t *)malloc((seg->n_terms ? seg->n_terms : 1) * sizeof(uint64_t));
+    for (uint32_t t = 0; t < seg->n_terms; t++) enc[s].off[t] = UINT64_MAX;
+    size_t cap = 1 << 20, used = 0;
+    enc[s].bytes = (uint8_t *)malloc(cap);
+    for (uint32_t i = 0; i < total_terms; i++) {
+      uint32_t tid = q_terms[(size_t)i * n_segs + s];
+      if (tid == SLO_NO_TERM || tid >= seg->n_terms || enc[s].off[tid] != UINT64_MAX) continue;
+      uint64_t a = seg->term_offsets[tid];
+      uint32_t df = (uint32_t)(seg->term_offsets[tid + 1] - a);
+      size_t need = 17 + (size_t)df * 10;
+      if (used + need > cap) {
+        while (used + need > cap) cap *= 2;
+        enc[s].bytes = (uint8_t *)realloc(enc[s].bytes, cap);
+      }
+      enc[s].off[tid] = used;
+      uint8_t *o = enc[s].bytes + used;
+      memcpy(o, &df, 4);
+      o[4] = 0;
+      memset(o + 5, 0, 12);
+      size_t n = 17;
+      for (uint32_t j = 0; j < df; j++) {
+        n += put_var(o + n, seg->doc_ids[a + j]);
+        n += put_var(o + n, seg->tfs[a + j]);
+      }
+      used += n;
+    }
+  }
+  faithful_ctx *ctxs = (faithful_ctx *)calloc(n_threads, sizeof(faithful_ctx));
+  pthread_t *th = (pthread_t *)malloc(n_threads * sizeof(pthread_t));
+  struct timespec ta, tb;
+  clock_gettime(CLOCK_MONOTONIC, &ta);
+  for (int t = 0; t < n_threads; t++) {
+    batch_ctx *c = &ctxs[t].base;
+    c->segs = segs;
+    c->n_segs = n_segs;
+    c->nq = nq;
+    c->q_offsets = q_offsets;
+    c->q_terms = q_terms;
+    c->q_weights = q_weights;
+    c->k = k;
+    c->strategy = strategy;
+    c->block_size = 0;
+    c->out_doc = out_doc;
+    c->out_seg = out_seg;
+    c->out_score = out_score;
+    c->out_count = out_count;
+    c->tid = t;
+    c->n_threads = n_threads;
+    ctxs[t].enc = enc;
+    pthread_create(&th[t], NULL, faithful_worker, &ctxs[t]);
+  }
+  for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+  clock_gettime(CLOCK_MONOTONIC, &tb);
+  for (uint32_t s = 0; s < n_segs; s++) {
+    free(enc[s].bytes);
+    free(enc[s].off);
+  }
+  free(enc);
+  free(ctxs);
+  free(th);
+  return (double)(tb.tv_sec - ta.tv_sec) + 1e-9 * (double)(tb.tv_nsec - ta.tv_nsec);
+}

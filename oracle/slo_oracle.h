@@ -163,4 +163,11 @@ int slo_rerank_multi(int metric, uint32_t dim, const uint32_t *vec_offsets, uint
                      uint32_t n_cand, uint32_t k_out, uint32_t *out_doc, float *out_score,
                      float *out_vec_score);
 
+/* BASELINE.md "Baseline A" (context): the scorer plus the per-query decode / doc-length rebuild
+ * IndexReader::search pays around it; returns the seconds of the query phase. */
+double slo_search_batch_faithful(const slo_segment *segs, uint32_t n_segs, uint32_t nq,
+                                 const uint32_t *q_offsets, const uint32_t *q_terms, const float *q_weights,
+                                 uint32_t k, int strategy, int n_threads, uint32_t *out_doc,
+                                 uint32_t *out_seg, float *out_score, uint32_t *out_count);
+
 #endif

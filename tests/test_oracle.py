@@ -417,3 +417,17 @@ def test_score_plan_arithmetic_against_numpy(oracle):
         assert n == len(want)
         for i in range(n):
             assert np.float32(got[2][0, i]).view(np.uint32) == np.float32(want[int(got[0][0, i])]).view(np.uint32)
+
+
+def test_baseline_a_model_returns_the_scorer_results(oracle):
+    """BASELINE.md "Baseline A" (scorer + per-query posting decode x2 + doc-length rebuild): the
+    decode / rebuild round trip must not change a single hit."""
+    from searchlite_amd import corpus
+    seg = corpus.zipf_segment(30_000, 1 << 12, seed=5, n_threads=2)
+    offs, terms, w = corpus.zipf_queries(24, 3, rank_lo=8, rank_hi=2048, seed=3, vocab=1 << 12)
+    want = oracle.search_batch([seg], offs, terms, w, 11, strategy=oracle.WAND, n_threads=2)
+    got, secs = oracle.search_batch_faithful([seg], offs, terms, w, 11, strategy=oracle.WAND, n_threads=2)
+    assert secs > 0
+    for a, b in zip(got, want):
+        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
+                              b.view(np.uint32) if b.dtype == np.float32 else b)
