@@ -45,6 +45,7 @@ constexpr int kUniCap = kUniSlots * 64;      // postings per round
 constexpr int kUniMaxLists = 4;              // lists per sub-query (one filter bit each)
 constexpr int kJoinWords = 1024;             // filter words = 8192 doc fields; also the join queue
 constexpr int kJoinPairs = 24;               // queue sizes up to this are joined all-pairs in registers
+                                             // (16 / 40 / 64 measured: no better)
 static_assert(kJoinWords * 4 >= kUniCap * 8, "the join queue ({doc, score} per posting) overlays the filter");
 // k <= 256 (KREGS <= 4): buffered top-k in LDS (BufTopK); larger k: every doc above the seed
 // threshold goes to the slice's candidate region and select_topk_kernel picks the k best
@@ -340,13 +341,19 @@ score_uniform_kernel(RoundScoreParams p) {
       const uint2 me = have ? queue[lane] : make_uint2(kDocEnd, 0u);
       float acc = 0.0f;
       bool lower = false;  // an earlier entry (= a lower list) holds my doc
-      for (uint32_t l = 0; l < n; l++) {
+      auto pair_step = [&](const uint32_t l) {
         const uint32_t dl = rl(me.x, l);
         const float xl = __uint_as_float(rl(me.y, l));
         const bool hit = dl == me.x;
         acc = hit ? acc + xl : acc;
         lower = lower || (hit && l < lane);
+      };
+      uint32_t l = 0;
+      for (; l + 1 < n; l += 2) {  // two senders per iteration: -1.4 % kernel time
+        pair_step(l);
+        pair_step(l + 1);
       }
+      if (l < n) pair_step(l);
       const uint64_t ownerm = __ballot(have && !lower);
       n_scored += (uint32_t)__popcll(ownerm);
       if ((__ballot(acc >= threshold_score()) & ownerm) != 0ull) take_checked((ownerm >> lane) & 1ull, acc, me.x);
