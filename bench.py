@@ -324,19 +324,25 @@ def main():
     thr_streams = [torch.cuda.Stream() for _ in range(n_thr)]
     first_results = {}
 
-    def host_leg(n_steps, first):
-        counter = itertools.count(first)
-        lock = threading.Lock()
-        errors = []
+    import queue
 
-        def worker(tid):
-            try:
-                torch.cuda.set_device(local_rank)
-                while True:
-                    with lock:
-                        i = next(counter)
-                    if i >= first + n_steps:
-                        return
+    class HostPool:
+        """Persistent caller threads (a server's request threads): created and warmed before the
+        timed region, fed step numbers through a queue; run(n) returns when n steps are done."""
+
+        def __init__(self):
+            self.todo, self.done, self.errors = queue.Queue(), queue.Queue(), []
+            self.threads = [threading.Thread(target=self._worker, args=(t,), daemon=True) for t in range(n_thr)]
+            for t in self.threads:
+                t.start()
+
+        def _worker(self, tid):
+            torch.cuda.set_device(local_rank)
+            while True:
+                i = self.todo.get()
+                if i is None:
+                    return
+                try:
                     offs, terms, w = qs[i % n_sets]
                     b = index.prepare(offs, terms, w, k, strategy)
                     b.set_stream(thr_streams[tid].cuda_stream)
@@ -345,25 +351,37 @@ def main():
                     b.close()
                     if (i % n_sets) not in first_results:
                         first_results[i % n_sets] = res
-            except Exception as e:  # noqa: BLE001
-                errors.append(e)
+                except Exception as e:  # noqa: BLE001
+                    self.errors.append(e)
+                self.done.put(i)
 
-        th = [threading.Thread(target=worker, args=(t,)) for t in range(n_thr)]
-        for x in th:
-            x.start()
-        for x in th:
-            x.join()
-        if errors:
-            raise errors[0]
+        def run(self, n_steps, first):
+            for i in range(first, first + n_steps):
+                self.todo.put(i)
+            for _ in range(n_steps):
+                self.done.get()
+            if self.errors:
+                raise self.errors[0]
+
+        def close(self):
+            for _ in self.threads:
+                self.todo.put(None)
+            for t in self.threads:
+                t.join()
 
     value = ms_per_step = None
     if not rerank and not args.kernel_leg_only:
-        host_leg(args.warmup, 0)
+        pool = HostPool()
+        # untimed: --warmup steps, and at least three batches per caller thread so that every
+        # thread has run and the library's buffer pool holds a set of work buffers per batch in flight
+        host_warm = max(args.warmup, 3 * n_thr)
+        pool.run(host_warm, 0)
         fence()
         t1 = time.perf_counter()
-        host_leg(args.steps, args.warmup)
+        pool.run(args.steps, host_warm)
         fence()
         elapsed = max_over_ranks(time.perf_counter() - t1)
+        pool.close()
         ms_per_step = elapsed / args.steps * 1e3
         value = nq * world / (elapsed / args.steps)
 
@@ -480,6 +498,7 @@ def main():
                                     if not rerank else
                                     "device-resident pipeline BM25 top-1000 -> rerank -> top-10 of pre-planned batches"),
                        "host_threads": None if rerank else n_thr,
+                       "host_warmup_steps": None if (rerank or args.kernel_leg_only) else host_warm,
                        "rotating_query_sets": n_sets,
                        "posting_working_set_bytes": int(8 * sum(i["n_postings"] for i in infos)),
                        "kernel_only_qps": round(resident_qps, 1),
