@@ -233,6 +233,7 @@ struct slg_batch {
   const uint32_t *d_slice_seg = nullptr;
   const uint32_t *d_slice_order = nullptr;
   const slg::QueryRef *d_queries = nullptr;
+  const uint32_t *d_bnd_coarse = nullptr;
   DevBuf d_bounds, d_rdoc, d_slice_tk, d_slice_doc, d_q_scored, d_slice_desc;
   DevBuf d_q_filter;       // [nq] 0 = none, f + 1 (select_topk_kernel); empty when unfiltered
   bool cand_mode = false;  // uniform kernel, k > 256: candidates + select_topk_kernel
@@ -1125,6 +1126,17 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     const size_t o_sseg = place<uint32_t>(cur, slice_seg.size());
     const size_t o_sord = place<uint32_t>(cur, slice_order.size());
     const size_t o_q = place<slg::QueryRef>(cur, qrefs.size());
+    // sub-query of every 32nd round boundary (partition_rounds_kernel walks from there)
+    std::vector<uint32_t> bnd_coarse((size_t)((n_bnd + 31) / 32));
+    {
+      size_t i = 0;
+      for (size_t c = 0; c < bnd_coarse.size(); c++) {
+        const uint64_t bb = (uint64_t)c * 32;
+        while (i + 1 < sqs.size() && sqs[i + 1].bnd_begin <= bb) i++;
+        bnd_coarse[c] = (uint32_t)i;
+      }
+    }
+    const size_t o_bc = place<uint32_t>(cur, bnd_coarse.size());
     const size_t total = (cur + 15) & ~(size_t)15;
     // (a blocking hipMemcpy from pageable memory, outside any lock.  Measured against a pinned
     // image copied asynchronously on the batch's stream in front of the kernels: that variant
@@ -1139,6 +1151,7 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     if (!slice_seg.empty()) std::memcpy(hb + o_sseg, slice_seg.data(), slice_seg.size() * 4);
     if (!slice_order.empty()) std::memcpy(hb + o_sord, slice_order.data(), slice_order.size() * 4);
     if (!qrefs.empty()) std::memcpy(hb + o_q, qrefs.data(), qrefs.size() * sizeof(slg::QueryRef));
+    if (!bnd_coarse.empty()) std::memcpy(hb + o_bc, bnd_coarse.data(), bnd_coarse.size() * 4);
     b->d_desc.alloc_pooled(&ix->pool, total);
     SLG_HIP(hipMemcpy(b->d_desc.p, hbuf, total, hipMemcpyHostToDevice));
     unsigned char *db = b->d_desc.as<unsigned char>();
@@ -1148,6 +1161,7 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     b->d_slice_seg = reinterpret_cast<const uint32_t *>(db + o_sseg);
     b->d_slice_order = reinterpret_cast<const uint32_t *>(db + o_sord);
     b->d_queries = reinterpret_cast<const slg::QueryRef *>(db + o_q);
+    b->d_bnd_coarse = reinterpret_cast<const uint32_t *>(db + o_bc);
 
     b->d_bounds.alloc_pooled(&ix->pool, (size_t)n_bounds * 4);
     b->d_rdoc.alloc_pooled(&ix->pool, (size_t)n_bnd * 4);
@@ -1207,6 +1221,7 @@ int slg_batch_run(slg_batch *b) {
       pp.sq = b->d_sq;
       pp.terms = b->d_terms;
       pp.n_sq = b->n_sq;
+      pp.bnd_coarse = b->d_bnd_coarse;
       pp.segs = ix->d_segs.as<slg::SegDev>();
       pp.bounds = b->d_bounds.as<uint32_t>();
       pp.rdoc = b->d_rdoc.as<uint32_t>();

@@ -33,6 +33,7 @@ struct RoundPartParams {
   const RoundQuery *sq;
   const TermRef *terms;
   const SegDev *segs;
+  const uint32_t *bnd_coarse;  // [ceil(n_boundaries / 32)] sub-query of every 32nd boundary
   uint32_t n_sq;
   uint32_t *bounds;
   uint32_t *rdoc;
@@ -71,19 +72,10 @@ static __global__ void __launch_bounds__(256) partition_rounds_kernel(RoundPartP
   const uint32_t b = gid >> 3, u = gid & 7;
   if (b >= p.n_boundaries) return;
   // the sub-query that owns boundary b: the last one whose first boundary is <= b (bnd_begin
-  // ascends) — found here rather than uploaded as a per-boundary table (most of the descriptors)
-  uint32_t sqi = 0;
-  {
-    uint32_t lo = 0, hi = p.n_sq;
-    while (hi - lo > 1) {
-      const uint32_t mid = lo + ((hi - lo) >> 1);
-      if (p.sq[mid].bnd_begin <= b)
-        lo = mid;
-      else
-        hi = mid;
-    }
-    sqi = lo;
-  }
+  // ascends).  The host uploads it for every 32nd boundary (a per-boundary table was most of the
+  // descriptor upload); from there a short walk (sub-queries have ~85 boundaries on config 2)
+  uint32_t sqi = p.bnd_coarse[b >> 5];
+  while (sqi + 1 < p.n_sq && p.sq[sqi + 1].bnd_begin <= b) sqi++;
   const RoundQuery s = p.sq[sqi];
   const uint32_t j = b - s.bnd_begin;
   const uint32_t *docs = p.segs[s.seg].docs;
