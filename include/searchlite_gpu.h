@@ -158,8 +158,9 @@ typedef struct {
   uint32_t slices_per_subquery;  /* SLG_SLICES_PER_SUBQUERY (16) */
   int32_t cand_mode;             /* !SLG_NO_CAND_MODE (1): 256 < k <= 1024 via candidates + select */
   int32_t slice_order;           /* !SLG_NO_SLICE_ORDER (1): longest slices launch first */
-  int32_t block_max;             /* !SLG_NO_BLOCK_MAX (1): stage per-block maxima (block 128,
-                                    index/postings.rs:11,101-111) and skip blocks of probed lists */
+  int32_t block_max;             /* !SLG_NO_BLOCK_MAX (1): block skipping — 64-posting blocks of
+                                    pruning-classified lists whose doc range holds no candidate doc
+                                    are not loaded (query/wand.rs:205-265) */
 } slg_tuning;
 void slg_tuning_default(slg_tuning *out);
 slg_index *slg_index_create_tuned(const slg_segment_desc *segs, uint32_t n_segs, int device,
@@ -273,6 +274,12 @@ int slg_batch_device_result_block(slg_batch *batch, void **d_block, uint64_t *n_
  * algorithmic byte count 12*postings + 8*k*nq. */
 int slg_batch_info(const slg_batch *batch, uint64_t *n_postings, uint32_t *n_slices,
                    uint64_t *algorithmic_bytes);
+/* Block skipping (query/wand.rs:205-265), last run of the batch: postings of the batch's
+ * pruning-classified (non-essential) lists, and how many of them were never loaded — their
+ * 64-posting block, or their whole round, held no candidate doc.  Blocks are tested only in lists
+ * much denser than the query's essential lists.  Both 0 when the batch has no classified list or
+ * slg_tuning.block_max is off.  Waits for the batch. */
+int slg_batch_skip_counts(slg_batch *batch, uint64_t *probed_postings, uint64_t *skipped_postings);
 void slg_batch_destroy(slg_batch *batch);
 
 /*

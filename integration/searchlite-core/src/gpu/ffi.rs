@@ -75,6 +75,7 @@ extern "C" {
         d_score: *mut *mut c_void, d_count: *mut *mut c_void) -> c_int;
     pub fn slg_batch_device_result_block(batch: *mut slg_batch, d_block: *mut *mut c_void, n_bytes: *mut u64) -> c_int;
     pub fn slg_batch_info(batch: *const slg_batch, n_postings: *mut u64, n_slices: *mut u32, algorithmic_bytes: *mut u64) -> c_int;
+    pub fn slg_batch_skip_counts(batch: *mut slg_batch, probed_postings: *mut u64, skipped_postings: *mut u64) -> c_int;
     pub fn slg_batch_destroy(batch: *mut slg_batch);
     // multi-GPU merge of per-shard result blocks, profiling, rerank
     pub fn slg_merge_shards_device(index: *mut slg_index, n_shards: u32, nq: u32, k: u32,

@@ -124,6 +124,7 @@ def load():
         "slg_batch_device_results": (i32, [vp, vp, vp, vp, vp]),
         "slg_batch_device_result_block": (i32, [vp, vp, vp]),
         "slg_batch_info": (i32, [vp, vp, vp, vp]),
+        "slg_batch_skip_counts": (i32, [vp, vp, vp]),
         "slg_batch_destroy": (None, [vp]),
         "slg_merge_shards_device": (i32, [vp, u32, u32, u32, vp, vp, vp, vp, u32, vp, vp, vp, vp]),
         "slg_profile_enable": (i32, [vp, i32]),

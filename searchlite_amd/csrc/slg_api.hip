@@ -242,7 +242,8 @@ struct slg_batch {
   uint32_t *d_out_doc = nullptr, *d_out_seg = nullptr, *d_out_count = nullptr;
   float *d_out_score = nullptr;
   DevBuf d_stamps;  // SLG_STAMPS diagnostic builds
-  DevBuf d_blk_skip;  // block-max pruning: per (sub-query, list) skip flags of 128-posting blocks
+  DevBuf d_blk_skip;  // block skipping: postings of non-essential lists that were never loaded (u64)
+  uint64_t n_postings_nonessential = 0;  // postings of the pruning-classified (non-essential) lists
 };
 
 namespace {
@@ -978,6 +979,17 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
             longest = i;
           }
         }
+        // block skipping pays where a 64-posting block of a non-essential list usually holds no
+        // candidate doc: a block spans 64 * N / df docs, which hold 64 * P / df essential postings
+        // on average; blocks are tested only below 2 (>= e^-2 = 13 % of them can be skipped).
+        // Config 3's lists are all of similar density (>= 64 per block): no test, no cost.
+        sq.skip_mask = 0;
+        if (tn.block_max)
+          for (uint32_t i = 0; i < sq.n_terms && i < 32; i++) {
+            const uint64_t df = terms[sq.term_begin + i].df;
+            if (!((ess_mask >> i) & 1u) && 64ull * P < 2ull * df) sq.skip_mask |= 1u << i;
+          }
+        b->n_postings_nonessential += P_all - P;
         b->q_postings[q] += P_all;
         b->n_postings += P_all;
         b->n_postings_essential += P;
@@ -1226,6 +1238,9 @@ int slg_batch_run(slg_batch *b) {
       pp.bounds = b->d_bounds.as<uint32_t>();
       pp.rdoc = b->d_rdoc.as<uint32_t>();
       pp.q_scored = b->d_q_scored.as<uint32_t>();
+      const bool skipping = b->pruned && !b->uniform && ix->tune.block_max != 0;
+      if (skipping && !b->d_blk_skip.p) b->d_blk_skip.alloc(16);
+      pp.skip_counts = skipping ? b->d_blk_skip.as<unsigned long long>() : nullptr;
       pp.slice_sq = b->d_slice_sq;
       pp.slice_order = b->d_slice_order;
       pp.slice_desc = b->d_slice_desc.as<slg::SliceDesc>();
@@ -1257,6 +1272,8 @@ int slg_batch_run(slg_batch *b) {
       sp.q_scored = b->d_q_scored.as<uint32_t>();
       sp.n_slices = b->n_slices;
       sp.k = b->k;
+      sp.block_skip = skipping ? 1u : 0u;
+      sp.skip_counts = pp.skip_counts;
       sp.stamps = nullptr;
 #ifdef SLG_STAMPS
       b->d_stamps.alloc((size_t)b->n_slices * 96);
@@ -1390,6 +1407,20 @@ int slg_batch_info(const slg_batch *b, uint64_t *n_postings, uint32_t *n_slices,
     if (n_postings) *n_postings = b->n_postings;
     if (n_slices) *n_slices = b->n_slices;
     if (algorithmic_bytes) *algorithmic_bytes = 12ull * b->n_postings + 8ull * b->k * b->nq;
+  });
+}
+
+int slg_batch_skip_counts(slg_batch *b, uint64_t *probed_postings, uint64_t *skipped_postings) {
+  return guarded([&] {
+    SLG_REQUIRE_LIVE(b);
+    DeviceGuard g(b->idx->device);
+    unsigned long long c = 0ull;
+    if (b->d_blk_skip.p) {
+      SLG_HIP(hipStreamSynchronize(batch_stream(b)));
+      SLG_HIP(hipMemcpy(&c, b->d_blk_skip.p, 8, hipMemcpyDeviceToHost));
+    }
+    if (probed_postings) *probed_postings = b->d_blk_skip.p ? b->n_postings_nonessential : 0ull;
+    if (skipped_postings) *skipped_postings = c;
   });
 }
 

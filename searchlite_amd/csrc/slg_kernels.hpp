@@ -59,6 +59,8 @@ struct RoundQuery {  // sub-query = (query, segment) pair with >= 1 non-empty te
   uint32_t bnd_begin;     // first boundary task of this sub-query (partition kernel)
   uint32_t longest;       // index of the longest ESSENTIAL list (splitter source)
   uint32_t ess_mask;      // bit t: list t is essential (MaxScore); the others are only probed
+  uint32_t skip_mask;     // bit t: non-essential list t is sparse-probed: its 64-posting blocks are
+                          // tested against the candidate docs before they are loaded (block skipping)
   uint32_t filter;        // 0: none; f + 1: docs must also pass filter f (reject table row f)
   uint32_t cand_lo, cand_hi;  // large-k mode: first candidate slot of this sub-query (u64)
   // score plan (query/planner.rs:113-153): 0 = every term its own leaf, summed (the flat sum in

@@ -22,6 +22,11 @@
 // below the seed threshold (slg_api.hip) — a doc found only in them cannot reach the top-k.  Such
 // lists set no bitmap bits in sweep A; in sweep C their postings are only probed against the
 // bitmap of the essential lists and added (in list order) where the doc is present.
+// Block skipping (wand.rs:205-265 advance_to / skip_to_block: postings between candidate docs are
+// never visited): a 64-posting slot of a non-essential list is a block; its first and last doc id
+// are read (2 sectors) before sweep A, and after P2 the bitmap's rank structure says how many
+// essential docs lie in [first, last] — none: the slot is dropped from sweep C, its 512 B of
+// postings are never loaded.  A round with no essential posting at all is skipped outright.
 //
 // Score plans (query/planner.rs:113-153): when several terms share a ScorePlan leaf
 // (multi-field query strings) or the root is a DisMax, the lists arrive sorted by leaf; vals[]
@@ -122,6 +127,9 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
     if (th0 > 0.0f) btop.set_floor(th0);
   }
   uint32_t n_scored = 0;
+  const uint32_t skip_mask = MS && p.block_skip ? rfl(s.skip_mask) : 0u;
+  const bool skipping = skip_mask != 0u;
+  uint32_t n_skipped = 0;  // postings of non-essential lists that were never loaded
 #ifdef SLG_STAMPS
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
@@ -205,6 +213,10 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
       // essential postings need accumulators; all slots' descriptors live in the 64 lanes
       // (without pruning every posting is essential and R <= 512 already implies <= 8 + T slots)
       const uint32_t R_ess = MS ? wave_sum(my_ess ? rem : 0u) : R;
+      if (MS && p.block_skip && R_ess == 0u) {  // no essential posting left in this round: nothing can score
+        n_skipped += R;
+        break;
+      }
       const uint32_t S_all = MS ? wave_sum((rem + 63u) >> 6) : 0u;
       uint32_t chunk = rem, dhi = rdhi;
       bool cut = false;
@@ -234,8 +246,20 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
       uint32_t a_st = d_st, a_cnt = d_cnt, a_lo = d_lo, a_hi = d_hi, S_a = S;
       if constexpr (MS) S_a = describe(my_ess ? chunk : 0u, cur, a_st, a_cnt, a_lo, a_hi);
       const uint32_t nb_a = (S_a + 7u) >> 3;
-      const uint32_t nb = (S + 7u) >> 3;
+      uint32_t nb = (S + 7u) >> 3;
       const uint32_t wspan = dhi - wbase;
+      // block skipping: lane G = slot G of a non-essential list reads the slot's first and last doc
+      // id now (the loads fly during sweep A); the skip test follows P2
+      bool probe = false;
+      uint32_t p_fd = 0, p_ld = 0;
+      if (skipping) {
+        probe = lane < S && d_cnt != 0u && ((skip_mask >> d_st) & 1u) != 0u;
+        if (probe) {
+          const uint64_t base = ((uint64_t)d_hi << 32) | d_lo;
+          p_fd = gdocs[base];
+          p_ld = gdocs[base + d_cnt - 1u];
+        }
+      }
       SLG_STAMP(0);
 
       // ---- P0: clear bitmap and accumulators ----
@@ -270,7 +294,7 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
           for (int jj = 0; jj < NS; jj++) {
             const bool live = lane < rl(a_cnt, bb * 8u + jj) && src[jj] < dhi;
             const uint32_t rel = src[jj] - wbase;
-            if (live && rel < wspan) atomicOr(&bm[rel & (kSpanWords - 1)], 1u << (rel >> 9));
+            if (live && rel < wspan) atomicOr(&bm[rel >> 5], 1u << (rel & 31u));
           }
         };
         if (nb_a > 0) issue_docs(da, 0);
@@ -287,17 +311,18 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
       SLG_STAMP(2);
       issue_batch(0, d_lo, d_hi);  // sweep C's first batch
       wave_fence();
-      // ---- P2: exclusive prefix popcount (lane l owns words 4l..4l+3 and 256+4l..256+4l+3) ----
+      // ---- P2: exclusive prefix popcount (lane l owns words 8l..8l+7: bit order = doc order, so
+      //      rank(doc) is monotone and a doc range's population is a difference of two ranks) ----
       uint32_t ndocs;
       {
-        const uint4 a = bm4[lane], bb = bm4[lane + 64];
+        const uint4 a = bm4[2 * lane], bb = bm4[2 * lane + 1];
         const uint32_t c0 = __popc(a.x), c1 = c0 + __popc(a.y), c2 = c1 + __popc(a.z),
                        c3 = c2 + __popc(a.w), c4 = c3 + __popc(bb.x), c5 = c4 + __popc(bb.y),
                        c6 = c5 + __popc(bb.z), c7 = c6 + __popc(bb.w);
         const uint32_t incl = wave_incl_scan(c7);
         const uint32_t ex = incl - c7;
-        pre4[lane] = make_uint4(ex, ex + c0, ex + c1, ex + c2);
-        pre4[lane + 64] = make_uint4(ex + c3, ex + c4, ex + c5, ex + c6);
+        pre4[2 * lane] = make_uint4(ex, ex + c0, ex + c1, ex + c2);
+        pre4[2 * lane + 1] = make_uint4(ex + c3, ex + c4, ex + c5, ex + c6);
         ndocs = rl(incl, 63);
         n_scored += ndocs;
       }
@@ -325,9 +350,50 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
         wave_fence();
       };
       uint32_t cur_leaf = 0xFFFFFFFFu;
+      uint32_t consumed = 0;  // what every list consumes: its postings below the cut
+      if (skipping) {
+        // essential docs in [first, last] of my slot = rank(last + 1) - rank(first); rank(x) =
+        // docs of the window below x (bits at or past wspan are never set)
+        auto rank_below = [&](const uint32_t x) {
+          const uint32_t wi = (x >> 5) & (kSpanWords - 1);
+          const uint32_t r = pre[wi] + __popc(bm[wi] & ((1u << (x & 31u)) - 1u));
+          return x >= wspan ? ndocs : r;
+        };
+        // a slot that begins at or past the cut has no posting in this chunk; one that straddles
+        // the cut is kept (its consumed count comes from the loaded doc ids)
+        const bool past = probe && p_fd >= dhi;
+        const bool whole = probe && p_ld < dhi;
+        const uint32_t hits = probe && !past ? rank_below((p_ld < dhi ? p_ld : dhi - 1u) - wbase + 1u) -
+                                                   rank_below(p_fd - wbase)
+                                             : 0u;
+        const bool skip = probe && (past || (whole && hits == 0u));
+        const uint64_t skipm = __ballot(skip);
+        if (skipm != 0ull) {
+          n_skipped += wave_sum(skip && whole ? d_cnt : 0u);  // (slots past the cut come again)
+          if (cut)  // a skipped slot below the cut is consumed whole
+            for (uint32_t t = 0; t < T; t++) {
+              const uint32_t c = wave_sum(skip && whole && d_st == t ? d_cnt : 0u);
+              consumed += lane == t ? c : 0u;
+            }
+          // compact the descriptor lanes of the kept slots (order preserved = list order); the
+          // dropped lanes all land on lane 63 with count 0, lanes nobody writes read 0
+          const uint64_t keepm = ~skipm;
+          const uint32_t pos = skip ? 63u
+                                    : __builtin_amdgcn_mbcnt_hi((uint32_t)(keepm >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)keepm, 0u));
+          const uint32_t kept = (uint32_t)__popcll(keepm & (S >= 64u ? ~0ull : ((1ull << S) - 1ull)));
+          const bool first8_same = (skipm & 0xFFull) == 0ull;
+          d_cnt = (uint32_t)__builtin_amdgcn_ds_permute((int)(pos * 4u), (int)(skip ? 0u : d_cnt));
+          d_st = (uint32_t)__builtin_amdgcn_ds_permute((int)(pos * 4u), (int)d_st);
+          d_lo = (uint32_t)__builtin_amdgcn_ds_permute((int)(pos * 4u), (int)d_lo);
+          d_hi = (uint32_t)__builtin_amdgcn_ds_permute((int)(pos * 4u), (int)d_hi);
+          if (kept < 64u && lane >= kept) d_cnt = 0u;  // (lane 63 may hold a dropped slot's leftovers)
+          nb = (kept + 7u) >> 3;
+          if (!first8_same && nb != 0u) issue_batch(0, d_lo, d_hi);  // batch 0 changed: load it again
+        }
+      }
       SLG_STAMP(3);
       // ---- sweep C: rank every posting, accumulate slot by slot (= in list order) ----
-      uint32_t consumed = 0;  // what every list consumes: its postings below the cut
       for (uint32_t b = 0; b < nb; b++) {
         take_batch(b, d_cnt, dhi);
         if (b + 1 < nb) issue_batch(b + 1, d_lo, d_hi);
@@ -338,13 +404,13 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
 #pragma unroll
           for (int jj = 0; jj < NS; jj++) {
             const uint32_t rel = doc[jj] - wbase;
-            const uint32_t wi = rel & (kSpanWords - 1);
+            const uint32_t wi = (rel >> 5) & (kSpanWords - 1);
             in[jj] = rel < wspan;
             if (cut) {  // (the ballot must run in all lanes: keep it out of the lane select)
               const uint32_t n_in = (uint32_t)__popcll(__ballot(in[jj]));
               consumed += lane == rl(d_st, b * 8u + jj) ? n_in : 0u;
             }
-            bit[jj] = 1u << ((rel >> 9) & 31u);
+            bit[jj] = 1u << (rel & 31u);
             wd[jj] = bm[wi];
             pf[jj] = pre[wi];
           }
@@ -424,6 +490,7 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
     p.slice_ccnt[slice] = ccur;
   }
   if (p.q_scored && lane == 0 && n_scored) atomicAdd(&p.q_scored[s.q], n_scored);
+  if (p.skip_counts && lane == 0 && n_skipped) atomicAdd(&p.skip_counts[0], (unsigned long long)n_skipped);
 #ifdef SLG_STAMPS
   SLG_STAMP(6);
   if (p.stamps && lane == 0) {

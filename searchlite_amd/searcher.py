@@ -350,6 +350,13 @@ class PreparedBatch:
         return {"n_postings": npost.value, "n_slices": nsl.value,
                 "algorithmic_bytes": nbytes.value}
 
+    def skip_counts(self):
+        """-> (postings of pruning-classified lists the plan covered, those never loaded) of the
+        last run (block skipping, query/wand.rs:205-265)."""
+        probed, skipped = C.c_uint64(), C.c_uint64()
+        N.check(self._lib.slg_batch_skip_counts(self._h, C.addressof(probed), C.addressof(skipped)))
+        return probed.value, skipped.value
+
     def device_results(self):
         """-> (d_doc, d_seg, d_score, d_count) raw device addresses."""
         ptrs = [C.c_void_p() for _ in range(4)]

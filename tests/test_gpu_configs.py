@@ -85,6 +85,46 @@ def test_five_terms_top100_pruned_kernel_small(gpu, oracle, tuning):
             assert sum(pr[q].scored_docs for q in range(192)) < sum(ex[q].scored_docs for q in range(192))
 
 
+def _skewed_queries(nq, vocab, seed):
+    """One stop-word-like term (rank 1..8: in most docs) at a varying position among four rare
+    terms (ranks 4096..32768): the shape WAND's skipping is made for."""
+    rng = np.random.default_rng(seed)
+    T = 5
+    terms = np.empty((nq, T), dtype=np.uint32)
+    for q in range(nq):
+        rare = rng.choice(np.arange(4096, min(32768, vocab), dtype=np.uint32), size=T - 1, replace=False) - 1
+        row = list(rare)
+        row.insert(q % T, np.uint32(rng.integers(0, 8)))
+        terms[q] = row
+    offs = (np.arange(nq + 1, dtype=np.uint32) * T).astype(np.uint32)
+    return offs, terms.reshape(-1), np.ones(nq * T, dtype=np.float32)
+
+
+@pytest.mark.parametrize("tuning", [None, {"probe_target": 8192}, {"block_max": 0}])
+def test_block_skipping_skewed_queries(gpu, oracle, tuning):
+    """Block skipping (query/wand.rs:205-265): 64-posting blocks of a non-essential list that hold
+    no candidate doc are not loaded.  Same hits as the exhaustive oracle, and most of the dense
+    list's postings are skipped.  probe_target 8192 makes rounds of > 60 slots, which are cut into
+    chunks (the skipped slots below the cut must count as consumed)."""
+    from searchlite_amd import corpus
+    seg = corpus.zipf_segment(200_000, 1 << 15, seed=45)
+    offs, terms, w = _skewed_queries(96, 1 << 15, seed=3)
+    for k in (11, 101):
+        want = oracle.search_batch([seg], offs, terms, w, k, strategy=oracle.BM25, n_threads=8)
+        with gpu.GpuIndex([seg], tuning=tuning) as ix:
+            for strat in (gpu.Wand, gpu.Bmw):
+                b = ix.prepare(offs, terms, w, k, strat)
+                b.run()
+                got = b.fetch()
+                probed, skipped = b.skip_counts()
+                b.close()
+                assert_same_hits(got[:4], want, 0.0, f"skewed k={k} strategy {strat} tuning {tuning}")
+                if tuning and tuning.get("block_max") == 0:
+                    assert (probed, skipped) == (0, 0)
+                else:
+                    assert probed > 0 and skipped > probed // 3, (probed, skipped)
+
+
 # ---- config 4: 8 index shards, batch 8192, all-gather + merge -----------------------------------------
 def test_config4_eight_shards_merge_on_one_gpu(gpu, oracle):
     """Config 4's data path on one GPU: the 8 shards bench.py --config c4 builds (1.25M docs each,

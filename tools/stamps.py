@@ -11,7 +11,7 @@ if len(sys.argv) > 1:
 seg = corpus.zipf_segment(1_000_000, 1 << 18, seed=42)
 offs, terms, w = corpus.zipf_queries(1024, int(os.environ.get("TERMS", "3")), seed=7, vocab=1 << 18)
 ix = searcher.GpuIndex([seg])
-b = ix.prepare(offs, terms, w, 11, int(os.environ.get("STRATEGY", "1")))
+b = ix.prepare(offs, terms, w, int(os.environ.get("K", "11")), int(os.environ.get("STRATEGY", "1")))
 for _ in range(3):
     b.run()
 b.sync()
