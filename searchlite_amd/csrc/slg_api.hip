@@ -1187,6 +1187,9 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
       b->d_slice_doc.alloc_pooled(&ix->pool, (size_t)b->n_slices * k * 4);
     }
     b->d_q_scored.alloc_pooled(&ix->pool, (size_t)nq * 4);
+    // (from the pool like every per-batch buffer: a raw hipMalloc / hipFree per batch synchronises
+    // the device and cost config 4's two-in-flight pipeline 60 %)
+    if (b->pruned && !b->uniform && tn.block_max) b->d_blk_skip.alloc_pooled(&ix->pool, 16);
     if (any_filter) {
       std::vector<uint32_t> qf(nq, 0u);
       for (uint32_t q = 0; q < nq; q++)
@@ -1238,8 +1241,7 @@ int slg_batch_run(slg_batch *b) {
       pp.bounds = b->d_bounds.as<uint32_t>();
       pp.rdoc = b->d_rdoc.as<uint32_t>();
       pp.q_scored = b->d_q_scored.as<uint32_t>();
-      const bool skipping = b->pruned && !b->uniform && ix->tune.block_max != 0;
-      if (skipping && !b->d_blk_skip.p) b->d_blk_skip.alloc(16);
+      const bool skipping = b->d_blk_skip.p != nullptr;
       pp.skip_counts = skipping ? b->d_blk_skip.as<unsigned long long>() : nullptr;
       pp.slice_sq = b->d_slice_sq;
       pp.slice_order = b->d_slice_order;

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Files what tools/final_run.sh produced (merged back into gpurun_out/) under profiles/.
+# usage: bash tools/final_copy.sh <round tag>
+TAG=${1:-r02}
+G=gpurun_out
+for c in c2 c3 c4 c5; do tail -1 $G/final/bench_$c.json > profiles/${TAG}_bench_$c.json; done
+tail -1 $G/final/bench_c2_steps20.json > profiles/${TAG}_bench_c2_steps20.json
+for c in c2 c3; do
+  cp $G/prof_${TAG}_$c/trace/run_kernel_stats.csv profiles/${TAG}_${c}_kernel_stats.csv
+  cp $G/prof_${TAG}_$c/summary.txt profiles/${TAG}_${c}_rocprof_summary.txt
+  cp $G/prof_${TAG}_$c/traffic.json profiles/traffic_$c.json
+done
+tail -2 $G/final/pytest_gpu.log > profiles/${TAG}_pytest_gpu_tail.txt
