@@ -50,15 +50,18 @@ static_assert(kJoinWords * 4 >= kUniCap * 8, "the join queue ({doc, score} per p
 // k <= 256 (KREGS <= 4): buffered top-k in LDS (BufTopK); larger k: every doc above the seed
 // threshold goes to the slice's candidate region and select_topk_kernel picks the k best
 constexpr bool uni_buffered(int kregs) { return kregs <= 4; }
-constexpr int uni_wave_lds(int kregs) {  // filter / join queue, top-k buffer
-  return kJoinWords * 4 + (uni_buffered(kregs) ? buftopk_lds(kregs) : 0);
-}
+// per-wave LDS: filter / join queue, top-k buffer, then the slice's cut points (64 words) and the
+// lists' posting offsets (2 x 4 words) — values needed once per 8 rounds, kept out of the VGPRs
+constexpr int kUniPlanLds = 64 * 4 + 2 * kUniMaxLists * 4;
+constexpr int uni_plan_off(int kregs) { return kJoinWords * 4 + (uni_buffered(kregs) ? buftopk_lds(kregs) : 0); }
+constexpr int uni_wave_lds(int kregs) { return uni_plan_off(kregs) + kUniPlanLds; }
 
 #ifndef SLG_UNI_WAVES
-#define SLG_UNI_WAVES 5  // waves per SIMD the register allocation aims at
+#define SLG_UNI_WAVES 6  // waves per SIMD the register allocation aims at (80 VGPRs, no spills)
 #endif
 template <int KREGS>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLG_UNI_WAVES, SLG_UNI_WAVES)))
+__global__ void __launch_bounds__(64)
+    __attribute__((amdgpu_waves_per_eu(KREGS == 4 ? 5 : SLG_UNI_WAVES, KREGS == 4 ? 5 : SLG_UNI_WAVES)))  // (k 129..256: 16 spills at 6)
 score_uniform_kernel(RoundScoreParams p) {
   constexpr int NS = kUniSlots;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -83,19 +86,20 @@ score_uniform_kernel(RoundScoreParams p) {
   const gu32_t gdel = (gu32_t)(fid ? p.reject_table[(size_t)(fid - 1) * p.n_segs + sl.seg] : sd.deleted);
   const uint32_t k = p.k;
 
-  // lane t < T: list t's posting offset and weight
-  uint64_t my_off = 0;
+  // lane t < T: list t's weight; its posting offset and all cut points of the slice (entry
+  // r*T + t: where round r starts in list t) go to LDS
+  uint32_t *const bflat = reinterpret_cast<uint32_t *>(smem + uni_plan_off(KREGS));
+  uint32_t *const off_lo = bflat + 64, *const off_hi = off_lo + kUniMaxLists;
   float my_w = 0.0f;
   if (lane < T) {
     const TermRef tr = p.terms[sl.term_begin + lane];
-    my_off = tr.off;
     my_w = tr.weight;
+    off_lo[lane] = (uint32_t)tr.off;
+    off_hi[lane] = (uint32_t)(tr.off >> 32);
   }
-  const uint32_t my_off_lo = (uint32_t)my_off, my_off_hi = (uint32_t)(my_off >> 32);
-  // all cut points of the slice in one register (lane i: its i-th cut point)
-  const uint32_t bflat = lane < (n_r + 1) * T ? p.bounds[sl.bounds_off + lane] : 0u;
-  // lane i = r*T + t: postings of list t in round r
-  const uint32_t dcnt = __shfl(bflat, (lane + T) & 63u, 64) - bflat;
+  bflat[lane] = lane < (n_r + 1) * T ? p.bounds[sl.bounds_off + lane] : 0u;
+  wave_fence();
+  auto list_off = [&](const uint32_t t) { return ((uint64_t)off_hi[t] << 32) | off_lo[t]; };
 
   BufTopK<BUF ? KREGS : 1> btop;  // k <= 256; for larger k only its threshold is used
   btop.init(reinterpret_cast<uint64_t *>(smem + kJoinWords * 4));
@@ -105,7 +109,7 @@ score_uniform_kernel(RoundScoreParams p) {
   uint64_t cbeg = 0;
   if (!BUF) {
     uint32_t before = 0;
-    for (uint32_t t = 0; t < T; t++) before += rl(bflat, t);
+    for (uint32_t t = 0; t < T; t++) before += rfl(bflat[t]);
     cbeg = (((uint64_t)rfl(sl.cand_hi) << 32) | rfl(sl.cand_lo)) + before;
   }
   uint2 *const creg = BUF ? nullptr : p.cand + cbeg;
@@ -116,7 +120,7 @@ score_uniform_kernel(RoundScoreParams p) {
   // distinct docs scored (QueryStats.scored_docs): every posting of the slice is one, except the
   // queued ones, of which only the owners count (added in the join)
   uint32_t n_scored = 0;
-  for (uint32_t t = 0; t < T; t++) n_scored += rl(bflat, n_r * T + t) - rl(bflat, t);
+  for (uint32_t t = 0; t < T; t++) n_scored += rfl(bflat[n_r * T + t]) - rfl(bflat[t]);
 #ifdef SLG_STAMPS
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_ins = 0, st_queued = 0;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
@@ -124,16 +128,21 @@ score_uniform_kernel(RoundScoreParams p) {
 #endif
 
   // One round's postings: slot jj holds <= 64 postings of one list.  A slot is described by one
-  // lane of a Desc (list, postings in the slot, 64-bit index of its first posting); the slots of
-  // a round are the 8 lanes starting at `dbase`.
+  // lane of a Desc; the slots of a round are the 8 lanes starting at `dbase`.  Two VGPRs per
+  // descriptor set (the kernel's time follows its waves per SIMD: every register counts):
+  //   meta = list | postings in the slot << 4 | slots the round needs << 12 (saturated: > NS means
+  //          it does not fit and is streamed in chunks) | bits 32.. of the first posting's index << 20
+  //   lo   = bits 0..31 of that index
   struct Desc {
-    uint32_t st, cnt, lo, hi;
-    uint32_t nsl;  // slots the round needs (> NS: it does not fit and is streamed in chunks)
+    uint32_t meta, lo;
+  };
+  auto mk_meta = [](const uint32_t st, const uint32_t cnt, const uint32_t nsl, const uint32_t hi) {
+    return st | (cnt << 4) | ((nsl < 255u ? nsl : 255u) << 12) | (hi << 20);
   };
   struct URound {
     uint32_t doc[NS];
     float imp[NS];
-    uint32_t st, cnt;  // copies of the Desc's list ids / counts (it may be rebuilt meanwhile)
+    uint32_t stpack;  // uniform: list of slot jj in bits 4jj..4jj+3 (set by settle)
     uint32_t dbase;   // uniform: first descriptor lane of this round
     uint32_t nslots;  // uniform
   };
@@ -144,26 +153,24 @@ score_uniform_kernel(RoundScoreParams p) {
     const uint32_t ri = g0 + (lane >> 3), j = lane & 7u;
     const bool rv = ri < n_r;
     uint32_t run = 0;  // slots of the lists before list t
-    d.st = 0;
-    d.cnt = 0;
+    uint32_t st = 0, cnt = 0, hi = 0;
     d.lo = 0;
-    d.hi = 0;
     for (uint32_t t = 0; t < T; t++) {
       const uint32_t src = (ri * T + t) & 63u;
-      const uint32_t lo_t = __shfl(bflat, (int)src, 64);
-      const uint32_t c_t = __shfl(dcnt, (int)src, 64);
+      const uint32_t lo_t = bflat[src];
+      const uint32_t c_t = bflat[(src + T) & 63u] - lo_t;  // postings of list t in the round
       const uint32_t m = rv ? (c_t + 63u) >> 6 : 0u;
       const bool mine = j >= run && j < run + m;
       const uint32_t kin = (j - run) * 64u;  // postings of the list before this slot
-      const uint64_t base = (((uint64_t)rl(my_off_hi, t) << 32) | rl(my_off_lo, t)) + lo_t + kin;
+      const uint64_t base = list_off(t) + lo_t + kin;
       const uint32_t left = c_t - kin;
-      d.st = mine ? t : d.st;
-      d.cnt = mine ? (left < 64u ? left : 64u) : d.cnt;
+      st = mine ? t : st;
+      cnt = mine ? (left < 64u ? left : 64u) : cnt;
       d.lo = mine ? (uint32_t)base : d.lo;
-      d.hi = mine ? (uint32_t)(base >> 32) : d.hi;
+      hi = mine ? (uint32_t)(base >> 32) : hi;
       run += m;
     }
-    d.nsl = run;
+    d.meta = mk_meta(st, cnt, run, hi);
   };
 
   // ---- descriptors for per-list ranges [lo, lo+cnt) held in lane t (chunks of an over-full
@@ -175,53 +182,51 @@ score_uniform_kernel(RoundScoreParams p) {
       ss = lane == t ? run : ss;
       run += rl(m, t);
     }
-    d.nsl = run;
     // lane j: which list owns slot j = the last list whose first slot is <= j
     uint32_t tj = 0;
     for (uint32_t t = 1; t < T; t++) tj = lane >= rl(ss, t) ? t : tj;
     const uint32_t l_ss = __shfl(ss, (int)tj, 64), l_cnt = __shfl(cnt, (int)tj, 64);
-    const uint64_t l_abs = (((uint64_t)__shfl(my_off_hi, (int)tj, 64) << 32) |
-                            __shfl(my_off_lo, (int)tj, 64)) +
-                           __shfl(lo, (int)tj, 64);
+    const uint64_t l_abs = list_off(tj) + __shfl(lo, (int)tj, 64);
     const uint32_t kin = (lane - l_ss) * 64u;
     const bool used = lane < run && lane < (uint32_t)NS;
     const uint32_t left = used && l_cnt > kin ? l_cnt - kin : 0u;
-    d.st = tj;
-    d.cnt = left < 64u ? left : 64u;
     const uint64_t base = l_abs + kin;
+    d.meta = mk_meta(tj, left < 64u ? left : 64u, run, (uint32_t)(base >> 32));
     d.lo = (uint32_t)base;
-    d.hi = (uint32_t)(base >> 32);
   };
 
   // ---- issue the loads of the round described by lanes dbase .. dbase+7 of d: whole 64-lane
   //      slots, scalar base + lane (no per-lane predicate; the arrays are padded by 64 entries).
   //      Lanes past the slot's count hold other postings until settle() masks them. ----
   auto issue = [&](URound &r, const Desc &d, const uint32_t dbase) {
-    r.st = d.st;
-    r.cnt = d.cnt;
     r.dbase = dbase;
 #pragma unroll
     for (int jj = 0; jj < NS; jj++) {
-      const uint64_t base = ((uint64_t)rl(d.hi, dbase + jj) << 32) | rl(d.lo, dbase + jj);
+      const uint64_t base = ((uint64_t)(rl(d.meta, dbase + jj) >> 20) << 32) | rl(d.lo, dbase + jj);
       r.doc[jj] = gdocs[base + lane];
       r.imp[jj] = gimps[base + lane];
     }
   };
   // ---- dst = the loaded round src, ready to accumulate: lanes beyond each slot's count become
   //      idle lanes (doc = kDocEnd) and the impacts are multiplied by the slot's list weight
-  //      (score_tf, query/wand.rs:285: one scalar per slot) ----
-  auto settle = [&](URound &dst, const URound &src) {
-    dst.st = src.st;
-    dst.cnt = src.cnt;
+  //      (score_tf, query/wand.rs:285: one scalar per slot).  d = the descriptors src was issued
+  //      from (still in place: the next group is described after the settle) ----
+  auto settle = [&](URound &dst, const URound &src, const Desc &d) {
     dst.dbase = src.dbase;
     dst.nslots = src.nslots;
+    uint32_t sp = 0;
 #pragma unroll
     for (int jj = 0; jj < NS; jj++) {
-      const float w = __int_as_float((int)rl((uint32_t)__float_as_int(my_w), rl(src.st, src.dbase + jj)));
-      dst.doc[jj] = lane < rl(src.cnt, src.dbase + jj) ? src.doc[jj] : kDocEnd;
+      const uint32_t m = rl(d.meta, src.dbase + jj);
+      const uint32_t st = m & 15u, cnt = (m >> 4) & 255u;
+      const float w = __int_as_float((int)rl((uint32_t)__float_as_int(my_w), st));
+      dst.doc[jj] = lane < cnt ? src.doc[jj] : kDocEnd;
       dst.imp[jj] = src.imp[jj] * w;
+      sp |= st << (4 * jj);
     }
+    dst.stpack = sp;
   };
+  auto slot_list = [](const URound &e, const int jj) { return (e.stpack >> (4 * jj)) & 15u; };
 
   // ---- candidates -> top-k.  Cheap necessary condition first (an IEEE compare with the
   //      threshold's score: total_cmp order implies it), exact compare + append in take_checked.
@@ -265,7 +270,7 @@ score_uniform_kernel(RoundScoreParams p) {
       // P1: one bit per posting: word = doc mod 1024, field = (doc / 1024) mod 8, bit = list
 #pragma unroll
       for (int jj = 0; jj < NS; jj++) {
-        const uint32_t lbit = 1u << rl(e.st, e.dbase + jj);  // uniform
+        const uint32_t lbit = 1u << slot_list(e, jj);  // uniform
         if (e.doc[jj] != kDocEnd)
           atomicOr(&flt[e.doc[jj] & (kJoinWords - 1)], lbit << ((e.doc[jj] >> 8) & 0x1Cu));
       }
@@ -280,7 +285,7 @@ score_uniform_kernel(RoundScoreParams p) {
       // P3: shared docs (and aliases) are queued, in slot = list order
 #pragma unroll
       for (int jj = 0; jj < NS; jj++) {
-        const uint32_t tj = rl(e.st, e.dbase + jj);  // uniform
+        const uint32_t tj = slot_list(e, jj);  // uniform
         const uint32_t others = 0xFu & ~(1u << tj);
         const uint32_t fld = (fin[jj] >> ((e.doc[jj] >> 8) & 0x1Cu)) & others;
         const uint64_t m = __ballot(fld != 0u) & validm[jj];
@@ -363,7 +368,7 @@ score_uniform_kernel(RoundScoreParams p) {
       uint32_t qe0 = 0, qe1 = 0, qe2 = 0, qe3 = 0;
 #pragma unroll
       for (int jj = 0; jj < NS; jj++) {
-        const uint32_t tj = rl(e.st, e.dbase + jj);
+        const uint32_t tj = slot_list(e, jj);
         const uint32_t c = (uint32_t)__popcll(sharedm[jj]);  // (0 for unused slots)
         qe0 += tj <= 0u ? c : 0u;
         qe1 += tj <= 1u ? c : 0u;
@@ -410,7 +415,7 @@ score_uniform_kernel(RoundScoreParams p) {
   // lane t < T: cut points of round rr and rr + 1 of this slice
   auto cuts = [&](const uint32_t rr, uint32_t &lo, uint32_t &hi) {
     const uint32_t src = rr * T + lane;
-    const uint32_t a = __shfl(bflat, src & 63, 64), b = __shfl(bflat, (src + T) & 63, 64);
+    const uint32_t a = bflat[src & 63], b = bflat[(src + T) & 63];
     lo = lane < T ? a : 0u;
     hi = lane < T ? b : 0u;
   };
@@ -426,15 +431,14 @@ score_uniform_kernel(RoundScoreParams p) {
   URound ew, en;
   Desc G, C;  // descriptors of the current group of 8 planned rounds / of the current chunk
   describe_group(G, 0);
-  en.nslots = rl(G.nsl, 0);
-  en.st = G.st;
+  en.nslots = (rl(G.meta, 0) >> 12) & 255u;
   en.dbase = 0;
   if (en.nslots <= (uint32_t)NS) issue(en, G, 0);
   for (uint32_t rr = 0; rr < n_r; rr++) {
     const bool big = en.nslots > (uint32_t)NS;
     uint32_t ocur = 0, oend = 0;
     if (big) cuts(rr, ocur, oend);
-    if (!big) settle(ew, en);
+    if (!big) settle(ew, en, G);
 #ifdef SLG_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -442,8 +446,7 @@ score_uniform_kernel(RoundScoreParams p) {
     if (rr + 1 < n_r) {  // prefetch the next round
       const uint32_t nx = rr + 1, db = (nx & 7u) * 8u;
       if (db == 0) describe_group(G, nx);
-      en.nslots = rl(G.nsl, db);
-      en.st = G.st;
+      en.nslots = (rl(G.meta, db) >> 12) & 255u;
       en.dbase = db;
       if (en.nslots <= (uint32_t)NS) issue(en, G, db);
     }
@@ -466,11 +469,11 @@ score_uniform_kernel(RoundScoreParams p) {
           chunk = rem < mslots * 64u ? rem : mslots * 64u;
         }
         uint32_t lastdoc = kDocEnd;
-        if (chunk < rem) lastdoc = gdocs[my_off + ocur + chunk - 1];
+        if (chunk < rem) lastdoc = gdocs[list_off(lane < T ? lane : 0u) + ocur + chunk - 1];
         describe_chunk(C, ocur, chunk);
-        ew.nslots = C.nsl;
+        ew.nslots = (rl(C.meta, 0) >> 12) & 255u;
         issue(ew, C, 0);
-        settle(ew, ew);
+        settle(ew, ew, C);
         uint32_t bound = kDocEnd;
         for (uint32_t t = 0; t < T; t++) {
           const uint32_t ld = rl(lastdoc, t);
@@ -482,7 +485,7 @@ score_uniform_kernel(RoundScoreParams p) {
 #pragma unroll
         for (int jj = 0; jj < NS; jj++) {
           const uint32_t cnt = (uint32_t)__popcll(__ballot(ew.doc[jj] < dhi));
-          consumed += lane == rl(ew.st, jj) ? cnt : 0u;  // chunk descriptors: dbase 0
+          consumed += lane == slot_list(ew, jj) ? cnt : 0u;
           ew.doc[jj] = ew.doc[jj] < dhi ? ew.doc[jj] : kDocEnd;  // the rest: next chunk
         }
         ocur += consumed;
