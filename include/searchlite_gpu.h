@@ -94,7 +94,10 @@ typedef struct {
   uint32_t vec_rows;
 } slg_segment_desc;
 
-/* query/wand.rs:45-50 QueryStats, per query (brute-force accounting, wand.rs:472,500-503) */
+/* query/wand.rs:45-50 QueryStats, per query: brute-force accounting (wand.rs:472,500-503) of the
+ * work the device did — scored_docs = candidates_examined = distinct docs that got a score (under
+ * pruning: docs of the essential lists), postings_advanced = postings of the query's lists minus
+ * those block skipping never loaded.  Not the reference's wand_loop pivot counters. */
 typedef struct {
   uint64_t scored_docs;
   uint64_t candidates_examined;

@@ -1189,7 +1189,7 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     b->d_q_scored.alloc_pooled(&ix->pool, (size_t)nq * 4);
     // (from the pool like every per-batch buffer: a raw hipMalloc / hipFree per batch synchronises
     // the device and cost config 4's two-in-flight pipeline 60 %)
-    if (b->pruned && !b->uniform && tn.block_max) b->d_blk_skip.alloc_pooled(&ix->pool, 16);
+    if (b->pruned && !b->uniform && tn.block_max) b->d_blk_skip.alloc_pooled(&ix->pool, ((size_t)nq + 1) * 8);
     if (any_filter) {
       std::vector<uint32_t> qf(nq, 0u);
       for (uint32_t q = 0; q < nq; q++)
@@ -1249,7 +1249,7 @@ int slg_batch_run(slg_batch *b) {
       pp.nq = b->nq;
       pp.n_boundaries = b->n_boundaries;
       pp.n_slices = b->n_slices;
-      const uint64_t pthreads = std::max<uint64_t>(std::max<uint64_t>((uint64_t)b->n_boundaries * 8, b->nq), b->n_slices);
+      const uint64_t pthreads = std::max<uint64_t>(std::max<uint64_t>((uint64_t)b->n_boundaries * 8, (uint64_t)b->nq + 1), b->n_slices);
       hipLaunchKernelGGL(slg::partition_rounds_kernel, dim3((uint32_t)((pthreads + 255) / 256)),
                          dim3(256), 0, st, pp);
       SLG_HIP(hipGetLastError());
@@ -1356,6 +1356,7 @@ int slg_batch_fetch(slg_batch *b, uint32_t *out_doc, uint32_t *out_seg, float *o
     }
     const size_t n = (size_t)b->nq * b->k;
     std::vector<uint32_t> scored;
+    std::vector<unsigned long long> skipped;
     if (b->nq) {
       // the results are one contiguous block doc | seg | score | count: one D2H copy
       std::vector<uint32_t> blk(3 * n + b->nq);
@@ -1364,6 +1365,10 @@ int slg_batch_fetch(slg_batch *b, uint32_t *out_doc, uint32_t *out_seg, float *o
         scored.resize(b->nq);
         SLG_HIP(hipMemcpyAsync(scored.data(), b->d_q_scored.p, (size_t)b->nq * 4,
                                hipMemcpyDeviceToHost, st));
+        if (b->d_blk_skip.p && b->launched) {
+          skipped.resize((size_t)b->nq + 1);
+          SLG_HIP(hipMemcpyAsync(skipped.data(), b->d_blk_skip.p, skipped.size() * 8, hipMemcpyDeviceToHost, st));
+        }
       }
       SLG_HIP(hipStreamSynchronize(st));
       if (n) {
@@ -1375,8 +1380,9 @@ int slg_batch_fetch(slg_batch *b, uint32_t *out_doc, uint32_t *out_seg, float *o
     }
     if (stats)
       for (uint32_t q = 0; q < b->nq; q++) {
-        // brute-force accounting: wand.rs:472 (postings_advanced += len), :500-503
-        stats[q].postings_advanced = b->q_postings[q];
+        // brute-force accounting: wand.rs:472 (postings_advanced += len), :500-503; with block
+        // skipping, the postings that were never loaded are not counted as advanced over
+        stats[q].postings_advanced = b->q_postings[q] - (skipped.empty() ? 0ull : skipped[q + 1]);
         stats[q].scored_docs = scored[q];
         stats[q].candidates_examined = scored[q];
       }

@@ -38,7 +38,7 @@ struct RoundPartParams {
   uint32_t *bounds;
   uint32_t *rdoc;
   uint32_t *q_scored;  // [nq] zeroed here (saves a memset node per batch)
-  unsigned long long *skip_counts;  // [1] zeroed here, or null
+  unsigned long long *skip_counts;  // [1 + nq] zeroed here, or null
   const uint32_t *slice_sq;     // [n_slices]
   const uint32_t *slice_order;  // [n_slices] launch position -> slice
   SliceDesc *slice_desc;        // [n_slices] out, by launch position
@@ -51,7 +51,7 @@ struct RoundPartParams {
 static __global__ void __launch_bounds__(256) partition_rounds_kernel(RoundPartParams p) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid < p.nq) p.q_scored[gid] = 0;
-  if (gid == 0 && p.skip_counts) p.skip_counts[0] = 0ull;
+  if (gid <= p.nq && p.skip_counts) p.skip_counts[gid] = 0ull;
   if (gid < p.n_slices) {  // the slice record of launch position gid
     const uint32_t slice = p.slice_order[gid];
     const RoundQuery s = p.sq[p.slice_sq[slice]];
@@ -179,7 +179,8 @@ struct RoundScoreParams {
   // block skipping (many-term kernel with classified lists): 64-posting slots of non-essential
   // lists whose doc range holds no doc of an essential list are never loaded
   uint32_t block_skip;
-  unsigned long long *skip_counts;  // [1] postings of non-essential lists that were never loaded, or null
+  // postings of non-essential lists that were never loaded: [0] of the batch, [1 + q] of query q; or null
+  unsigned long long *skip_counts;
   unsigned long long *stamps;  // [n_slices * 8] (SLG_STAMPS builds only)
 };
 

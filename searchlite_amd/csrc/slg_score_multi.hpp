@@ -490,7 +490,10 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
     p.slice_ccnt[slice] = ccur;
   }
   if (p.q_scored && lane == 0 && n_scored) atomicAdd(&p.q_scored[s.q], n_scored);
-  if (p.skip_counts && lane == 0 && n_skipped) atomicAdd(&p.skip_counts[0], (unsigned long long)n_skipped);
+  if (p.skip_counts && lane == 0 && n_skipped) {
+    atomicAdd(&p.skip_counts[0], (unsigned long long)n_skipped);
+    atomicAdd(&p.skip_counts[1u + s.q], (unsigned long long)n_skipped);
+  }
 #ifdef SLG_STAMPS
   SLG_STAMP(6);
   if (p.stamps && lane == 0) {

@@ -115,9 +115,12 @@ def test_block_skipping_skewed_queries(gpu, oracle, tuning):
             for strat in (gpu.Wand, gpu.Bmw):
                 b = ix.prepare(offs, terms, w, k, strat)
                 b.run()
-                got = b.fetch()
+                got = b.fetch(want_stats=True)
                 probed, skipped = b.skip_counts()
+                info = b.info()
                 b.close()
+                # QueryStats: postings never loaded are not counted as advanced over
+                assert sum(got[4][q].postings_advanced for q in range(96)) == info["n_postings"] - skipped
                 assert_same_hits(got[:4], want, 0.0, f"skewed k={k} strategy {strat} tuning {tuning}")
                 if tuning and tuning.get("block_max") == 0:
                     assert (probed, skipped) == (0, 0)
