@@ -60,15 +60,144 @@ __device__ __forceinline__ float wave_sum_f(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(x, 63));
 }
 
-// One workgroup (4 waves) per query.  Each wave takes candidates c = wave, wave+4, ... four at
-// a time: the 4 rows' 16-byte lane loads are issued together (rows are >= 1 KiB apart: an HBM
-// row gather), then reduced in registers.
+// vector score + blend of candidate c (lane 0 stores): api/reader.rs:217-223, :240-246,
+// vectors/mod.rs:112-118, :128
+__device__ __forceinline__ void rerank_finish(const float sum, const bool have_row, const int32_t metric,
+                                              const float alpha, const float bm, float *s_blend,
+                                              float *s_vec, const uint32_t c, const bool store) {
+  float vs;
+  if (!have_row)
+    vs = metric == 0 ? -1.0f : -3.40282347e+38f;
+  else if (metric == 0)
+    vs = (sum != sum) ? 0.0f : sum;
+  else
+    vs = -sqrtf(sum);
+  if (store) {
+    float blended;
+    if (alpha >= 1.0f)
+      blended = bm;
+    else if (alpha <= 0.0f)
+      blended = vs;
+    else
+      blended = alpha * bm + (1.0f - alpha) * vs;
+    s_blend[c] = blended;
+    s_vec[c] = vs;
+  }
+}
+
+// Whole-row scan for dim <= 256 * CH, dim % 4 == 0 (config 5: 768 = 3 chunks).  A wave takes 4
+// candidates at a time and issues ALL 16-byte lane loads of their 4 rows at once (4 x 3 KiB
+// contiguous: whole DRAM pages instead of 1 KiB pieces of 8 rows, and no load -> FMA -> load
+// round trips inside a row); the query vector stays in registers; the next group's row pointers
+// (candidate -> segment -> offsets[doc], a chain of dependent scalar loads) are resolved while
+// this group's rows are in flight.
+template <int CH>
+__device__ __forceinline__ void rerank_scan_rows(const RerankParams &p, const uint32_t q, const uint32_t n,
+                                                 const float alpha, float *s_blend, float *s_vec,
+                                                 const uint32_t lane, const uint32_t wave) {
+  constexpr int U = 4;
+  const uint32_t dim = p.dim;
+  const float *__restrict__ qv = p.qvecs + (size_t)q * dim;
+  const uint32_t *__restrict__ cdoc = p.cand_doc + (size_t)q * p.max_cand;
+  const uint32_t *__restrict__ cseg = p.cand_seg + (size_t)q * p.max_cand;
+  const float *__restrict__ cbm = p.cand_bm25 + (size_t)q * p.max_cand;
+  // lane's piece of chunk ch: floats idx[ch] .. idx[ch]+3 of a row (lanes past the row's end
+  // re-read its first floats and are masked out)
+  typedef float fvec4 __attribute__((ext_vector_type(4)));
+  fvec4 a[CH];
+  uint32_t idx[CH];
+  bool valid[CH];
+#pragma unroll
+  for (int ch = 0; ch < CH; ch++) {
+    const uint32_t i = ch * 256 + lane * 4;
+    valid[ch] = i < dim;
+    idx[ch] = valid[ch] ? i : 0u;
+    const fvec4 v = *reinterpret_cast<const fvec4 *>(qv + idx[ch]);
+    a[ch] = valid[ch] ? v : (fvec4){0.f, 0.f, 0.f, 0.f};
+  }
+  // candidate -> row pointer, branch-free on the scalar unit (every index is clamped to something
+  // readable; a candidate without a vector reads the query vector and its sum is discarded)
+  // (pointers read from memory are generic: cast to the global address space, or the row loads
+  // become flat_load and their waits couple with the scalar chain's)
+  typedef const __attribute__((address_space(1))) fvec4 *grow_t;
+  typedef const __attribute__((address_space(1))) uint32_t *gword_t;
+  grow_t rowN[U];
+  bool haveN[U];
+  int32_t metN[U];
+  float bmN[U];
+  auto resolve = [&](const uint32_t c0) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const uint32_t c = c0 + u;
+      const bool c_ok = c < n;
+      const uint32_t cc = c_ok ? c : 0u;
+      const uint32_t doc = cdoc[cc], seg = cseg[cc];
+      bmN[u] = cbm[cc];
+      const bool seg_ok = seg < p.n_segs;
+      const VecSegDev vd = p.vsegs[seg_ok ? seg : 0u];
+      const bool doc_ok = c_ok && seg_ok && vd.dim == dim && doc < vd.n_docs;
+      const gword_t optr = doc_ok ? (gword_t)(vd.offsets + doc) : (gword_t)p.cand_count;  // (any readable word)
+      const uint32_t off = *optr;
+      haveN[u] = doc_ok && off != 0xFFFFFFFFu;
+      metN[u] = seg_ok ? vd.metric : 0;
+      rowN[u] = (grow_t)(haveN[u] ? vd.values + (size_t)off * dim : qv);
+    }
+  };
+  resolve(wave * U);
+  for (uint32_t c0 = wave * U; c0 < n; c0 += 4 * U) {
+    grow_t row[U];
+    bool have[U];
+    int32_t met[U];
+    float bm[U];
+    fvec4 b[U][CH];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      row[u] = rowN[u];
+      have[u] = haveN[u];
+      met[u] = metN[u];
+      bm[u] = bmN[u];
+#pragma unroll
+      for (int ch = 0; ch < CH; ch++) b[u][ch] = row[u][idx[ch] >> 2];
+    }
+    if (c0 + 4 * U < n) resolve(c0 + 4 * U);  // the next group's pointers, under this group's rows
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int ch = 0; ch < CH; ch++) {
+        const fvec4 bb = valid[ch] ? b[u][ch] : a[ch];  // masked lanes: a = 0 and a - a = 0
+        if (met[u] == 0) {
+          acc += a[ch].x * bb.x;
+          acc += a[ch].y * bb.y;
+          acc += a[ch].z * bb.z;
+          acc += a[ch].w * bb.w;
+        } else {
+          const float d0 = a[ch].x - bb.x, d1 = a[ch].y - bb.y, d2 = a[ch].z - bb.z, d3 = a[ch].w - bb.w;
+          acc += d0 * d0;
+          acc += d1 * d1;
+          acc += d2 * d2;
+          acc += d3 * d3;
+        }
+      }
+      const uint32_t c = c0 + u;
+      const float sum = wave_sum_f(acc);
+      rerank_finish(sum, have[u], met[u], alpha, bm[u], s_blend, s_vec, c, lane == 0 && c < n);
+    }
+  }
+}
+
+// One workgroup (4 waves) per query.  dim <= 768 and a multiple of 4: rerank_scan_rows (whole
+// rows, 4 candidates per wave and step).  Other dims: 8 candidates per wave and step, 256 floats
+// of each row at a time.
 template <int KREGS>
 __global__ void __launch_bounds__(256) rerank_kernel(RerankParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *s_blend = reinterpret_cast<float *>(smem);
   float *s_vec = s_blend + p.max_cand;
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t lane = threadIdx.x & 63;
+  // (a scalar: candidate indices derived from it are wave-uniform, so the candidate -> row pointer
+  // chain runs on the scalar unit and row pointers live in SGPRs)
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t q = blockIdx.x;
   uint32_t n = p.cand_count[q];
   n = n < p.max_cand ? n : p.max_cand;
@@ -79,8 +208,16 @@ __global__ void __launch_bounds__(256) rerank_kernel(RerankParams p) {
   const uint32_t *cseg = p.cand_seg + (size_t)q * p.max_cand;
   const float *cbm = p.cand_bm25 + (size_t)q * p.max_cand;
   constexpr int U = 8;
-
-  for (uint32_t c0 = wave * U; c0 < n; c0 += 4 * U) {
+  const bool whole_rows = (dim & 3u) == 0 && dim <= 768u;
+  if (whole_rows) {
+    if (dim <= 256u)
+      rerank_scan_rows<1>(p, q, n, alpha, s_blend, s_vec, lane, wave);
+    else if (dim <= 512u)
+      rerank_scan_rows<2>(p, q, n, alpha, s_blend, s_vec, lane, wave);
+    else
+      rerank_scan_rows<3>(p, q, n, alpha, s_blend, s_vec, lane, wave);
+  }
+  for (uint32_t c0 = whole_rows ? n : wave * U; c0 < n; c0 += 4 * U) {
     const float *row[U];
     int32_t metric[U];
     float acc[U];
