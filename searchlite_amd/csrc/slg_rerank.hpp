@@ -425,19 +425,45 @@ __global__ void __launch_bounds__(256) rerank_multi_kernel(RerankMultiParams mp)
   };
 
   if (metric == 0 && (dim & 15u) == 0) {
-    // ---- cosine on the matrix cores: tiles of 16 candidates, round-robin over the 4 waves ----
+    // ---- cosine on the matrix cores: tiles of 16 candidates, round-robin over the 4 waves.
+    //      Row loads go through global-address-space pointers (a pointer read from memory is
+    //      generic: flat loads would share the LDS counter with the clause-vector reads), a
+    //      candidate without a vector reads the query (its products are never used), four
+    //      16-byte pieces per lane are in flight, and the next tile's row pointers (a chain of
+    //      three dependent loads) are fetched under this tile's rows ----
+    typedef const __attribute__((address_space(1))) f32x4_t *grow_t;
     const uint32_t g = lane >> 4, cl = lane & 15u;
+    const f32x4_t *qrow = reinterpret_cast<const f32x4_t *>(s_q + (cl < NC ? cl : 0u) * qs);
+    const float *dummy = p.qvecs + (size_t)q * NC * dim;
+    const float *nrow = row_of(wave * 16 + cl);
     for (uint32_t t0 = wave * 16; t0 < n; t0 += 64) {
-      const float *row = row_of(t0 + cl);
-      const float *qrow = cl < NC ? s_q + cl * qs : nullptr;
+      const grow_t row = (grow_t)(nrow ? nrow : dummy);
       f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
-      for (uint32_t kb = 4 * g; kb < dim; kb += 16) {
-        const float4 a = row ? *reinterpret_cast<const float4 *>(row + kb) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 b = qrow ? *reinterpret_cast<const float4 *>(qrow + kb) : make_float4(0.f, 0.f, 0.f, 0.f);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+      uint32_t kb = g;  // in units of 4 floats; lane g takes pieces g, g + 4, ...
+      const uint32_t kend = dim >> 2;
+      f32x4_t a0 = row[kb], a1 = a0, a2 = a0, a3 = a0;
+      if (kb + 4 < kend) a1 = row[kb + 4];
+      if (kb + 8 < kend) a2 = row[kb + 8];
+      if (kb + 12 < kend) a3 = row[kb + 12];
+      if (t0 + 64 < n) nrow = row_of(t0 + 64 + cl);
+      for (; kb < kend; kb += 16) {
+        const f32x4_t c0 = a0, c1 = a1, c2 = a2, c3 = a3;
+        const uint32_t nk = kb + 16;
+        if (nk < kend) a0 = row[nk];  // (uniform conditions: dim is a multiple of 16)
+        if (nk + 4 < kend) a1 = row[nk + 4];
+        if (nk + 8 < kend) a2 = row[nk + 8];
+        if (nk + 12 < kend) a3 = row[nk + 12];
+        auto step = [&](const f32x4_t a, const uint32_t at) {
+          const f32x4_t b = qrow[at];
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+        };
+        step(c0, kb);
+        if (kb + 4 < kend) step(c1, kb + 4);
+        if (kb + 8 < kend) step(c2, kb + 8);
+        if (kb + 12 < kend) step(c3, kb + 12);
       }
       if (cl < NC) {  // lane holds D[candidate t0 + 4g + r][clause cl]
 #pragma unroll
@@ -449,14 +475,40 @@ __global__ void __launch_bounds__(256) rerank_multi_kernel(RerankMultiParams mp)
       }
     }
   } else {
-    // ---- VALU path: one candidate per wave at a time, every clause against the same row ----
+    // ---- VALU path: one candidate per wave at a time; its row is read ONCE into registers
+    //      (dim <= 1024) and every clause runs against it ----
+    typedef const __attribute__((address_space(1))) float *gf_t;
+    constexpr int RV = 16;
     for (uint32_t c = wave; c < n; c += 4) {
       const float *row = row_of(c);
+      float rv[RV];
+      const bool cached = dim <= 64u * RV;
+      if (row && cached) {
+#pragma unroll
+        for (int j = 0; j < RV; j++) {
+          const uint32_t i = lane + 64u * j;
+          rv[j] = i < dim ? ((gf_t)row)[i] : 0.0f;
+        }
+      }
       for (uint32_t cc = 0; cc < NC; cc++) {
         float acc = 0.0f;
-        if (row)
+        if (row && cached) {
+#pragma unroll
+          for (int j = 0; j < RV; j++) {
+            const uint32_t i = lane + 64u * j;
+            if (64u * j < dim) {  // uniform
+              const float a = i < dim ? s_q[cc * qs + i] : 0.0f;
+              if (metric == 0) {
+                acc += a * rv[j];
+              } else {
+                const float d = i < dim ? a - rv[j] : 0.0f;
+                acc += d * d;
+              }
+            }
+          }
+        } else if (row) {
           for (uint32_t i = lane; i < dim; i += 64) {
-            const float a = s_q[cc * qs + i], bb = row[i];
+            const float a = s_q[cc * qs + i], bb = ((gf_t)row)[i];
             if (metric == 0) {
               acc += a * bb;
             } else {
@@ -464,6 +516,7 @@ __global__ void __launch_bounds__(256) rerank_multi_kernel(RerankMultiParams mp)
               acc += d * d;
             }
           }
+        }
         const float sum = wave_sum_f(acc);
         if (lane == 0) s_vs[cc * p.max_cand + c] = metric == 0 ? (sum != sum ? 0.0f : sum) : -sqrtf(sum);
       }
