@@ -52,7 +52,11 @@ def test_rerank_golden(metric, name):
     _check(got, z[f"exp_doc_{name}"], z[f"exp_score_{name}"], z[f"exp_vec_{name}"], name)
 
 
-@pytest.mark.parametrize("dim,ncand,k_out", [(768, 1001, 10), (100, 300, 70), (6, 40, 40)])
+@pytest.mark.parametrize("dim,ncand,k_out", [(768, 1001, 10), (100, 300, 70), (6, 40, 40),
+                                             # whole-row paths of 1 / 2 / 3 chunks with a ragged last chunk,
+                                             # and the piecewise path (dim > 768, dim % 4 != 0)
+                                             (256, 200, 10), (260, 200, 10), (384, 500, 20), (516, 200, 10),
+                                             (1000, 200, 10), (1030, 100, 10)])
 def test_rerank_random(oracle, dim, ncand, k_out):
     """config 5 shape: BM25 top-1000 -> cosine rerank -> top-10 (dim 768)."""
     import searchlite_amd as sa
@@ -82,6 +86,42 @@ def test_rerank_random(oracle, dim, ncand, k_out):
             ws.append(s_)
             wv.append(v_)
         _check(got, wd, ws, wv, f"metric {metric} dim {dim}")
+
+
+def test_rerank_candidates_from_two_segments(oracle):
+    """Candidates of one query come from several segments (api/reader.rs:2670-2778 merges them before
+    the hybrid score): each row is fetched from its own segment's store; ties break by
+    (segment, doc)."""
+    import searchlite_amd as sa
+    from searchlite_amd import corpus
+    rng = np.random.default_rng(5)
+    n, dim, ncand, k_out, nq = 1500, 384, 300, 25, 3
+    stores, offs = [], []
+    for sgi in range(2):
+        stores.append(corpus.unit_vectors(n, dim, seed=41 + sgi))
+        o = np.arange(n, dtype=np.uint32)
+        o[rng.choice(n, size=100, replace=False)] = 0xFFFFFFFF
+        offs.append(o)
+    segs = [_segment_with_vectors(n, offs[i], stores[i], 0) for i in range(2)]
+    q = corpus.unit_vectors(nq, dim, seed=43)
+    cseg = rng.integers(0, 2, size=(nq, ncand)).astype(np.uint32)
+    cdoc = np.stack([rng.choice(n, size=ncand, replace=False) for _ in range(nq)]).astype(np.uint32)
+    bm = (rng.random((nq, ncand)) * 5).astype(np.float32)
+    bm[:, :40] = 1.0  # ties in the text score
+    cnt = np.full(nq, ncand, np.uint32)
+    alpha = np.array([0.5, 1.0, 0.3], np.float32)
+    with sa.GpuIndex(segs) as ix:
+        got = ix.rerank_batch(q, alpha, cdoc, cseg, bm, cnt, k_out)
+    # the oracle on ONE store holding both segments: combined id = seg * n + doc (same tie order)
+    comb_vals = np.concatenate(stores)
+    comb_offs = np.concatenate([offs[0], np.where(offs[1] == 0xFFFFFFFF, 0xFFFFFFFF, offs[1] + n)]).astype(np.uint32)
+    for i in range(nq):
+        d_, s_, v_ = oracle.rerank(0, comb_offs, comb_vals, q[i], float(alpha[i]),
+                                   (cseg[i] * n + cdoc[i]).astype(np.uint32), bm[i], k_out)
+        gd, gs, gsc, gv, gc = got
+        assert gc[i] == len(d_)
+        assert np.abs(gsc[i, :len(d_)] - s_).max() <= TOL
+        assert list(gs[i, :len(d_)].astype(np.int64) * n + gd[i, :len(d_)]) == list(d_), f"query {i}"
 
 
 def test_hybrid_blends_text_and_vector_gpu(oracle):
@@ -146,6 +186,43 @@ def test_rerank_multi_clause(oracle, n_clauses, metric):
                 _check(got, wd, ws, wv, f"{n_clauses} clauses metric {metric} boost {bst is not None}")
             finally:
                 TOL = tol_save
+
+
+@pytest.mark.parametrize("dim", [16, 48, 100, 400, 1100])
+@pytest.mark.parametrize("metric", [0, 1])
+def test_rerank_multi_clause_dims(oracle, dim, metric):
+    """The multi-clause kernel's three paths: matrix cores (cosine, dim % 16 == 0: 16, 48, 400),
+    rows cached in registers (dim <= 1024 otherwise) and the streaming loop (dim > 1024)."""
+    import searchlite_amd as sa
+    from searchlite_amd import corpus
+    rng = np.random.default_rng(7 * dim + metric)
+    n, ncand, k_out, nq, nc = 3000, 257, 12, 4, 3
+    vals = corpus.unit_vectors(n, dim, seed=31)
+    offsets = np.arange(n, dtype=np.uint32)
+    offsets[rng.choice(n, size=200, replace=False)] = 0xFFFFFFFF
+    q = corpus.unit_vectors(nq * nc, dim, seed=32).reshape(nq, nc, dim)
+    cand = np.stack([rng.choice(n, size=ncand, replace=False) for _ in range(nq)]).astype(np.uint32)
+    bm = (rng.random((nq, ncand)) * 20).astype(np.float32)
+    cnt = np.array([ncand, 100, 17, ncand], np.uint32)
+    alpha = rng.choice(np.array([0.0, 0.3, 0.5, 1.0], np.float32), size=(nq, nc))
+    boost = (rng.random((nq, nc)) + 0.5).astype(np.float32)
+    seg = _segment_with_vectors(n, offsets, vals, metric)
+    with sa.GpuIndex([seg]) as ix:
+        got = ix.rerank_multi_batch(q, alpha, cand, np.zeros_like(cand), bm, cnt, k_out, boost=boost)
+    wd, ws, wv = [], [], []
+    for i in range(nq):
+        d_, s_, v_ = oracle.rerank_multi(metric, offsets, vals, q[i], alpha[i], cand[i, :cnt[i]],
+                                         bm[i, :cnt[i]], k_out, boost=boost[i])
+        wd.append(d_)
+        ws.append(s_)
+        wv.append(v_)
+    global TOL
+    tol_save = TOL
+    TOL = 2e-5
+    try:
+        _check(got, wd, ws, wv, f"dim {dim} metric {metric}")
+    finally:
+        TOL = tol_save
 
 
 def test_rerank_multi_matches_single_clause_kernel():
