@@ -96,6 +96,7 @@ __device__ __forceinline__ void rerank_scan_rows(const RerankParams &p, const ui
                                                  const float alpha, float *s_blend, float *s_vec,
                                                  const uint32_t lane, const uint32_t wave) {
   constexpr int U = 4;
+  if (n == 0) return;  // (the clamped loads below read candidate 0)
   const uint32_t dim = p.dim;
   const float *__restrict__ qv = p.qvecs + (size_t)q * dim;
   const uint32_t *__restrict__ cdoc = p.cand_doc + (size_t)q * p.max_cand;

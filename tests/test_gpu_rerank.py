@@ -88,6 +88,25 @@ def test_rerank_random(oracle, dim, ncand, k_out):
         _check(got, wd, ws, wv, f"metric {metric} dim {dim}")
 
 
+def test_rerank_query_without_candidates(oracle):
+    """A query whose text pass found nothing (cand_count 0) beside one that found 5."""
+    import searchlite_amd as sa
+    from searchlite_amd import corpus
+    n, dim = 200, 768
+    vals = corpus.unit_vectors(n, dim, seed=51)
+    seg = _segment_with_vectors(n, np.arange(n, dtype=np.uint32), vals, 0)
+    q = corpus.unit_vectors(2, dim, seed=52)
+    cand = np.array([[0, 0, 0, 0, 0], [3, 9, 27, 81, 150]], np.uint32)
+    bm = np.ones((2, 5), np.float32)
+    with sa.GpuIndex([seg]) as ix:
+        gd, gs, gsc, gv, gc = ix.rerank_batch(q, 0.5, cand, np.zeros_like(cand), bm, np.array([0, 5], np.uint32), 3)
+        md, ms, msc, mv, mc = ix.rerank_multi_batch(q.reshape(2, 1, dim), 0.5, cand, np.zeros_like(cand), bm,
+                                                     np.array([0, 5], np.uint32), 3, boost=np.full((2, 1), 2.0, np.float32))
+    assert list(gc) == [0, 3] and list(mc) == [0, 3]
+    d_, s_, v_ = oracle.rerank(0, np.arange(n, dtype=np.uint32), vals, q[1], 0.5, cand[1], bm[1], 3)
+    assert list(gd[1]) == list(d_) and np.abs(gsc[1] - s_).max() <= TOL
+
+
 def test_rerank_candidates_from_two_segments(oracle):
     """Candidates of one query come from several segments (api/reader.rs:2670-2778 merges them before
     the hybrid score): each row is fetched from its own segment's store; ties break by

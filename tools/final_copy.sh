@@ -11,3 +11,7 @@ for c in c2 c3; do
   cp $G/prof_${TAG}_$c/traffic.json profiles/traffic_$c.json
 done
 tail -2 $G/final/pytest_gpu.log > profiles/${TAG}_pytest_gpu_tail.txt
+grep -v amdgpu.ids $G/final/skewed_queries.txt > profiles/${TAG}_skewed_queries.txt
+grep -v amdgpu.ids $G/final/rerank_multi.txt > profiles/${TAG}_rerank_multi.txt
+cp $G/prof_${TAG}_c5/trace/run_kernel_stats.csv profiles/${TAG}_c5_kernel_stats.csv
+python3 tools/pmc_avg.py $G/prof_${TAG}_c5 rerank_kernel > profiles/${TAG}_c5_rerank_pmc.txt

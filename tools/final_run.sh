@@ -17,5 +17,8 @@ python bench.py --steps 20 --warmup 5 > $OUT/bench_c2_steps20.json 2>/dev/null
 for c in c3 c4 c5; do
   python bench.py --config $c --steps 12 --warmup 3 > $OUT/bench_$c.json 2> $OUT/bench_$c.err && tail -1 $OUT/bench_$c.json | cut -c1-160
 done
+python tools/skewed_queries.py > $OUT/skewed_queries.txt 2>&1 && tail -3 $OUT/skewed_queries.txt
+python tools/rerank_multi_time.py > $OUT/rerank_multi.txt 2>&1 && tail -10 $OUT/rerank_multi.txt
 bash tools/profile.sh ${TAG}_c2 c2 > $OUT/profile_c2.log 2>&1 && echo "profile c2 done"
 bash tools/profile.sh ${TAG}_c3 c3 > $OUT/profile_c3.log 2>&1 && echo "profile c3 done"
+bash tools/profile.sh ${TAG}_c5 c5 > $OUT/profile_c5.log 2>&1 && echo "profile c5 done"
