@@ -712,7 +712,7 @@ struct SelectParams {
 };
 
 constexpr uint32_t kSelectCap = 2048;      // keys sorted in LDS at a time (a rank range of the result)
-constexpr uint32_t kSelectMaxSlices = 1024;  // slice table in LDS; more: strided slice loops
+constexpr uint32_t kSelectMaxSlices = 512;   // slice table in LDS; more: strided slice loops (34 KB of LDS per workgroup: 4 per CU)
 constexpr uint32_t kSelectThreads = 512;
 
 static __global__ void __launch_bounds__(kSelectThreads) select_topk_kernel(SelectParams p) {
