@@ -341,6 +341,42 @@ int slg_rerank_batch_device(slg_index *index, uint32_t nq, const float *d_qvecs,
  * matrix cores (v_mfma_f32_16x16x4_f32).  n_clauses * (dim + 4 + max_cand) + 2 * max_cand floats
  * must fit the kernel's LDS budget (36 Ki floats), else SLG_ERR_UNSUPPORTED.
  */
+/*
+ * Vector fields beyond the one in slg_segment_desc (vectors/mod.rs:10-17: one VectorStore per
+ * vector field).  Field 0 is the store of the segment descriptors; every call stages one more
+ * field — one descriptor per segment of the index, vec_dim 0 where the segment has no vectors in
+ * it — and returns its id (>= 1), or a negative error code.
+ */
+typedef struct {
+  uint32_t vec_dim;            /* 0 => this segment has no vectors in the field */
+  int32_t vec_metric;          /* SLG_METRIC_* */
+  const uint32_t *vec_offsets; /* [n_docs] row index or SLG_NO_VECTOR */
+  const float *vec_values;     /* [vec_rows * vec_dim] row-major */
+  uint32_t vec_rows;
+} slg_vector_field_desc;
+int slg_index_add_vector_field(slg_index *index, const slg_vector_field_desc *per_segment, uint32_t n_segs);
+
+/*
+ * Hybrid rerank whose clauses name different vector fields (api/reader.rs:225-254: every clause has
+ * its own field, metric and dimension).  clause_field[c] = field id of clause c (host array);
+ * qvecs[q] = the clause vectors of query q one after another (sum of the clause dimensions
+ * floats); alpha / boost [nq][n_clauses] as in slg_rerank_multi_batch.  A candidate without a
+ * vector in clause c's field takes that clause's missing-vector score (-1.0 / f32::MIN by the
+ * clause's metric); out_vec_score sums the clauses that found one.
+ */
+int slg_rerank_fields_batch(slg_index *index, uint32_t nq, uint32_t n_clauses, const uint32_t *clause_field,
+                            const float *qvecs, const float *alpha, const float *boost,
+                            const uint32_t *cand_doc, const uint32_t *cand_seg, const float *cand_bm25,
+                            const uint32_t *cand_count, uint32_t max_cand, uint32_t k_out, uint32_t *out_doc,
+                            uint32_t *out_seg, float *out_score, float *out_vec_score, uint32_t *out_count);
+int slg_rerank_fields_batch_device(slg_index *index, uint32_t nq, uint32_t n_clauses,
+                                   const uint32_t *clause_field, const float *d_qvecs, const float *d_alpha,
+                                   const float *d_boost, const uint32_t *d_cand_doc,
+                                   const uint32_t *d_cand_seg, const float *d_cand_bm25,
+                                   const uint32_t *d_cand_count, uint32_t max_cand, uint32_t k_out,
+                                   uint32_t *d_out_doc, uint32_t *d_out_seg, float *d_out_score,
+                                   float *d_out_vec_score, uint32_t *d_out_count);
+
 int slg_rerank_multi_batch(slg_index *index, uint32_t nq, uint32_t n_clauses, const float *qvecs,
                            const float *alpha, const float *boost, const uint32_t *cand_doc,
                            const uint32_t *cand_seg, const float *cand_bm25, const uint32_t *cand_count,

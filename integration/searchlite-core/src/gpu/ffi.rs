@@ -27,6 +27,9 @@ pub struct slg_tuning {
     pub probe_target: u32, pub rounds_per_slice: u32, pub max_rounds_per_slice: u32,
     pub slices_per_subquery: u32, pub cand_mode: i32, pub slice_order: i32, pub block_max: i32,
 }
+#[repr(C)] pub struct slg_vector_field_desc {
+    pub vec_dim: u32, pub vec_metric: i32, pub vec_offsets: *const u32, pub vec_values: *const c_float, pub vec_rows: u32,
+}
 #[repr(C)] pub struct slg_stats { pub scored_docs: u64, pub candidates_examined: u64, pub postings_advanced: u64 }
 #[repr(C)] pub struct slg_query { pub n_terms: u32, pub term_ids: *const u32, pub weights: *const c_float }
 
@@ -91,6 +94,16 @@ extern "C" {
         d_cand_doc: *const u32, d_cand_seg: *const u32, d_cand_bm25: *const c_float, d_cand_count: *const u32,
         max_cand: u32, k_out: u32, d_out_doc: *mut u32, d_out_seg: *mut u32, d_out_score: *mut c_float,
         d_out_vec_score: *mut c_float, d_out_count: *mut u32) -> c_int;
+    pub fn slg_index_add_vector_field(index: *mut slg_index, per_segment: *const slg_vector_field_desc, n_segs: u32) -> c_int;
+    pub fn slg_rerank_fields_batch(index: *mut slg_index, nq: u32, n_clauses: u32, clause_field: *const u32,
+        qvecs: *const c_float, alpha: *const c_float, boost: *const c_float, cand_doc: *const u32, cand_seg: *const u32,
+        cand_bm25: *const c_float, cand_count: *const u32, max_cand: u32, k_out: u32, out_doc: *mut u32,
+        out_seg: *mut u32, out_score: *mut c_float, out_vec_score: *mut c_float, out_count: *mut u32) -> c_int;
+    pub fn slg_rerank_fields_batch_device(index: *mut slg_index, nq: u32, n_clauses: u32, clause_field: *const u32,
+        d_qvecs: *const c_float, d_alpha: *const c_float, d_boost: *const c_float, d_cand_doc: *const u32,
+        d_cand_seg: *const u32, d_cand_bm25: *const c_float, d_cand_count: *const u32, max_cand: u32, k_out: u32,
+        d_out_doc: *mut u32, d_out_seg: *mut u32, d_out_score: *mut c_float, d_out_vec_score: *mut c_float,
+        d_out_count: *mut u32) -> c_int;
     pub fn slg_rerank_multi_batch(index: *mut slg_index, nq: u32, n_clauses: u32, qvecs: *const c_float,
         alpha: *const c_float, boost: *const c_float, cand_doc: *const u32, cand_seg: *const u32,
         cand_bm25: *const c_float, cand_count: *const u32, max_cand: u32, k_out: u32, out_doc: *mut u32,

@@ -317,6 +317,50 @@ def rerank_multi(metric, vec_offsets, vec_values, qvecs, alpha, cand_doc, cand_b
     return out_doc[:n].copy(), out_score[:n].copy(), out_vec[:n].copy()
 
 
+def rerank_fields(fields, clause_field, qvecs, alpha, cand_doc, cand_bm25, k_out, boost=None):
+    """compute_hybrid_score (api/reader.rs:225-254) when the clauses name different vector fields
+    (one segment).  fields: list of (metric, vec_offsets, vec_values); clause_field[c] indexes it;
+    qvecs: list of the clause vectors.  Numpy restatement (small cases): similarities are f32 sums
+    taken left to right (vectors/mod.rs:107-120: cosine = dot of the stored vectors, NaN -> 0;
+    L2 = -sqrt(sum (x - y)^2)); a clause whose field has no vector for the doc takes
+    missing_vector_score of ITS metric (:217-223); blended = mean over the clauses (:240-251);
+    the vector score sums the clauses that found a vector (:236-238), and is the missing score of
+    clause 0 when none did (what the single-field oracle reports).  Order: blended desc, doc asc."""
+    f32 = np.float32
+    nc = len(clause_field)
+    alpha = np.asarray(alpha, dtype=f32)
+    bst = np.ones(nc, f32) if boost is None else np.asarray(boost, dtype=f32)
+    rows = []
+    for d, bm in zip(np.asarray(cand_doc, dtype=np.uint32), np.asarray(cand_bm25, dtype=f32)):
+        blended_sum, vector_sum, has = f32(0), f32(0), False
+        for c in range(nc):
+            metric, offs, vals = fields[clause_field[c]]
+            miss = f32(-1.0) if metric == 0 else f32(-3.40282347e+38)
+            off = offs[d] if d < len(offs) else 0xFFFFFFFF
+            if off == 0xFFFFFFFF:
+                vs = miss
+            else:
+                x, y = np.asarray(vals[off], dtype=f32), np.asarray(qvecs[c], dtype=f32)
+                if metric == 0:
+                    sm = np.add.accumulate((y * x).astype(f32), dtype=f32)[-1]
+                    sim = f32(0) if np.isnan(sm) else sm
+                else:
+                    diff = (y - x).astype(f32)
+                    sim = -np.sqrt(np.add.accumulate((diff * diff).astype(f32), dtype=f32)[-1], dtype=f32)
+                vs = f32(sim * bst[c])
+                vector_sum = f32(vector_sum + vs)
+                has = True
+            a = alpha[c]
+            blended = bm if a >= 1.0 else (vs if a <= 0.0 else f32(f32(a * bm) + f32(f32(f32(1.0) - a) * vs)))
+            blended_sum = f32(blended_sum + blended)
+        m0 = f32(-1.0) if fields[clause_field[0]][0] == 0 else f32(-3.40282347e+38)
+        rows.append((f32(blended_sum / f32(nc)), int(d), vector_sum if has else m0))
+    rows.sort(key=lambda r: (-float(r[0]), r[1]))
+    rows = rows[:k_out]
+    return (np.array([r[1] for r in rows], np.uint32), np.array([r[0] for r in rows], f32),
+            np.array([r[2] for r in rows], f32))
+
+
 def search_batch_faithful(segments, q_offsets, q_terms, q_weights, k, strategy=WAND, n_threads=1):
     """BASELINE.md "Baseline A": scorer + the reference's per-query posting decode (twice) and
     doc-length rebuild.  -> ((doc, seg, score, count), seconds of the query phase)."""

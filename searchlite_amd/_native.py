@@ -42,6 +42,11 @@ class SegmentDesc(C.Structure):
                 ("vec_rows", C.c_uint32)]
 
 
+class VectorFieldDesc(C.Structure):
+    _fields_ = [("vec_dim", C.c_uint32), ("vec_metric", C.c_int32), ("vec_offsets", C.c_void_p),
+                ("vec_values", C.c_void_p), ("vec_rows", C.c_uint32)]
+
+
 class Stats(C.Structure):
     _fields_ = [("scored_docs", C.c_uint64), ("candidates_examined", C.c_uint64),
                 ("postings_advanced", C.c_uint64)]
@@ -136,6 +141,11 @@ def load():
                                          vp, vp]),
         "slg_rerank_multi_batch_device": (i32, [vp, u32, u32, vp, vp, vp, vp, vp, vp, vp, u32, u32, vp,
                                                 vp, vp, vp, vp]),
+        "slg_index_add_vector_field": (i32, [vp, vp, u32]),
+        "slg_rerank_fields_batch": (i32, [vp, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp,
+                                          vp, vp]),
+        "slg_rerank_fields_batch_device": (i32, [vp, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, vp,
+                                                 vp, vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)  # AttributeError if the symbol is not exported

@@ -188,6 +188,14 @@ struct SegHost {
   DevBuf d_vec_offsets, d_vec_values;
 };
 
+// a vector field beyond the one in the segment descriptors (slg_index_add_vector_field)
+struct VecFieldHost {
+  uint32_t dim = 0;
+  int32_t metric = 0;
+  std::vector<DevBuf> offsets, values;  // per segment (empty buffers: no vectors there)
+  DevBuf d_vsegs;                       // slg::VecSegDev[n_segs]
+};
+
 }  // namespace
 
 struct slg_index {
@@ -200,6 +208,7 @@ struct slg_index {
   std::vector<std::unique_ptr<SegHost>> segs;
   DevBuf d_segs;  // slg::SegDev[n_segs]
   DevBuf d_vsegs; // slg::VecSegDev[n_segs]
+  std::vector<std::unique_ptr<VecFieldHost>> vfields;  // field id f >= 1 is vfields[f - 1] (under mu)
   uint64_t device_bytes = 0;
   std::mutex mu;
   // doc filters (slg_index_add_filter*): per filter and segment a reject bitmap (deleted | ~filter)
@@ -645,6 +654,7 @@ void slg_index_destroy(slg_index *ix) {
     (void)hipEventDestroy(pr.second);
   }
   ix->segs.clear();
+  ix->vfields.clear();
   ix->d_segs.release();
   ix->d_vsegs.release();
   if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
@@ -1684,6 +1694,202 @@ int slg_rerank_multi_batch_device(slg_index *ix, uint32_t nq, uint32_t n_clauses
     mp.n_clauses = n_clauses;
     mp.q_stride = dim + 4;
     SLG_HIP(slg::launch_rerank_multi(mp, kregs_for(k_out ? k_out : 1), ix->stream));
+  });
+}
+
+int slg_index_add_vector_field(slg_index *ix, const slg_vector_field_desc *per_segment, uint32_t n_segs) {
+  int id = 0;
+  const int rc = guarded([&] {
+    SLG_REQUIRE(ix != nullptr && per_segment != nullptr, "index or descriptors are NULL");
+    SLG_REQUIRE(n_segs == ix->segs.size(), "one descriptor per segment of the index is required");
+    auto vf = std::make_unique<VecFieldHost>();
+    for (uint32_t s = 0; s < n_segs; s++) {
+      const slg_vector_field_desc &d = per_segment[s];
+      if (!d.vec_dim) continue;
+      SLG_REQUIRE(d.vec_offsets != nullptr && (d.vec_rows == 0 || d.vec_values != nullptr), "vector arrays are NULL");
+      SLG_REQUIRE(d.vec_metric == SLG_METRIC_COSINE || d.vec_metric == SLG_METRIC_L2, "unknown vector metric");
+      SLG_REQUIRE(vf->dim == 0 || (vf->dim == d.vec_dim && vf->metric == d.vec_metric),
+                  "segments disagree on the field's dimension or metric");
+      vf->dim = d.vec_dim;
+      vf->metric = d.vec_metric;
+      const uint32_t nd = ix->segs[s]->n_docs;
+      for (uint32_t i = 0; i < nd; i++)
+        SLG_REQUIRE(d.vec_offsets[i] == SLG_NO_VECTOR || d.vec_offsets[i] < d.vec_rows, "vector offset past vec_rows");
+    }
+    SLG_REQUIRE(vf->dim != 0, "no segment has vectors in this field");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    vf->offsets.resize(n_segs);
+    vf->values.resize(n_segs);
+    std::vector<slg::VecSegDev> vd(n_segs);
+    for (uint32_t s = 0; s < n_segs; s++) {
+      const slg_vector_field_desc &d = per_segment[s];
+      vd[s] = slg::VecSegDev{nullptr, nullptr, ix->segs[s]->n_docs, 0u, vf->metric, 0u};
+      if (!d.vec_dim) continue;
+      const size_t ob = (size_t)ix->segs[s]->n_docs * 4, vb = (size_t)d.vec_rows * d.vec_dim * 4;
+      vf->offsets[s].alloc(ob);
+      if (ob) SLG_HIP(hipMemcpy(vf->offsets[s].p, d.vec_offsets, ob, hipMemcpyHostToDevice));
+      vf->values[s].alloc(vb);
+      if (vb) SLG_HIP(hipMemcpy(vf->values[s].p, d.vec_values, vb, hipMemcpyHostToDevice));
+      ix->device_bytes += vf->offsets[s].bytes + vf->values[s].bytes;
+      vd[s].offsets = vf->offsets[s].as<uint32_t>();
+      vd[s].values = vf->values[s].as<float>();
+      vd[s].dim = d.vec_dim;
+    }
+    vf->d_vsegs.alloc(n_segs * sizeof(slg::VecSegDev));
+    SLG_HIP(hipMemcpy(vf->d_vsegs.p, vd.data(), n_segs * sizeof(slg::VecSegDev), hipMemcpyHostToDevice));
+    ix->vfields.push_back(std::move(vf));
+    id = (int)ix->vfields.size();
+  });
+  return rc == SLG_OK ? id : rc;
+}
+
+namespace {
+// dimension / metric / device stores of vector field f (0: the field of the segment descriptors)
+void field_facts(slg_index *ix, uint32_t f, uint32_t *dim, int32_t *metric, const slg::VecSegDev **vsegs) {
+  if (f == 0) {
+    uint32_t d = 0;
+    int32_t m = -1;
+    for (auto &s : ix->segs) {
+      if (!s->vec_dim) continue;
+      SLG_REQUIRE(d == 0 || d == s->vec_dim, "segments disagree on vec_dim");
+      SLG_REQUIRE(m < 0 || m == s->vec_metric, "segments disagree on the vector metric");
+      d = s->vec_dim;
+      m = s->vec_metric;
+    }
+    if (d == 0) throw SlgError(SLG_ERR_UNSUPPORTED, "index has no vector field 0");
+    *dim = d;
+    *metric = m;
+    *vsegs = ix->d_vsegs.as<slg::VecSegDev>();
+    return;
+  }
+  SLG_REQUIRE(f <= ix->vfields.size(), "unknown vector field id");
+  const VecFieldHost &vf = *ix->vfields[f - 1];
+  *dim = vf.dim;
+  *metric = vf.metric;
+  *vsegs = vf.d_vsegs.as<slg::VecSegDev>();
+}
+}  // namespace
+
+int slg_rerank_fields_batch_device(slg_index *ix, uint32_t nq, uint32_t n_clauses, const uint32_t *clause_field,
+                                   const float *d_qvecs, const float *d_alpha, const float *d_boost,
+                                   const uint32_t *d_cand_doc, const uint32_t *d_cand_seg,
+                                   const float *d_cand_bm25, const uint32_t *d_cand_count, uint32_t max_cand,
+                                   uint32_t k_out, uint32_t *d_out_doc, uint32_t *d_out_seg, float *d_out_score,
+                                   float *d_out_vec_score, uint32_t *d_out_count) {
+  return guarded([&] {
+    SLG_REQUIRE(ix != nullptr && clause_field != nullptr, "index or clause_field is NULL");
+    if (n_clauses < 1 || n_clauses > SLG_MAX_VECTOR_CLAUSES)
+      throw SlgError(SLG_ERR_UNSUPPORTED, "n_clauses outside 1..SLG_MAX_VECTOR_CLAUSES");
+    if (k_out > SLG_MAX_RERANK_K) throw SlgError(SLG_ERR_UNSUPPORTED, "k_out > SLG_MAX_RERANK_K");
+    if (nq == 0) return;
+    SLG_REQUIRE(d_qvecs && d_alpha && d_cand_count && d_out_count, "device arrays are NULL");
+    SLG_REQUIRE(max_cand == 0 || (d_cand_doc && d_cand_seg && d_cand_bm25), "candidate arrays are NULL");
+    SLG_REQUIRE(k_out == 0 || (d_out_doc && d_out_seg && d_out_score), "output arrays are NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    slg::RerankFieldsParams fp{};
+    uint32_t qf = 0;
+    for (uint32_t c = 0; c < n_clauses; c++) {
+      field_facts(ix, clause_field[c], &fp.cdim[c], &fp.cmetric[c], &fp.cvsegs[c]);
+      fp.coff[c] = qf;
+      qf += fp.cdim[c];
+    }
+    if (slg::rerank_fields_lds_floats(n_clauses, qf, max_cand) > slg::kRerankMultiLdsFloats)
+      throw SlgError(SLG_ERR_UNSUPPORTED, "clause vectors + n_clauses * max_cand exceed the LDS budget of the rerank");
+    slg::RerankParams &rp = fp.base;
+    rp.vsegs = nullptr;
+    rp.n_segs = (uint32_t)ix->segs.size();
+    rp.dim = 0;
+    rp.qvecs = d_qvecs;
+    rp.alpha = d_alpha;
+    rp.cand_doc = d_cand_doc;
+    rp.cand_seg = d_cand_seg;
+    rp.cand_bm25 = d_cand_bm25;
+    rp.cand_count = d_cand_count;
+    rp.max_cand = max_cand;
+    rp.k_out = k_out;
+    rp.out_doc = d_out_doc;
+    rp.out_seg = d_out_seg;
+    rp.out_score = d_out_score;
+    rp.out_vec = d_out_vec_score;
+    rp.out_count = d_out_count;
+    rp.nq = nq;
+    fp.boost = d_boost;
+    fp.n_clauses = n_clauses;
+    fp.q_floats = qf;
+    SLG_HIP(slg::launch_rerank_fields(fp, kregs_for(k_out ? k_out : 1), ix->stream));
+  });
+}
+
+int slg_rerank_fields_batch(slg_index *ix, uint32_t nq, uint32_t n_clauses, const uint32_t *clause_field,
+                            const float *qvecs, const float *alpha, const float *boost,
+                            const uint32_t *cand_doc, const uint32_t *cand_seg, const float *cand_bm25,
+                            const uint32_t *cand_count, uint32_t max_cand, uint32_t k_out, uint32_t *out_doc,
+                            uint32_t *out_seg, float *out_score, float *out_vec_score, uint32_t *out_count) {
+  uint32_t qf = 0;
+  int rc = guarded([&] {
+    SLG_REQUIRE(ix != nullptr && clause_field != nullptr, "index or clause_field is NULL");
+    if (n_clauses < 1 || n_clauses > SLG_MAX_VECTOR_CLAUSES)
+      throw SlgError(SLG_ERR_UNSUPPORTED, "n_clauses outside 1..SLG_MAX_VECTOR_CLAUSES");
+    if (nq == 0) return;
+    SLG_REQUIRE(qvecs && alpha && cand_count && out_count, "host arrays are NULL");
+    SLG_REQUIRE(max_cand == 0 || (cand_doc && cand_seg && cand_bm25), "candidate arrays are NULL");
+    SLG_REQUIRE(k_out == 0 || (out_doc && out_seg && out_score), "output arrays are NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    for (uint32_t c = 0; c < n_clauses; c++) {
+      uint32_t d;
+      int32_t m;
+      const slg::VecSegDev *v;
+      field_facts(ix, clause_field[c], &d, &m, &v);
+      qf += d;
+    }
+  });
+  if (rc != SLG_OK || nq == 0) return rc;
+  DevBuf dq, da, db, dcd, dcs, dcb, dcc, dod, dos, dosc, dov, doc_;
+  const size_t nc = (size_t)nq * max_cand, no = (size_t)nq * k_out, nqc = (size_t)nq * n_clauses;
+  rc = guarded([&] {
+    DeviceGuard g(ix->device);
+    hipStream_t st = ix->stream;
+    dq.alloc((size_t)nq * qf * 4);
+    da.alloc(nqc * 4);
+    if (boost) db.alloc(nqc * 4);
+    dcd.alloc(nc * 4);
+    dcs.alloc(nc * 4);
+    dcb.alloc(nc * 4);
+    dcc.alloc((size_t)nq * 4);
+    dod.alloc(no * 4);
+    dos.alloc(no * 4);
+    dosc.alloc(no * 4);
+    dov.alloc(no * 4);
+    doc_.alloc((size_t)nq * 4);
+    SLG_HIP(hipMemcpyAsync(dq.p, qvecs, (size_t)nq * qf * 4, hipMemcpyHostToDevice, st));
+    SLG_HIP(hipMemcpyAsync(da.p, alpha, nqc * 4, hipMemcpyHostToDevice, st));
+    if (boost) SLG_HIP(hipMemcpyAsync(db.p, boost, nqc * 4, hipMemcpyHostToDevice, st));
+    if (nc) {
+      SLG_HIP(hipMemcpyAsync(dcd.p, cand_doc, nc * 4, hipMemcpyHostToDevice, st));
+      SLG_HIP(hipMemcpyAsync(dcs.p, cand_seg, nc * 4, hipMemcpyHostToDevice, st));
+      SLG_HIP(hipMemcpyAsync(dcb.p, cand_bm25, nc * 4, hipMemcpyHostToDevice, st));
+    }
+    SLG_HIP(hipMemcpyAsync(dcc.p, cand_count, (size_t)nq * 4, hipMemcpyHostToDevice, st));
+  });
+  if (rc != SLG_OK) return rc;
+  rc = slg_rerank_fields_batch_device(ix, nq, n_clauses, clause_field, dq.as<float>(), da.as<float>(),
+                                      boost ? db.as<float>() : nullptr, dcd.as<uint32_t>(), dcs.as<uint32_t>(),
+                                      dcb.as<float>(), dcc.as<uint32_t>(), max_cand, k_out, dod.as<uint32_t>(),
+                                      dos.as<uint32_t>(), dosc.as<float>(), dov.as<float>(), doc_.as<uint32_t>());
+  if (rc != SLG_OK) return rc;
+  return guarded([&] {
+    DeviceGuard g(ix->device);
+    hipStream_t st = ix->stream;
+    if (no) {
+      SLG_HIP(hipMemcpyAsync(out_doc, dod.p, no * 4, hipMemcpyDeviceToHost, st));
+      SLG_HIP(hipMemcpyAsync(out_seg, dos.p, no * 4, hipMemcpyDeviceToHost, st));
+      SLG_HIP(hipMemcpyAsync(out_score, dosc.p, no * 4, hipMemcpyDeviceToHost, st));
+      if (out_vec_score) SLG_HIP(hipMemcpyAsync(out_vec_score, dov.p, no * 4, hipMemcpyDeviceToHost, st));
+    }
+    SLG_HIP(hipMemcpyAsync(out_count, doc_.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    SLG_HIP(hipStreamSynchronize(st));
   });
 }
 

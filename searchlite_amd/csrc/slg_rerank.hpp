@@ -60,6 +60,75 @@ __device__ __forceinline__ float wave_sum_f(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(x, 63));
 }
 
+// The k_out best blended scores of query q by (blended desc, segment asc, doc asc), their vector
+// scores, the count: wave 0 of the workgroup, after the blends are in LDS.
+template <int KREGS>
+__device__ __forceinline__ void rerank_emit_topk(const RerankParams &p, const uint32_t q, const uint32_t n,
+                                                 const float *s_blend, const float *s_vec,
+                                                 const uint32_t *cdoc, const uint32_t *cseg,
+                                                 const uint32_t lane) {
+  const uint32_t k = p.k_out;
+  if (k == 0) {
+    if (lane == 0) p.out_count[q] = 0;
+    return;
+  }
+  WaveTopK<KREGS, true> top;
+  top.init();
+  for (uint32_t base = 0; base < n; base += 64) {
+    const uint32_t i = base + lane;
+    int32_t ctk = kSentinelTk;
+    uint32_t d = 0xFFFFFFFFu, sg = 0xFFFFFFFFu;
+    if (i < n) {
+      ctk = total_key(s_blend[i]);
+      d = cdoc[i];
+      sg = cseg[i];
+    }
+    uint64_t m = __ballot(i < n && top.passes(ctk, sg, d));
+    while (m) {
+      const uint32_t l = (uint32_t)__builtin_ctzll(m);
+      top.insert((int32_t)rl((uint32_t)ctk, l), rl(sg, l), rl(d, l), k, lane);
+      m &= m - 1;
+      m &= __ballot(top.passes(ctk, sg, d));
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < KREGS; r++) {
+    const uint32_t pos = lane * KREGS + r;
+    if (pos < k) {
+      const bool real = pos < top.count;
+      p.out_doc[(size_t)q * k + pos] = real ? top.doc[r] : 0u;
+      p.out_seg[(size_t)q * k + pos] = real ? top.seg[r] : 0u;
+      p.out_score[(size_t)q * k + pos] = real ? key_to_float(top.tk[r]) : 0.0f;
+    }
+  }
+  if (p.out_vec) {
+    // vector score of each winner: all lanes scan the candidate list for its (seg, doc)
+    const uint32_t nout = top.count < k ? top.count : k;
+    for (uint32_t pos = 0; pos < nout; pos++) {
+      const uint32_t pl = pos / KREGS, pr = pos % KREGS;
+      uint32_t wd = top.doc[0], ws = top.seg[0];
+#pragma unroll
+      for (int r = 1; r < KREGS; r++) {
+        wd = pr == (uint32_t)r ? top.doc[r] : wd;
+        ws = pr == (uint32_t)r ? top.seg[r] : ws;
+      }
+      wd = rl(wd, pl);
+      ws = rl(ws, pl);
+      for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + lane;
+        const bool match = i < n && cdoc[i] == wd && cseg[i] == ws;
+        const uint64_t mm = __ballot(match);
+        if (mm) {
+          if (lane == (uint32_t)__builtin_ctzll(mm)) p.out_vec[(size_t)q * k + pos] = s_vec[i];
+          break;
+        }
+      }
+    }
+    for (uint32_t pos = nout + lane; pos < k; pos += 64) p.out_vec[(size_t)q * k + pos] = 0.0f;
+  }
+  if (lane == 0) p.out_count[q] = top.count;
+}
+
 // vector score + blend of candidate c (lane 0 stores): api/reader.rs:217-223, :240-246,
 // vectors/mod.rs:112-118, :128
 __device__ __forceinline__ void rerank_finish(const float sum, const bool have_row, const int32_t metric,
@@ -306,66 +375,7 @@ __global__ void __launch_bounds__(256) rerank_kernel(RerankParams p) {
   __syncthreads();
   if (wave != 0) return;
 
-  const uint32_t k = p.k_out;
-  if (k == 0) {
-    if (lane == 0) p.out_count[q] = 0;
-    return;
-  }
-  WaveTopK<KREGS, true> top;
-  top.init();
-  for (uint32_t base = 0; base < n; base += 64) {
-    const uint32_t i = base + lane;
-    int32_t ctk = kSentinelTk;
-    uint32_t d = 0xFFFFFFFFu, sg = 0xFFFFFFFFu;
-    if (i < n) {
-      ctk = total_key(s_blend[i]);
-      d = cdoc[i];
-      sg = cseg[i];
-    }
-    uint64_t m = __ballot(i < n && top.passes(ctk, sg, d));
-    while (m) {
-      const uint32_t l = (uint32_t)__builtin_ctzll(m);
-      top.insert((int32_t)rl((uint32_t)ctk, l), rl(sg, l), rl(d, l), k, lane);
-      m &= m - 1;
-      m &= __ballot(top.passes(ctk, sg, d));
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < KREGS; r++) {
-    const uint32_t pos = lane * KREGS + r;
-    if (pos < k) {
-      const bool real = pos < top.count;
-      p.out_doc[(size_t)q * k + pos] = real ? top.doc[r] : 0u;
-      p.out_seg[(size_t)q * k + pos] = real ? top.seg[r] : 0u;
-      p.out_score[(size_t)q * k + pos] = real ? key_to_float(top.tk[r]) : 0.0f;
-    }
-  }
-  if (p.out_vec) {
-    // vector score of each winner: all lanes scan the candidate list for its (seg, doc)
-    const uint32_t nout = top.count < k ? top.count : k;
-    for (uint32_t pos = 0; pos < nout; pos++) {
-      const uint32_t pl = pos / KREGS, pr = pos % KREGS;
-      uint32_t wd = top.doc[0], ws = top.seg[0];
-#pragma unroll
-      for (int r = 1; r < KREGS; r++) {
-        wd = pr == (uint32_t)r ? top.doc[r] : wd;
-        ws = pr == (uint32_t)r ? top.seg[r] : ws;
-      }
-      wd = rl(wd, pl);
-      ws = rl(ws, pl);
-      for (uint32_t base = 0; base < n; base += 64) {
-        const uint32_t i = base + lane;
-        const bool match = i < n && cdoc[i] == wd && cseg[i] == ws;
-        const uint64_t mm = __ballot(match);
-        if (mm) {
-          if (lane == (uint32_t)__builtin_ctzll(mm)) p.out_vec[(size_t)q * k + pos] = s_vec[i];
-          break;
-        }
-      }
-    }
-    for (uint32_t pos = nout + lane; pos < k; pos += 64) p.out_vec[(size_t)q * k + pos] = 0.0f;
-  }
-  if (lane == 0) p.out_count[q] = top.count;
+  rerank_emit_topk<KREGS>(p, q, n, s_blend, s_vec, cdoc, cseg, lane);
 }
 
 // ---- hybrid rerank with several vector clauses (api/reader.rs:225-254, MAX_VECTOR_CLAUSES = 8) ----
@@ -553,65 +563,113 @@ __global__ void __launch_bounds__(256) rerank_multi_kernel(RerankMultiParams mp)
   __syncthreads();
   if (wave != 0) return;
 
-  const uint32_t k = p.k_out;
-  if (k == 0) {
-    if (lane == 0) p.out_count[q] = 0;
-    return;
-  }
-  WaveTopK<KREGS, true> top;
-  top.init();
-  for (uint32_t base = 0; base < n; base += 64) {
-    const uint32_t i = base + lane;
-    int32_t ctk = kSentinelTk;
-    uint32_t d = 0xFFFFFFFFu, sg = 0xFFFFFFFFu;
-    if (i < n) {
-      ctk = total_key(s_blend[i]);
-      d = cdoc[i];
-      sg = cseg[i];
-    }
-    uint64_t m = __ballot(i < n && top.passes(ctk, sg, d));
-    while (m) {
-      const uint32_t l = (uint32_t)__builtin_ctzll(m);
-      top.insert((int32_t)rl((uint32_t)ctk, l), rl(sg, l), rl(d, l), k, lane);
-      m &= m - 1;
-      m &= __ballot(top.passes(ctk, sg, d));
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < KREGS; r++) {
-    const uint32_t pos = lane * KREGS + r;
-    if (pos < k) {
-      const bool real = pos < top.count;
-      p.out_doc[(size_t)q * k + pos] = real ? top.doc[r] : 0u;
-      p.out_seg[(size_t)q * k + pos] = real ? top.seg[r] : 0u;
-      p.out_score[(size_t)q * k + pos] = real ? key_to_float(top.tk[r]) : 0.0f;
-    }
-  }
-  if (p.out_vec) {
-    const uint32_t nout = top.count < k ? top.count : k;
-    for (uint32_t pos = 0; pos < nout; pos++) {
-      const uint32_t pl = pos / KREGS, pr = pos % KREGS;
-      uint32_t wd = top.doc[0], ws = top.seg[0];
-#pragma unroll
-      for (int r = 1; r < KREGS; r++) {
-        wd = pr == (uint32_t)r ? top.doc[r] : wd;
-        ws = pr == (uint32_t)r ? top.seg[r] : ws;
-      }
-      wd = rl(wd, pl);
-      ws = rl(ws, pl);
-      for (uint32_t base = 0; base < n; base += 64) {
-        const uint32_t i = base + lane;
-        const bool match = i < n && cdoc[i] == wd && cseg[i] == ws;
-        const uint64_t mm = __ballot(match);
-        if (mm) {
-          if (lane == (uint32_t)__builtin_ctzll(mm)) p.out_vec[(size_t)q * k + pos] = s_vsum[i];
-          break;
+  rerank_emit_topk<KREGS>(p, q, n, s_blend, s_vsum, cdoc, cseg, lane);
+}
+
+// ---- hybrid rerank whose clauses name DIFFERENT vector fields (api/reader.rs:225-254: every clause
+// has its own field, metric and dimension; a doc may have a vector in one field and none in
+// another — then only that clause takes the missing-vector score, and the reported vector score
+// sums the clauses that found one).  One candidate per wave at a time, clause after clause, each
+// against its own field's row: a plain VALU path (requests of this shape are rare; clauses over ONE
+// field take rerank_multi_kernel). ----
+struct RerankFieldsParams {
+  RerankParams base;           // vsegs / dim unused; qvecs: [nq][q_floats]; alpha: [nq][n_clauses]
+  const float *boost;          // [nq][n_clauses] or nullptr (1.0)
+  uint32_t n_clauses;          // 1..8
+  uint32_t q_floats;           // floats of one query's clause vectors, clause after clause
+  const VecSegDev *cvsegs[8];  // per clause: the per-segment stores of its field
+  uint32_t cdim[8], coff[8];   // per clause: dimension, offset of its vector inside q_floats
+  int32_t cmetric[8];
+};
+
+template <int KREGS>
+__global__ void __launch_bounds__(256) rerank_fields_kernel(RerankFieldsParams fp) {
+  const RerankParams &p = fp.base;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef const __attribute__((address_space(1))) float *gf_t;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t q = blockIdx.x;
+  const uint32_t NC = fp.n_clauses;
+  uint32_t n = p.cand_count[q];
+  n = n < p.max_cand ? n : p.max_cand;
+  float *s_q = reinterpret_cast<float *>(smem);             // [q_floats]
+  float *s_vs = s_q + ((fp.q_floats + 3u) & ~3u);           // [NC][max_cand] similarity (no boost yet)
+  float *s_blend = s_vs + NC * p.max_cand;                  // [max_cand]
+  float *s_vsum = s_blend + p.max_cand;                     // [max_cand]
+  uint32_t *s_has = reinterpret_cast<uint32_t *>(s_vsum + p.max_cand);  // [max_cand] bit c: clause c found a vector
+  const uint32_t *cdoc = p.cand_doc + (size_t)q * p.max_cand;
+  const uint32_t *cseg = p.cand_seg + (size_t)q * p.max_cand;
+  const float *cbm = p.cand_bm25 + (size_t)q * p.max_cand;
+  for (uint32_t i = threadIdx.x; i < fp.q_floats; i += 256) s_q[i] = p.qvecs[(size_t)q * fp.q_floats + i];
+  __syncthreads();
+
+  for (uint32_t c = wave; c < n; c += 4) {
+    const uint32_t doc = cdoc[c], seg = cseg[c];
+    uint32_t has = 0;
+    for (uint32_t cc = 0; cc < NC; cc++) {
+      const uint32_t dim = fp.cdim[cc];
+      const int32_t metric = fp.cmetric[cc];
+      const float *row = nullptr;
+      if (seg < p.n_segs) {
+        const VecSegDev vd = fp.cvsegs[cc][seg];
+        if (vd.dim == dim && doc < vd.n_docs) {
+          const uint32_t off = vd.offsets[doc];
+          if (off != 0xFFFFFFFFu) row = vd.values + (size_t)off * dim;
         }
       }
+      if (row == nullptr) continue;
+      const float *qc = s_q + fp.coff[cc];
+      float acc = 0.0f;
+      for (uint32_t i = lane; i < dim; i += 64) {
+        const float a = qc[i], bb = ((gf_t)row)[i];
+        if (metric == 0) {
+          acc += a * bb;
+        } else {
+          const float d = a - bb;
+          acc += d * d;
+        }
+      }
+      const float sum = wave_sum_f(acc);
+      if (lane == 0) s_vs[cc * p.max_cand + c] = metric == 0 ? (sum != sum ? 0.0f : sum) : -sqrtf(sum);
+      has |= 1u << cc;
     }
-    for (uint32_t pos = nout + lane; pos < k; pos += 64) p.out_vec[(size_t)q * k + pos] = 0.0f;
+    if (lane == 0) s_has[c] = has;
   }
-  if (lane == 0) p.out_count[q] = top.count;
+  __syncthreads();
+  // ---- compute_hybrid_score (api/reader.rs:225-254) per candidate, clauses in order ----
+  for (uint32_t c = threadIdx.x; c < n; c += 256) {
+    const uint32_t has = s_has[c];
+    const float bm = cbm[c];
+    float blended_sum = 0.0f, vector_sum = 0.0f;
+    for (uint32_t cc = 0; cc < NC; cc++) {
+      const float alpha = p.alpha[(size_t)q * NC + cc];
+      float vs;
+      if ((has >> cc) & 1u) {
+        vs = s_vs[cc * p.max_cand + c] * (fp.boost ? fp.boost[(size_t)q * NC + cc] : 1.0f);
+        vector_sum += vs;
+      } else {
+        vs = fp.cmetric[cc] == 0 ? -1.0f : -3.40282347e+38f;  // missing_vector_score of THIS clause
+      }
+      float blended;
+      if (alpha >= 1.0f)
+        blended = bm;
+      else if (alpha <= 0.0f)
+        blended = vs;
+      else
+        blended = alpha * bm + (1.0f - alpha) * vs;
+      blended_sum += blended;
+    }
+    s_blend[c] = blended_sum / (float)NC;
+    s_vsum[c] = has ? vector_sum : (fp.cmetric[0] == 0 ? -1.0f : -3.40282347e+38f);
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  rerank_emit_topk<KREGS>(p, q, n, s_blend, s_vsum, cdoc, cseg, lane);
+}
+
+inline size_t rerank_fields_lds_floats(uint32_t n_clauses, uint32_t q_floats, uint32_t max_cand) {
+  return (size_t)((q_floats + 3u) & ~3u) + (size_t)n_clauses * max_cand + 3 * (size_t)max_cand;
 }
 
 inline size_t rerank_multi_lds_floats(uint32_t n_clauses, uint32_t dim, uint32_t max_cand) {
@@ -637,6 +695,17 @@ inline hipError_t launch_rerank_multi(const RerankMultiParams &mp, int kregs, hi
     case 4: return launch_with_lds(rerank_multi_kernel<4>, mp, mp.base.nq, lds, st);
     case 8: return launch_with_lds(rerank_multi_kernel<8>, mp, mp.base.nq, lds, st);
     default: return launch_with_lds(rerank_multi_kernel<16>, mp, mp.base.nq, lds, st);
+  }
+}
+
+inline hipError_t launch_rerank_fields(const RerankFieldsParams &fp, int kregs, hipStream_t st) {
+  const size_t lds = rerank_fields_lds_floats(fp.n_clauses, fp.q_floats, fp.base.max_cand) * 4 + 16;
+  switch (kregs) {
+    case 1: return launch_with_lds(rerank_fields_kernel<1>, fp, fp.base.nq, lds, st);
+    case 2: return launch_with_lds(rerank_fields_kernel<2>, fp, fp.base.nq, lds, st);
+    case 4: return launch_with_lds(rerank_fields_kernel<4>, fp, fp.base.nq, lds, st);
+    case 8: return launch_with_lds(rerank_fields_kernel<8>, fp, fp.base.nq, lds, st);
+    default: return launch_with_lds(rerank_fields_kernel<16>, fp, fp.base.nq, lds, st);
   }
 }
 

@@ -277,6 +277,55 @@ class GpuIndex:
             _ptr(out_score), _ptr(out_vec), _ptr(out_count)))
         return out_doc, out_seg, out_score, out_vec, out_count
 
+    def add_vector_field(self, per_segment) -> int:
+        """Stage one more vector field (vectors/mod.rs:10-17: a VectorStore per field).  per_segment[s]
+        = (metric, vec_offsets u32[n_docs], vec_values f32[rows, dim]) or None (segment s has no
+        vectors in it).  -> field id (>= 1; 0 is the field of the segment descriptors)."""
+        descs = (N.VectorFieldDesc * len(per_segment))()
+        keep = []
+        for s, f in enumerate(per_segment):
+            if f is None:
+                continue
+            metric, offs, vals = f
+            offs = np.ascontiguousarray(offs, dtype=np.uint32)
+            vals = np.ascontiguousarray(vals, dtype=np.float32)
+            keep += [offs, vals]
+            descs[s].vec_dim, descs[s].vec_metric = vals.shape[1], int(metric)
+            descs[s].vec_offsets, descs[s].vec_values = offs.ctypes.data, vals.ctypes.data
+            descs[s].vec_rows = vals.shape[0]
+        rc = self._lib.slg_index_add_vector_field(self._h, C.addressof(descs), len(per_segment))
+        if rc < 0:
+            N.check(rc)
+        return rc
+
+    def rerank_fields_batch(self, clause_field, qvecs, alpha, cand_doc, cand_seg, cand_bm25, cand_count,
+                            k_out: int, boost=None):
+        """Hybrid rerank whose clauses name different vector fields (api/reader.rs:225-254).
+        clause_field [n_clauses] field ids; qvecs [nq, sum of the clause dims] (a query's clause
+        vectors one after another); alpha / boost [nq, n_clauses]."""
+        cf = np.ascontiguousarray(clause_field, dtype=np.uint32)
+        nc = len(cf)
+        qvecs = np.ascontiguousarray(qvecs, dtype=np.float32)
+        nq = qvecs.shape[0]
+        alpha = np.ascontiguousarray(np.broadcast_to(np.asarray(alpha, dtype=np.float32), (nq, nc)))
+        bst = None if boost is None else \
+            np.ascontiguousarray(np.broadcast_to(np.asarray(boost, dtype=np.float32), (nq, nc)))
+        cand_doc = np.ascontiguousarray(cand_doc, dtype=np.uint32).reshape(nq, -1)
+        max_cand = cand_doc.shape[1]
+        cand_seg = np.ascontiguousarray(cand_seg, dtype=np.uint32).reshape(nq, max_cand)
+        cand_bm25 = np.ascontiguousarray(cand_bm25, dtype=np.float32).reshape(nq, max_cand)
+        cand_count = np.ascontiguousarray(cand_count, dtype=np.uint32)
+        out_doc = np.zeros((nq, k_out), dtype=np.uint32)
+        out_seg = np.zeros((nq, k_out), dtype=np.uint32)
+        out_score = np.zeros((nq, k_out), dtype=np.float32)
+        out_vec = np.zeros((nq, k_out), dtype=np.float32)
+        out_count = np.zeros(nq, dtype=np.uint32)
+        N.check(self._lib.slg_rerank_fields_batch(
+            self._h, nq, nc, _ptr(cf), _ptr(qvecs), _ptr(alpha), _ptr(bst), _ptr(cand_doc), _ptr(cand_seg),
+            _ptr(cand_bm25), _ptr(cand_count), max_cand, k_out, _ptr(out_doc), _ptr(out_seg),
+            _ptr(out_score), _ptr(out_vec), _ptr(out_count)))
+        return out_doc, out_seg, out_score, out_vec, out_count
+
     def rerank_batch_device(self, nq, d_qvecs, d_alpha, d_cand_doc, d_cand_seg, d_cand_bm25,
                             d_cand_count, max_cand, k_out, d_out_doc, d_out_seg, d_out_score,
                             d_out_vec, d_out_count) -> None:

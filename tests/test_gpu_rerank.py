@@ -244,6 +244,68 @@ def test_rerank_multi_clause_dims(oracle, dim, metric):
         TOL = tol_save
 
 
+def test_rerank_clauses_over_different_fields(oracle):
+    """Clauses that name different vector fields (api/reader.rs:225-254): a 96-d cosine field
+    (field 0, in the segment descriptor), a 40-d L2 field and a 256-d cosine field added with
+    slg_index_add_vector_field.  Docs may have a vector in one field and not in another: only that
+    clause takes its metric's missing score; the reported vector score sums the clauses found."""
+    import searchlite_amd as sa
+    from searchlite_amd import corpus
+    rng = np.random.default_rng(77)
+    n, ncand, k_out, nq = 900, 200, 15, 4
+    dims, metrics = [96, 40, 256], [0, 1, 0]
+    fields = []
+    for f in range(3):
+        vals = corpus.unit_vectors(n, dims[f], seed=60 + f)
+        offs = np.arange(n, dtype=np.uint32)
+        offs[rng.choice(n, size=250, replace=False)] = 0xFFFFFFFF
+        fields.append((metrics[f], offs, vals))
+    seg = _segment_with_vectors(n, fields[0][1], fields[0][2], 0)
+    cand = np.stack([rng.choice(n, size=ncand, replace=False) for _ in range(nq)]).astype(np.uint32)
+    bm = (rng.random((nq, ncand)) * 10).astype(np.float32)
+    cnt = np.array([ncand, 57, ncand, 1], np.uint32)
+    for clause_field in ([0, 1, 2], [2, 1], [1], [1, 1, 0, 2, 2]):
+        nc = len(clause_field)
+        qs = [corpus.unit_vectors(nq, dims[f], seed=70 + c) for c, f in enumerate(clause_field)]
+        qcat = np.concatenate(qs, axis=1)
+        alpha = rng.choice(np.array([0.0, 0.25, 0.5, 1.0], np.float32), size=(nq, nc))
+        boost = (rng.random((nq, nc)) + 0.5).astype(np.float32)
+        with sa.GpuIndex([seg]) as ix:
+            ids = [0, ix.add_vector_field([fields[1]]), ix.add_vector_field([fields[2]])]
+            assert ids == [0, 1, 2]
+            got = ix.rerank_fields_batch([ids[f] for f in clause_field], qcat, alpha, cand, np.zeros_like(cand),
+                                         bm, cnt, k_out, boost=boost)
+        wd, ws, wv = [], [], []
+        for i in range(nq):
+            d_, s_, v_ = oracle.rerank_fields(fields, clause_field, [q[i] for q in qs], alpha[i],
+                                              cand[i, :cnt[i]], bm[i, :cnt[i]], k_out, boost=boost[i])
+            wd.append(d_)
+            ws.append(s_)
+            wv.append(v_)
+        global TOL
+        tol_save = TOL
+        TOL = 1e-5 * max(1, nc // 2)
+        try:
+            _check(got, wd, ws, wv, f"fields {clause_field}")
+        finally:
+            TOL = tol_save
+
+
+def test_rerank_fields_errors():
+    import searchlite_amd as sa
+    from searchlite_amd import corpus
+    n = 50
+    vals = corpus.unit_vectors(n, 8, seed=1)
+    seg = _segment_with_vectors(n, np.arange(n, dtype=np.uint32), vals, 0)
+    cand = np.zeros((1, 4), np.uint32)
+    with sa.GpuIndex([seg]) as ix:
+        with pytest.raises(sa.SlgError):  # unknown field id
+            ix.rerank_fields_batch([3], np.zeros((1, 8), np.float32), 0.5, cand, cand, np.zeros((1, 4), np.float32),
+                                   np.array([4], np.uint32), 2)
+        with pytest.raises(sa.SlgError):  # offsets past the rows
+            ix.add_vector_field([(0, np.full(n, 7, np.uint32), vals[:3])])
+
+
 def test_rerank_multi_matches_single_clause_kernel():
     """One clause through the multi-clause entry (with a boost of 1.0, which takes the MFMA kernel)
     agrees with the GEMV-shaped single-clause kernel."""
