@@ -328,6 +328,7 @@ def rerank_fields(fields, clause_field, qvecs, alpha, cand_doc, cand_bm25, k_out
     clause 0 when none did (what the single-field oracle reports).  Order: blended desc, doc asc."""
     f32 = np.float32
     nc = len(clause_field)
+    old_err = np.seterr(over="ignore")  # f32::MIN sums saturate to -inf, as in the reference
     alpha = np.asarray(alpha, dtype=f32)
     bst = np.ones(nc, f32) if boost is None else np.asarray(boost, dtype=f32)
     rows = []
@@ -355,6 +356,7 @@ def rerank_fields(fields, clause_field, qvecs, alpha, cand_doc, cand_bm25, k_out
             blended_sum = f32(blended_sum + blended)
         m0 = f32(-1.0) if fields[clause_field[0]][0] == 0 else f32(-3.40282347e+38)
         rows.append((f32(blended_sum / f32(nc)), int(d), vector_sum if has else m0))
+    np.seterr(**old_err)
     rows.sort(key=lambda r: (-float(r[0]), r[1]))
     rows = rows[:k_out]
     return (np.array([r[1] for r in rows], np.uint32), np.array([r[0] for r in rows], f32),

@@ -20,6 +20,7 @@
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "slg_kernels.hpp"
@@ -95,7 +96,9 @@ struct BufPool {
   std::mutex mu;
   std::multimap<size_t, void *> free_;
   size_t pooled = 0;
-  static constexpr size_t kMaxPooled = 4ull << 30;
+  // (config 4 on one GPU holds ~1 GB of work buffers per 8192-query batch and keeps three batches
+  //  alive: with a 4 GB cap every batch ended in hipFree + hipMalloc, which synchronise the device)
+  static constexpr size_t kMaxPooled = 24ull << 30;
   static size_t size_class(size_t n) {  // powers of two up to 1 MiB, then eighths of an octave
     size_t c = 4096;
     while (c < n && c < (1u << 20)) c <<= 1;
@@ -104,13 +107,15 @@ struct BufPool {
     const size_t step = c >> 3;
     return c + ((n - c + step - 1) / step) * step;
   }
-  void *get(size_t cls) {
+  // a free block of class cls, or the next larger one within 25 % (its size goes back in *got)
+  void *get(size_t cls, size_t *got) {
     std::lock_guard<std::mutex> lk(mu);
-    auto it = free_.find(cls);
-    if (it == free_.end()) return nullptr;
+    auto it = free_.lower_bound(cls);
+    if (it == free_.end() || it->first > cls + cls / 4) return nullptr;
     void *p = it->second;
+    *got = it->first;
+    pooled -= it->first;
     free_.erase(it);
-    pooled -= cls;
     return p;
   }
   bool put(void *p, size_t cls) {
@@ -137,8 +142,8 @@ struct DevBuf {
   }
   void alloc_pooled(BufPool *pl, size_t n) {
     release();
-    const size_t cls = BufPool::size_class(n ? n : 16);
-    p = pl->get(cls);
+    size_t cls = BufPool::size_class(n ? n : 16);
+    p = pl->get(cls, &cls);
     if (!p) SLG_HIP(hipMalloc(&p, cls));
     bytes = cls;
     pool = pl;
@@ -204,6 +209,12 @@ struct slg_index {
   std::vector<slg_batch *> live;  // batches prepared on this index and not yet destroyed (under mu)
   int device = 0;
   hipStream_t own_stream = nullptr;
+  // descriptor uploads of slg_batch_prepare*: non-blocking streams picked by caller thread.  A plain
+  // hipMemcpy runs on the legacy default stream and waits for whatever the application has queued
+  // there (config 4: the previous batch's all-gather, shard merge and D2H) — planning would then
+  // serialise with the GPU work it is supposed to overlap
+  static constexpr int kUploadStreams = 8;
+  hipStream_t upload_streams[kUploadStreams] = {};
   hipStream_t stream = nullptr;
   std::vector<std::unique_ptr<SegHost>> segs;
   DevBuf d_segs;  // slg::SegDev[n_segs]
@@ -583,6 +594,7 @@ slg_index *slg_index_create_tuned(const slg_segment_desc *segs, uint32_t n_segs,
                      std::string("device is ") + prop.gcnArchName + ", this library targets gfx950");
     SLG_HIP(hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking));
     ix->stream = ix->own_stream;
+    for (auto &us : ix->upload_streams) SLG_HIP(hipStreamCreateWithFlags(&us, hipStreamNonBlocking));
     for (uint32_t s = 0; s < n_segs; s++) {
       ix->segs.emplace_back(new SegHost());
       stage_segment(ix, *ix->segs[s], segs[s]);
@@ -658,6 +670,8 @@ void slg_index_destroy(slg_index *ix) {
   ix->d_segs.release();
   ix->d_vsegs.release();
   if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
+  for (auto us : ix->upload_streams)
+    if (us) (void)hipStreamDestroy(us);
   delete ix;
   if (prev >= 0) (void)hipSetDevice(prev);
 }
@@ -852,162 +866,230 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
             }
       }
     }
-    for (uint32_t q = 0; q < nq; q++) {
-      q_sq_begin[q] = (uint32_t)sqs.size();
-      SLG_REQUIRE(q_offsets[q + 1] >= q_offsets[q], "q_offsets not monotone");
-      const uint32_t t0 = q_offsets[q], nt = q_offsets[q + 1] - t0;
-      if (nt > SLG_MAX_QUERY_TERMS)
-        throw SlgError(SLG_ERR_UNSUPPORTED, "query " + std::to_string(q) + " has more than " +
-                                                std::to_string(SLG_MAX_QUERY_TERMS) + " terms");
-      uint32_t fq = 0;  // doc filter of the query (0 none, id + 1)
-      if (q_filter && q_filter[q] >= 0) {
-        SLG_REQUIRE((size_t)q_filter[q] < filter_live.size() && filter_live[q_filter[q]],
-                    "unknown filter id in query " + std::to_string(q));
-        fq = (uint32_t)q_filter[q] + 1u;
-        any_filter = true;
-      }
-      // score plan of the query (query/planner.rs:113-153)
-      const int plan_kind = q_plan ? q_plan[q] : SLG_PLAN_SUM;
-      SLG_REQUIRE(plan_kind == SLG_PLAN_SUM || plan_kind == SLG_PLAN_DISMAX,
-                  "unknown score plan in query " + std::to_string(q));
-      const float tie = q_tie ? q_tie[q] : 0.0f;
-      // validate_tie_breaker (query/planner.rs:850-856); the threshold seed and the pruning bounds
-      // also rely on it: with tie in [0, 1] a DisMax is >= each of its non-negative leaves
-      SLG_REQUIRE(tie >= 0.0f && tie <= 1.0f,
-                  "tie breaker outside [0, 1] in query " + std::to_string(q));
-      uint32_t n_leaves = q_nleaves ? q_nleaves[q] : 0;
-      for (uint32_t i = 0; i < nt; i++) {
-        const uint32_t lf = q_leaf ? q_leaf[t0 + i] : i;
-        SLG_REQUIRE(lf < 0x80000000u, "leaf index >= 2^31 in query " + std::to_string(q));
-        n_leaves = std::max(n_leaves, lf + 1u);
-      }
-      if (k == 0) continue;  // wand.rs:413-416: k == 0 and no collector => no work
-      for (uint32_t s = 0; s < n_segs; s++) {
-        const SegHost &sh = *ix->segs[s];
-        slg::RoundQuery sq{};
-        sq.q = q;
-        sq.seg = s;
-        sq.filter = fq;
-        sq.term_begin = (uint32_t)terms.size();
-        uint64_t P = 0;
-        uint32_t longest = 0, longest_df = 0;
+    // Pass 1 is per query: large batches (config 4: 8192 queries x 8 segments = 65K sub-queries,
+    // 15 ms on one thread, mostly cache misses in the champion tables) are planned by several
+    // threads, each into its own vectors, stitched together in query order afterwards.
+    struct Pass1Out {
+      std::vector<slg::RoundQuery> sqs;
+      std::vector<slg::TermRef> terms;
+      std::vector<uint64_t> sq_postings, sq_postings_all;
+      uint64_t n_postings = 0, n_ess = 0, n_noness = 0;
+      uint32_t max_terms = 0;
+      bool any_plan = false, any_filter = false;
+      std::exception_ptr err;
+    };
+    auto plan_range = [&](const uint32_t q_lo, const uint32_t q_hi, Pass1Out &o) {
+      auto &sqs = o.sqs;
+      auto &terms = o.terms;
+      auto &sq_postings = o.sq_postings;
+      auto &sq_postings_all = o.sq_postings_all;
+      bool &any_plan = o.any_plan;
+      bool &any_filter = o.any_filter;
+      for (uint32_t q = q_lo; q < q_hi; q++) {
+        q_sq_begin[q] = (uint32_t)sqs.size();
+        SLG_REQUIRE(q_offsets[q + 1] >= q_offsets[q], "q_offsets not monotone");
+        const uint32_t t0 = q_offsets[q], nt = q_offsets[q + 1] - t0;
+        if (nt > SLG_MAX_QUERY_TERMS)
+          throw SlgError(SLG_ERR_UNSUPPORTED, "query " + std::to_string(q) + " has more than " +
+                                                  std::to_string(SLG_MAX_QUERY_TERMS) + " terms");
+        uint32_t fq = 0;  // doc filter of the query (0 none, id + 1)
+        if (q_filter && q_filter[q] >= 0) {
+          SLG_REQUIRE((size_t)q_filter[q] < filter_live.size() && filter_live[q_filter[q]],
+                      "unknown filter id in query " + std::to_string(q));
+          fq = (uint32_t)q_filter[q] + 1u;
+          any_filter = true;
+        }
+        // score plan of the query (query/planner.rs:113-153)
+        const int plan_kind = q_plan ? q_plan[q] : SLG_PLAN_SUM;
+        SLG_REQUIRE(plan_kind == SLG_PLAN_SUM || plan_kind == SLG_PLAN_DISMAX,
+                    "unknown score plan in query " + std::to_string(q));
+        const float tie = q_tie ? q_tie[q] : 0.0f;
+        // validate_tie_breaker (query/planner.rs:850-856); the threshold seed and the pruning bounds
+        // also rely on it: with tie in [0, 1] a DisMax is >= each of its non-negative leaves
+        SLG_REQUIRE(tie >= 0.0f && tie <= 1.0f,
+                    "tie breaker outside [0, 1] in query " + std::to_string(q));
+        uint32_t n_leaves = q_nleaves ? q_nleaves[q] : 0;
         for (uint32_t i = 0; i < nt; i++) {
-          const uint32_t tid = q_term_ids[(size_t)(t0 + i) * n_segs + s];
-          if (tid == SLG_NO_TERM) continue;
-          SLG_REQUIRE(tid < sh.n_terms, "term id out of range in query " + std::to_string(q));
-          const uint64_t off = sh.term_offsets[tid];
-          const uint32_t df = (uint32_t)(sh.term_offsets[tid + 1] - off);
-          if (df == 0) continue;  // wand.rs:441 filter(postings.len() > 0)
-          const float w = q_weights[t0 + i];
-          SLG_REQUIRE(std::isfinite(w), "non-finite weight in query " + std::to_string(q));
-          const uint32_t local = (uint32_t)terms.size() - sq.term_begin;
-          if (df > longest_df) {
-            longest_df = df;
-            longest = local;
-          }
-          terms.push_back(slg::TermRef{off, df, w, tid, q_leaf ? q_leaf[t0 + i] : i});
-          P += df;
+          const uint32_t lf = q_leaf ? q_leaf[t0 + i] : i;
+          SLG_REQUIRE(lf < 0x80000000u, "leaf index >= 2^31 in query " + std::to_string(q));
+          n_leaves = std::max(n_leaves, lf + 1u);
         }
-        sq.n_terms = (uint32_t)terms.size() - sq.term_begin;
-        if (sq.n_terms == 0) continue;
-        {
-          // Lists go to the device sorted by leaf (stable: a leaf's terms keep the term order in
-          // which the reference adds them, wand.rs:488-497).  plan 0 = the flat term-order sum,
-          // which is what Sum gives when no leaf holds two terms.
-          auto first = terms.begin() + sq.term_begin;
-          std::stable_sort(first, terms.end(),
-                           [](const slg::TermRef &a, const slg::TermRef &c) { return a.leaf < c.leaf; });
-          bool shared = false;
-          uint32_t present = 0;
-          for (uint32_t i = 0; i < sq.n_terms; i++) {
-            const bool fresh = i == 0 || first[i].leaf != first[i - 1].leaf;
-            present += fresh ? 1u : 0u;
-            shared = shared || !fresh;
+        if (k == 0) continue;  // wand.rs:413-416: k == 0 and no collector => no work
+        for (uint32_t s = 0; s < n_segs; s++) {
+          const SegHost &sh = *ix->segs[s];
+          slg::RoundQuery sq{};
+          sq.q = q;
+          sq.seg = s;
+          sq.filter = fq;
+          sq.term_begin = (uint32_t)terms.size();
+          uint64_t P = 0;
+          uint32_t longest = 0, longest_df = 0;
+          for (uint32_t i = 0; i < nt; i++) {
+            const uint32_t tid = q_term_ids[(size_t)(t0 + i) * n_segs + s];
+            if (tid == SLG_NO_TERM) continue;
+            SLG_REQUIRE(tid < sh.n_terms, "term id out of range in query " + std::to_string(q));
+            const uint64_t off = sh.term_offsets[tid];
+            const uint32_t df = (uint32_t)(sh.term_offsets[tid + 1] - off);
+            if (df == 0) continue;  // wand.rs:441 filter(postings.len() > 0)
+            const float w = q_weights[t0 + i];
+            SLG_REQUIRE(std::isfinite(w), "non-finite weight in query " + std::to_string(q));
+            const uint32_t local = (uint32_t)terms.size() - sq.term_begin;
+            if (df > longest_df) {
+              longest_df = df;
+              longest = local;
+            }
+            terms.push_back(slg::TermRef{off, df, w, tid, q_leaf ? q_leaf[t0 + i] : i});
+            P += df;
           }
-          sq.plan = plan_kind == SLG_PLAN_DISMAX ? 2u : (shared ? 1u : 0u);
-          sq.tie = tie;
-          sq.max_init = present < n_leaves ? 0.0f : -INFINITY;
-          sq.n_leaves = n_leaves;
-          if (sq.plan) any_plan = true;
-        }
-        // ---- threshold seed (kernels: RoundQuery::theta0) = max_t w_t * champ[t][rank(k)]: an
-        // exact lower bound of the k-th best score whenever no weight is negative (a doc's total
-        // is then >= each of its contributions) and no doc filter can reject the champions ----
-        float seed = 0.0f;
-        if (!sh.champ.empty() && k <= 1024u && fq == 0) {
-          bool nonneg = true;
-          for (uint32_t i = 0; i < sq.n_terms; i++) {
-            const slg::TermRef &tr = terms[sq.term_begin + i];
-            if (!(tr.weight >= 0.0f)) nonneg = false;
-            if (tr.weight > 0.0f)
-              seed = std::max(seed, tr.weight * sh.champ[(size_t)tr.term * slg::kChampions + slg::champ_index(k)]);
-          }
-          if (!nonneg) seed = 0.0f;
-        }
-        sq.theta0 = seed;
-        // ---- MaxScore classification (strategies Wand / Bmw; exact).  On by default for batches
-        // that run on the multi kernel (a query with >= 5 terms), where probing the non-essential
-        // lists is cheaper than scoring them; SLG_MAXSCORE=1 / 0 forces it on / off ----
-        // theta0 = max_t w_t * champ[t][k-1] is a lower bound of the final k-th score
-        // (slg_score.hpp sets the same floor on the device).  Lists taken in ascending order of
-        // their maximum contribution ub_t = w_t * champ[t][0] are non-essential while the running
-        // sum of ub stays below theta0: a doc found only in them totals < theta0.
-        uint32_t ess_mask = sq.n_terms >= 32 ? 0xFFFFFFFFu : ((1u << sq.n_terms) - 1u);
-        if (strategy != SLG_STRATEGY_BM25 && seed > 0.0f && !plans_requested && sq.n_terms > 1 && maxscore_on) {
-          const float theta0 = seed;
-          std::vector<std::pair<float, uint32_t>> ub(sq.n_terms);
-          for (uint32_t i = 0; i < sq.n_terms; i++) {
-            const slg::TermRef &tr = terms[sq.term_begin + i];
-            ub[i] = {tr.weight * sh.champ[(size_t)tr.term * slg::kChampions], i};
-          }
+          sq.n_terms = (uint32_t)terms.size() - sq.term_begin;
+          if (sq.n_terms == 0) continue;
           {
-            std::sort(ub.begin(), ub.end());
-            double acc = 0.0;
-            for (uint32_t i = 0; i + 1 < sq.n_terms; i++) {  // at least one list stays essential
-              acc += (double)ub[i].first;
-              // margin: f32 sums of the real contributions may round up by a few ulps
-              if (acc * (1.0 + 1e-5) < (double)theta0)
-                ess_mask &= ~(1u << ub[i].second);
-              else
-                break;
+            // Lists go to the device sorted by leaf (stable: a leaf's terms keep the term order in
+            // which the reference adds them, wand.rs:488-497).  plan 0 = the flat term-order sum,
+            // which is what Sum gives when no leaf holds two terms.
+            auto first = terms.begin() + sq.term_begin;
+            std::stable_sort(first, terms.end(),
+                             [](const slg::TermRef &a, const slg::TermRef &c) { return a.leaf < c.leaf; });
+            bool shared = false;
+            uint32_t present = 0;
+            for (uint32_t i = 0; i < sq.n_terms; i++) {
+              const bool fresh = i == 0 || first[i].leaf != first[i - 1].leaf;
+              present += fresh ? 1u : 0u;
+              shared = shared || !fresh;
+            }
+            sq.plan = plan_kind == SLG_PLAN_DISMAX ? 2u : (shared ? 1u : 0u);
+            sq.tie = tie;
+            sq.max_init = present < n_leaves ? 0.0f : -INFINITY;
+            sq.n_leaves = n_leaves;
+            if (sq.plan) any_plan = true;
+          }
+          // ---- threshold seed (kernels: RoundQuery::theta0) = max_t w_t * champ[t][rank(k)]: an
+          // exact lower bound of the k-th best score whenever no weight is negative (a doc's total
+          // is then >= each of its contributions) and no doc filter can reject the champions ----
+          float seed = 0.0f;
+          if (!sh.champ.empty() && k <= 1024u && fq == 0) {
+            bool nonneg = true;
+            for (uint32_t i = 0; i < sq.n_terms; i++) {
+              const slg::TermRef &tr = terms[sq.term_begin + i];
+              if (!(tr.weight >= 0.0f)) nonneg = false;
+              if (tr.weight > 0.0f)
+                seed = std::max(seed, tr.weight * sh.champ[(size_t)tr.term * slg::kChampions + slg::champ_index(k)]);
+            }
+            if (!nonneg) seed = 0.0f;
+          }
+          sq.theta0 = seed;
+          // ---- MaxScore classification (strategies Wand / Bmw; exact).  On by default for batches
+          // that run on the multi kernel (a query with >= 5 terms), where probing the non-essential
+          // lists is cheaper than scoring them; SLG_MAXSCORE=1 / 0 forces it on / off ----
+          // theta0 = max_t w_t * champ[t][k-1] is a lower bound of the final k-th score
+          // (slg_score.hpp sets the same floor on the device).  Lists taken in ascending order of
+          // their maximum contribution ub_t = w_t * champ[t][0] are non-essential while the running
+          // sum of ub stays below theta0: a doc found only in them totals < theta0.
+          uint32_t ess_mask = sq.n_terms >= 32 ? 0xFFFFFFFFu : ((1u << sq.n_terms) - 1u);
+          if (strategy != SLG_STRATEGY_BM25 && seed > 0.0f && !plans_requested && sq.n_terms > 1 && maxscore_on) {
+            const float theta0 = seed;
+            std::vector<std::pair<float, uint32_t>> ub(sq.n_terms);
+            for (uint32_t i = 0; i < sq.n_terms; i++) {
+              const slg::TermRef &tr = terms[sq.term_begin + i];
+              ub[i] = {tr.weight * sh.champ[(size_t)tr.term * slg::kChampions], i};
+            }
+            {
+              std::sort(ub.begin(), ub.end());
+              double acc = 0.0;
+              for (uint32_t i = 0; i + 1 < sq.n_terms; i++) {  // at least one list stays essential
+                acc += (double)ub[i].first;
+                // margin: f32 sums of the real contributions may round up by a few ulps
+                if (acc * (1.0 + 1e-5) < (double)theta0)
+                  ess_mask &= ~(1u << ub[i].second);
+                else
+                  break;
+              }
             }
           }
-        }
-        sq.ess_mask = ess_mask;
-        // the round planner works on the essential lists only
-        P = 0;
-        longest = 0;
-        longest_df = 0;
-        uint64_t P_all = 0;
-        for (uint32_t i = 0; i < sq.n_terms; i++) {
-          const uint32_t df = terms[sq.term_begin + i].df;
-          P_all += df;
-          if (!((ess_mask >> i) & 1u)) continue;
-          P += df;
-          if (df > longest_df) {
-            longest_df = df;
-            longest = i;
+          sq.ess_mask = ess_mask;
+          // the round planner works on the essential lists only
+          P = 0;
+          longest = 0;
+          longest_df = 0;
+          uint64_t P_all = 0;
+          for (uint32_t i = 0; i < sq.n_terms; i++) {
+            const uint32_t df = terms[sq.term_begin + i].df;
+            P_all += df;
+            if (!((ess_mask >> i) & 1u)) continue;
+            P += df;
+            if (df > longest_df) {
+              longest_df = df;
+              longest = i;
+            }
           }
+          // block skipping pays where a 64-posting block of a non-essential list usually holds no
+          // candidate doc: a block spans 64 * N / df docs, which hold 64 * P / df essential postings
+          // on average; blocks are tested only below 2 (>= e^-2 = 13 % of them can be skipped).
+          // Config 3's lists are all of similar density (>= 64 per block): no test, no cost.
+          sq.skip_mask = 0;
+          if (tn.block_max)
+            for (uint32_t i = 0; i < sq.n_terms && i < 32; i++) {
+              const uint64_t df = terms[sq.term_begin + i].df;
+              if (!((ess_mask >> i) & 1u) && 64ull * P < 2ull * df) sq.skip_mask |= 1u << i;
+            }
+          o.n_noness += P_all - P;
+          b->q_postings[q] += P_all;
+          o.n_postings += P_all;
+          o.n_ess += P;
+          sq.longest = longest;
+          o.max_terms = std::max(o.max_terms, sq.n_terms);
+          sqs.push_back(sq);
+          sq_postings.push_back(P);
+          sq_postings_all.push_back(P_all);
         }
-        // block skipping pays where a 64-posting block of a non-essential list usually holds no
-        // candidate doc: a block spans 64 * N / df docs, which hold 64 * P / df essential postings
-        // on average; blocks are tested only below 2 (>= e^-2 = 13 % of them can be skipped).
-        // Config 3's lists are all of similar density (>= 64 per block): no test, no cost.
-        sq.skip_mask = 0;
-        if (tn.block_max)
-          for (uint32_t i = 0; i < sq.n_terms && i < 32; i++) {
-            const uint64_t df = terms[sq.term_begin + i].df;
-            if (!((ess_mask >> i) & 1u) && 64ull * P < 2ull * df) sq.skip_mask |= 1u << i;
-          }
-        b->n_postings_nonessential += P_all - P;
-        b->q_postings[q] += P_all;
-        b->n_postings += P_all;
-        b->n_postings_essential += P;
-        sq.longest = longest;
-        b->max_terms = std::max(b->max_terms, sq.n_terms);
-        sqs.push_back(sq);
-        sq_postings.push_back(P);
-        sq_postings_all.push_back(P_all);
+      }
+    };
+    {
+      const uint64_t work = (uint64_t)nq * n_segs;
+      uint32_t n_thr = 1;
+      if (work >= 16384) n_thr = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(8, std::max(1u, std::thread::hardware_concurrency())), nq / 512);
+      n_thr = std::max(1u, n_thr);
+      std::vector<Pass1Out> parts(n_thr);
+      if (n_thr == 1) {
+        plan_range(0, nq, parts[0]);
+      } else {
+        std::vector<std::thread> pool;
+        for (uint32_t t = 0; t < n_thr; t++)
+          pool.emplace_back([&, t] {
+            try {
+              plan_range((uint32_t)((uint64_t)nq * t / n_thr), (uint32_t)((uint64_t)nq * (t + 1) / n_thr), parts[t]);
+            } catch (...) {
+              parts[t].err = std::current_exception();
+            }
+          });
+        for (auto &th : pool) th.join();
+        for (auto &pt : parts)
+          if (pt.err) std::rethrow_exception(pt.err);
+      }
+      for (uint32_t t = 0; t < n_thr; t++) {
+        Pass1Out &pt = parts[t];
+        const uint32_t sq_base = (uint32_t)sqs.size(), term_base = (uint32_t)terms.size();
+        const uint32_t q_lo = n_thr == 1 ? 0u : (uint32_t)((uint64_t)nq * t / n_thr);
+        const uint32_t q_hi = n_thr == 1 ? nq : (uint32_t)((uint64_t)nq * (t + 1) / n_thr);
+        for (uint32_t q = q_lo; q < q_hi; q++) q_sq_begin[q] += sq_base;
+        if (t == 0 && n_thr == 1) {
+          sqs.swap(pt.sqs);
+          terms.swap(pt.terms);
+          sq_postings.swap(pt.sq_postings);
+          sq_postings_all.swap(pt.sq_postings_all);
+        } else {
+          for (auto &sq : pt.sqs) sq.term_begin += term_base;
+          sqs.insert(sqs.end(), pt.sqs.begin(), pt.sqs.end());
+          terms.insert(terms.end(), pt.terms.begin(), pt.terms.end());
+          sq_postings.insert(sq_postings.end(), pt.sq_postings.begin(), pt.sq_postings.end());
+          sq_postings_all.insert(sq_postings_all.end(), pt.sq_postings_all.begin(), pt.sq_postings_all.end());
+        }
+        b->n_postings += pt.n_postings;
+        b->n_postings_essential += pt.n_ess;
+        b->n_postings_nonessential += pt.n_noness;
+        b->max_terms = std::max(b->max_terms, pt.max_terms);
+        any_plan = any_plan || pt.any_plan;
+        any_filter = any_filter || pt.any_filter;
       }
     }
     q_sq_begin[nq] = (uint32_t)sqs.size();
@@ -1058,6 +1140,14 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
             tn.uniform_round_target ? tn.uniform_round_target : dflt, slg::kUniCap));
       } else {
         round_target = std::max<uint32_t>(64, std::min<uint32_t>(tn.multi_round_target, slg::kMultiCap));
+        // the many-term kernel's bitmap covers a window of kSpan docs: a round whose essential
+        // postings are spread over more is cut into chunks, each paying the round's fixed costs.
+        // Sparse sub-queries get rounds that fit the window (postings per round <= 0.85 * kSpan *
+        // density of the essential lists)
+        const double dens = (double)sq_postings[i] / (double)std::max<uint32_t>(1u, ix->segs[sq.seg]->n_docs);
+        const double fit = 0.85 * (double)slg::kSpan * dens;  // (0.65 / 0.75 / 0.85 / 0.95 / 1.0 measured on config 3:
+                                                               //  7.88 / 7.54 / 7.35 / 7.76 / 8.20 ms; no rule: 8.69)
+        if (fit < (double)round_target) round_target = (uint32_t)std::max(64.0, fit);
       }
       // a round holds <= ~round_target postings of the essential lists (register slots) and
       // <= ~probe_target postings overall (non-essential lists are streamed per round), so
@@ -1160,12 +1250,26 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     }
     const size_t o_bc = place<uint32_t>(cur, bnd_coarse.size());
     const size_t total = (cur + 15) & ~(size_t)15;
-    // (a blocking hipMemcpy from pageable memory, outside any lock.  Measured against a pinned
-    // image copied asynchronously on the batch's stream in front of the kernels: that variant
-    // served 5.2-7.4M queries/s from 4-8 caller threads where this one serves 8.0-8.8M — the
-    // stream-ordered copy delays each batch's first kernel)
-    std::vector<unsigned char> hvec(total ? total : 16);
-    void *hbuf = hvec.data();
+    // (a copy from pageable memory that the caller waits for, outside any lock, on a stream of its
+    // own.  Measured against a pinned image copied asynchronously on the batch's stream in front
+    // of the kernels: that variant served 5.2-7.4M queries/s from 4-8 caller threads where this
+    // one serves 8.0-8.8M — the stream-ordered copy delays each batch's first kernel)
+    // (staging image kept per caller thread: a fresh 26 MB vector per config-4 batch spent half of
+    // its 5 ms in page faults)
+    // Pinned, so the copy is one DMA at PCIe speed (26 MB: 0.6 ms; from pageable memory 1-6 ms).
+    // Never freed: a thread's image lives as long as the process (freeing from a thread_local
+    // destructor would race the HIP runtime's own teardown).
+    static thread_local void *h_image = nullptr;
+    static thread_local size_t h_image_bytes = 0;
+    if (h_image_bytes < (total ? total : 16)) {
+      if (h_image) (void)hipHostFree(h_image);
+      h_image = nullptr;
+      h_image_bytes = 0;
+      const size_t want = std::max<size_t>((total * 5) / 4, 1u << 20);
+      SLG_HIP(hipHostMalloc(&h_image, want, hipHostMallocDefault));
+      h_image_bytes = want;
+    }
+    void *hbuf = h_image;
     unsigned char *hb = static_cast<unsigned char *>(hbuf);
     if (!sqs.empty()) std::memcpy(hb + o_sq, sqs.data(), sqs.size() * sizeof(slg::RoundQuery));
     if (!terms.empty()) std::memcpy(hb + o_terms, terms.data(), terms.size() * sizeof(slg::TermRef));
@@ -1175,7 +1279,12 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     if (!qrefs.empty()) std::memcpy(hb + o_q, qrefs.data(), qrefs.size() * sizeof(slg::QueryRef));
     if (!bnd_coarse.empty()) std::memcpy(hb + o_bc, bnd_coarse.data(), bnd_coarse.size() * 4);
     b->d_desc.alloc_pooled(&ix->pool, total);
-    SLG_HIP(hipMemcpy(b->d_desc.p, hbuf, total, hipMemcpyHostToDevice));
+    {
+      hipStream_t us = ix->upload_streams[std::hash<std::thread::id>()(std::this_thread::get_id()) %
+                                          slg_index::kUploadStreams];
+      SLG_HIP(hipMemcpyAsync(b->d_desc.p, hbuf, total, hipMemcpyHostToDevice, us));
+      SLG_HIP(hipStreamSynchronize(us));
+    }
     unsigned char *db = b->d_desc.as<unsigned char>();
     b->d_sq = reinterpret_cast<const slg::RoundQuery *>(db + o_sq);
     b->d_terms = reinterpret_cast<const slg::TermRef *>(db + o_terms);
@@ -1184,7 +1293,6 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     b->d_slice_order = reinterpret_cast<const uint32_t *>(db + o_sord);
     b->d_queries = reinterpret_cast<const slg::QueryRef *>(db + o_q);
     b->d_bnd_coarse = reinterpret_cast<const uint32_t *>(db + o_bc);
-
     b->d_bounds.alloc_pooled(&ix->pool, (size_t)n_bounds * 4);
     b->d_rdoc.alloc_pooled(&ix->pool, (size_t)n_bnd * 4);
     b->d_slice_desc.alloc_pooled(&ix->pool, (size_t)b->n_slices * sizeof(slg::SliceDesc));

@@ -128,6 +128,36 @@ def test_block_skipping_skewed_queries(gpu, oracle, tuning):
                     assert probed > 0 and skipped > probed // 3, (probed, skipped)
 
 
+def test_many_subqueries_are_planned_by_several_threads(gpu, oracle):
+    """Batches of >= 16384 sub-queries (queries x segments) are planned by several host threads,
+    each into its own vectors, stitched in query order (slg_batch_prepare_plan pass 1): 6000
+    ragged queries x 3 segments with weights, an absent term here and there, stats included —
+    every query against the oracle, both kernels."""
+    rng = np.random.default_rng(99)
+    vocab = 300
+    segs = [random_segment(rng, n, vocab, 12, zipf=True) for n in (9000, 4000, 14000)]
+    nq = 6000
+    lens = rng.integers(1, 8, size=nq)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+    terms = np.empty((int(offs[-1]), 3), dtype=np.uint32)
+    for q in range(nq):
+        t = rng.choice(vocab, size=int(lens[q]), replace=False)
+        for s_ in range(3):
+            terms[offs[q]:offs[q + 1], s_] = t
+    terms[rng.random(terms.shape) < 0.02] = 0xFFFFFFFF  # SLG_NO_TERM: the segment lacks the term
+    w = (rng.random(int(offs[-1])) * 2 + 0.25).astype(np.float32)
+    for k in (11, 101):
+        want = oracle.search_batch(segs, offs, terms.reshape(-1), w, k, strategy=oracle.BM25, n_threads=8,
+                                   want_stats=True)
+        with gpu.GpuIndex(segs) as ix:
+            for strat in (gpu.Wand, gpu.Bm25):
+                got = ix.search_batch(offs, terms.reshape(-1), w, k, strat, want_stats=True)
+                assert_same_hits(got[:4], want[:4], 0.0, f"18000 sub-queries k={k} strategy {strat}")
+                if strat == gpu.Bm25:
+                    assert [got[4][q].postings_advanced for q in range(nq)] == \
+                        [want[4][q].postings_advanced for q in range(nq)]
+
+
 # ---- config 4: 8 index shards, batch 8192, all-gather + merge -----------------------------------------
 def test_config4_eight_shards_merge_on_one_gpu(gpu, oracle):
     """Config 4's data path on one GPU: the 8 shards bench.py --config c4 builds (1.25M docs each,

@@ -1,31 +1,28 @@
-"""Host-side cost of the C ABI per 1024-query batch (config 2): plan + upload (slg_batch_prepare),
-the full prepare -> run -> fetch -> destroy cycle, and the same cycle from several host threads."""
-import sys, os, time, threading
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""Host planning time (slg_batch_prepare incl. the descriptor upload) per batch, one caller thread.
+usage (GPU box): python tools/prep_time.py"""
+import os, sys, time
 import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from searchlite_amd import corpus, searcher
-seg = corpus.zipf_segment(1_000_000, 1 << 18, seed=42)
-offs, terms, w = corpus.zipf_queries(1024, 3, seed=7, vocab=1 << 18)
-ix = searcher.GpuIndex([seg])
-for _ in range(3):
-    b = ix.prepare(offs, terms, w, 11); b.run(); b.sync(); b.close()
-N = 40
-t = time.perf_counter()
-for _ in range(N):
-    b = ix.prepare(offs, terms, w, 11)
-    b.close()
-t1 = (time.perf_counter() - t) / N
-def cycle(n, stream=None):
-    import torch
-    s = torch.cuda.Stream()
-    for _ in range(n):
-        b = ix.prepare(offs, terms, w, 11); b.set_stream(s.cuda_stream); b.run(); b.fetch(); b.close()
-t = time.perf_counter(); cycle(N); t2 = (time.perf_counter() - t) / N
-print(f"prepare+destroy {t1*1e3:.3f} ms; prepare+run+fetch+destroy {t2*1e3:.3f} ms -> {1024/t2:.0f} q/s (1 host thread)")
-for nth in (2, 4, 8):
-    th = [threading.Thread(target=cycle, args=(N,)) for _ in range(nth)]
-    t = time.perf_counter()
-    for x in th: x.start()
-    for x in th: x.join()
-    dt = time.perf_counter() - t
-    print(f"{nth} host threads: {1024 * N * nth / dt:.0f} q/s end to end (host buffers in, host buffers out)")
+
+def run(name, segs, nq, T, k, vocab):
+    offs, terms, w = corpus.zipf_queries(nq, T, seed=7, vocab=vocab)
+    if len(segs) > 1:
+        terms = np.repeat(terms.reshape(-1, 1), len(segs), axis=1).reshape(-1)
+    with searcher.GpuIndex(segs) as ix:
+        ts = []
+        for _ in range(6):
+            t0 = time.perf_counter()
+            b = ix.prepare(offs, terms, w, k, searcher.Wand)
+            t1 = time.perf_counter()
+            info = b.info()
+            b.close()
+            ts.append((t1 - t0) * 1e3)
+        print(f"{name}: prepare {min(ts):.2f} ms (median {sorted(ts)[3]:.2f}), slices {info['n_slices']}, postings {info['n_postings']}", flush=True)
+
+s2 = corpus.zipf_segment(1_000_000, 1 << 18, seed=42, n_threads=16)
+run("c2 (1024 x 3, 1M docs)", [s2], 1024, 3, 11, 1 << 18)
+del s2
+s4 = [corpus.zipf_segment(1_250_000, 1 << 20, seed=43 + r, n_threads=16) for r in range(int(os.environ.get("SEGS", "2")))]
+run("c4 one rank of 8 (8192 x 5, 1 segment of 1.25M)", s4[:1], 8192, 5, 101, 1 << 20)
+run(f"c4 {len(s4)} segments", s4, 8192, 5, 101, 1 << 20)
