@@ -1135,7 +1135,32 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
         // every list is padded to a 64-lane slot (half a slot wasted per list on average): aim
         // at (slots - terms + 1) slots of postings; measured optimum on config 2 (384 for 3 terms)
         const uint32_t t = sq.n_terms;
-        const uint32_t dflt = 64u * (slg::kUniSlots > t ? slg::kUniSlots - t : 0u) + 64u;
+        uint32_t dflt = 64u * (slg::kUniSlots > t ? slg::kUniSlots - t : 0u) + 64u;
+        if (!tn.uniform_round_target && t > 1) {
+          // A round that needs more than 8 slots is streamed in chunks at 2-3x the cost, so the
+          // target follows the sub-query's own mix of list lengths: the largest R (steps of 16)
+          // whose expected slots stay under 8 with 1.6 sigma to spare.  The longest list is cut at
+          // exact strides (its count is R * f); every other list's count c is roughly Poisson
+          // around R * f: ceil(c / 64) has mean c/64 + 1/2 and variance c/4096 + 1/12.
+          const double Pd = (double)sq_postings[i];
+          uint32_t best = 64;
+          for (uint32_t R = 96; R <= (uint32_t)slg::kUniCap; R += 16) {
+            double mu = 0.0, var = 0.0;
+            for (uint32_t j = 0; j < t; j++) {
+              const double c = (double)R * (double)terms[sq.term_begin + j].df / Pd;
+              if (j == sq.longest) {
+                mu += std::ceil(c / 64.0);
+              } else {
+                mu += c / 64.0 + 0.5;
+                var += c / 4096.0 + 1.0 / 12.0;
+              }
+            }
+            if (mu + 1.6 * std::sqrt(var) > 8.3) break;  // (1.0 / 1.3 / 1.6 / 2.0 / 2.5 sigma: 0.1024 / 0.1011 /
+                                                         //  0.1006 / 0.1019 / 0.1039 ms on config 2; fixed 384: 0.1042)
+            best = R;
+          }
+          dflt = best;
+        }
         round_target = std::max<uint32_t>(48, std::min<uint32_t>(
             tn.uniform_round_target ? tn.uniform_round_target : dflt, slg::kUniCap));
       } else {
