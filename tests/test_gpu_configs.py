@@ -158,6 +158,24 @@ def test_many_subqueries_are_planned_by_several_threads(gpu, oracle):
                         [want[4][q].postings_advanced for q in range(nq)]
 
 
+def test_planner_threads_report_bad_input(gpu):
+    """An out-of-range term id deep inside a batch that is planned by several threads comes back
+    as SLG_ERR_INVALID from the caller's thread (the worker's exception is carried over)."""
+    import searchlite_amd as sa
+    rng = np.random.default_rng(5)
+    seg = random_segment(rng, 3000, 50, 8)
+    nq = 20000
+    offs, terms, w = random_queries(rng, nq, 2, 50)
+    terms = terms.copy()
+    terms[2 * 17001, 0] = 4000  # no such term
+    with gpu.GpuIndex([seg]) as ix:
+        with pytest.raises(sa.SlgError) as e:
+            ix.search_batch(offs, terms.reshape(-1), w, 5, gpu.Wand)
+        assert "term id out of range in query 17001" in str(e.value)
+        ok = ix.search_batch(offs[:11], terms.reshape(-1)[:20], w[:20], 5, gpu.Wand)  # the index is still usable
+        assert ok[3].shape == (10,)
+
+
 # ---- config 4: 8 index shards, batch 8192, all-gather + merge -----------------------------------------
 def test_config4_eight_shards_merge_on_one_gpu(gpu, oracle):
     """Config 4's data path on one GPU: the 8 shards bench.py --config c4 builds (1.25M docs each,
