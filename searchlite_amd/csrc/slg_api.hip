@@ -1392,7 +1392,9 @@ int slg_batch_run(slg_batch *b) {
       pp.nq = b->nq;
       pp.n_boundaries = b->n_boundaries;
       pp.n_slices = b->n_slices;
-      const uint64_t pthreads = std::max<uint64_t>(std::max<uint64_t>((uint64_t)b->n_boundaries * 8, (uint64_t)b->nq + 1), b->n_slices);
+      pp.tpb_shift = b->max_terms <= 4 ? 2u : 3u;
+      const uint64_t pthreads = std::max<uint64_t>(
+          std::max<uint64_t>((uint64_t)b->n_boundaries << pp.tpb_shift, (uint64_t)b->nq + 1), b->n_slices);
       hipLaunchKernelGGL(slg::partition_rounds_kernel, dim3((uint32_t)((pthreads + 255) / 256)),
                          dim3(256), 0, st, pp);
       SLG_HIP(hipGetLastError());

@@ -45,9 +45,10 @@ struct RoundPartParams {
   uint32_t nq;
   uint32_t n_boundaries;
   uint32_t n_slices;
+  uint32_t tpb_shift;  // log2(threads per boundary): 2 when no sub-query has more than 4 lists, else 3
 };
 
-// 8 threads per boundary: thread u handles lists u, u+8, ...
+// 4 or 8 threads per boundary: thread u handles lists u, u + threads, ...
 static __global__ void __launch_bounds__(256) partition_rounds_kernel(RoundPartParams p) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid < p.nq) p.q_scored[gid] = 0;
@@ -71,7 +72,8 @@ static __global__ void __launch_bounds__(256) partition_rounds_kernel(RoundPartP
     d.cand_hi = s.cand_hi;
     p.slice_desc[gid] = d;
   }
-  const uint32_t b = gid >> 3, u = gid & 7;
+  const uint32_t tpb = 1u << p.tpb_shift;
+  const uint32_t b = gid >> p.tpb_shift, u = gid & (tpb - 1u);
   if (b >= p.n_boundaries) return;
   // the sub-query that owns boundary b: the last one whose first boundary is <= b (bnd_begin
   // ascends).  The host uploads it for every 32nd boundary (a per-boundary table was most of the
@@ -87,7 +89,7 @@ static __global__ void __launch_bounds__(256) partition_rounds_kernel(RoundPartP
   const bool first = j == 0, last = j >= s.n_rounds || posL >= L.df;
   uint32_t target = 0;
   if (!first && !last) target = docs[L.off + posL];
-  for (uint32_t t = u; t < s.n_terms; t += 8) {
+  for (uint32_t t = u; t < s.n_terms; t += tpb) {
     const TermRef me = p.terms[s.term_begin + t];
     uint32_t out;
     if (first) {
