@@ -36,7 +36,7 @@ t0s -= b0
 t1s -= b0
 span = t1s.max()
 print("kernel span (10 ns ticks)", span, "sum of slice durations", int((t1s - t0s).sum()),
-      "=> mean waves in flight", float((t1s - t0s).sum()) / span, "of", 256 * 4 * 5, "wave slots at 5/SIMD")
+      "=> mean waves in flight", float((t1s - t0s).sum()) / span, "of", 256 * 4 * 6, "wave slots at 6/SIMD")
 edges = np.linspace(0, span, 21)
 for a, b in zip(edges[:-1], edges[1:]):
     mid = (a + b) / 2
