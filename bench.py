@@ -66,6 +66,8 @@ def parse_args():
     ap.add_argument("--terms", type=int, default=0)
     ap.add_argument("--limit", type=int, default=0)
     ap.add_argument("--strategy", default="wand", choices=["bm25", "wand", "bmw"])
+    ap.add_argument("--regions", type=int, default=9,
+                    help="host-inclusive leg: the timed --steps region is repeated this many times; value = median")
     ap.add_argument("--rotate", type=int, default=8, help="distinct query sets the steps rotate over")
     ap.add_argument("--host-threads", type=int, default=8,
                     help="caller threads of the host-inclusive leg (each: prepare -> run -> fetch)")
@@ -369,21 +371,31 @@ def main():
             for t in self.threads:
                 t.join()
 
-    value = ms_per_step = None
+    value = ms_per_step = value_spread = None
     if not rerank and not args.kernel_leg_only:
         pool = HostPool()
         # untimed: --warmup steps, and at least three batches per caller thread so that every
         # thread has run and the library's buffer pool holds a set of work buffers per batch in flight
         host_warm = max(args.warmup, 3 * n_thr)
         pool.run(host_warm, 0)
-        fence()
-        t1 = time.perf_counter()
-        pool.run(args.steps, host_warm)
-        fence()
-        elapsed = max_over_ranks(time.perf_counter() - t1)
+        # the timed region = EXACTLY --steps steps between two fences; it is repeated --regions times
+        # (a 20-step region is 2.5 ms: 2.5 steps per caller thread with the pipeline's fill and drain
+        # inside) and `value` is the MEDIAN region; the spread is reported beside it
+        region_s = []
+        for r in range(max(1, args.regions)):
+            fence()
+            t1 = time.perf_counter()
+            pool.run(args.steps, host_warm + r * args.steps)
+            fence()
+            region_s.append(max_over_ranks(time.perf_counter() - t1))
         pool.close()
+        elapsed = float(np.median(region_s))
         ms_per_step = elapsed / args.steps * 1e3
         value = nq * world / (elapsed / args.steps)
+        value_spread = {"regions": len(region_s), "steps_per_region": args.steps,
+                        "min": round(nq * world / (max(region_s) / args.steps), 1),
+                        "max": round(nq * world / (min(region_s) / args.steps), 1),
+                        "value_is": "median over the regions"}
 
     # ---- leg 2: device-resident pre-planned batches, rotating, `inflight` streams ----
     inflight = max(1, args.inflight) if not rerank else 1
@@ -490,6 +502,7 @@ def main():
             "metric": "queries/sec at top-10 (batch=1024) + achieved HBM GB/s vs peak",
             "value": round(value, 1), "unit": "queries/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "value_spread": value_spread,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n_docs} synthetic Zipf docs (avg 256 tokens, V={vocab}, "
@@ -517,6 +530,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_measured_in_run": False,
                          "kernel": "score_uniform_kernel" if T <= 4 else "score_multi_kernel",
                          "kernel_ms": round(kern_avg_ms, 4), "launches": n_launch,
                          "algorithmic_bytes_per_launch": int(alg_bytes),
@@ -537,6 +551,34 @@ def main():
                              "frac_of_hbm_peak": round(rr_bytes / (rr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              "note": "BM25 top-1000 candidates reranked by cosine (dot of unit vectors) "
                                      "with alpha=0.5 blend to top-10; value = whole pipeline"}
+            # BASELINE.json labels config 5 "(MFMA path)": the same device candidates through the
+            # 2-clause cosine rerank, whose [candidates x clauses] products run on v_mfma_f32_16x16x4_f32
+            q2 = torch.from_numpy(np.stack([corpus.unit_vectors(nq, args.dim, seed=12),
+                                            corpus.unit_vectors(nq, args.dim, seed=13)], axis=1)).cuda()
+            a2 = torch.full((nq, 2), 0.5, dtype=torch.float32, device="cuda")
+            n_mf = max(4, min(args.steps, 16))
+            me_a = [torch.cuda.Event(enable_timing=True) for _ in range(n_mf)]
+            me_b = [torch.cuda.Event(enable_timing=True) for _ in range(n_mf)]
+            for i in range(-2, n_mf):
+                d = d_res[i % n_sets]
+                if i >= 0:
+                    me_a[i].record()
+                index.rerank_multi_batch_device(nq, 2, q2.data_ptr(), a2.data_ptr(), None, d[0], d[1], d[2], d[3],
+                                                k, k_out, r_doc.data_ptr(), r_seg.data_ptr(), r_score.data_ptr(),
+                                                r_vec.data_ptr(), r_count.data_ptr())
+                if i >= 0:
+                    me_b[i].record()
+            torch.cuda.synchronize()
+            mf_ms = sum(a.elapsed_time(b_) for a, b_ in zip(me_a, me_b)) / n_mf
+            mf_bytes = 4 * args.dim * cands + 8 * cands + 2 * 4 * args.dim * nq
+            out["rerank_mfma"] = {"kernel": "rerank_multi_kernel (2 cosine clauses, v_mfma_f32_16x16x4_f32)",
+                                  "kernel_ms": round(mf_ms, 4), "launches": n_mf, "clauses": 2,
+                                  "algorithmic_bytes": mf_bytes,
+                                  "achieved_GBps": round(mf_bytes / (mf_ms * 1e-3) / 1e9, 1),
+                                  "frac_of_hbm_peak": round(mf_bytes / (mf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  "flops": 2 * 2 * args.dim * cands,
+                                  "note": "HBM row-gather bound (SURVEY 8d): every candidate row is read once for "
+                                          "both clauses; the matrix cores do the contraction"}
 
     # ---- parity spot-check + CPU baseline (rank 0; the baseline at N = 1 only) ----
     if rank == 0:
@@ -608,8 +650,20 @@ def main():
             na = min(ncpu, 4 * cores)
             _, secs_a = O.search_batch_faithful([seg], offs[:na + 1], terms[:na * T], w[:na * T], k,
                                                 strategy=ostrat, n_threads=cores)
+            # Baseline B is `wand` for config 2 and `bmw` (block 128, postings.rs:11) for
+            # config 3; the other pruned strategy is timed beside it on the same sample
+            other = O.BMW if ostrat != O.BMW else O.WAND
+            reps_o, t_o = 0, 0.0
+            while t_o < 4.0 and reps_o < 20:
+                tc = time.perf_counter()
+                O.search_batch([seg], co, ct, cw, k, strategy=other, block_size=128, n_threads=cores,
+                               cache_min_len=True)
+                t_o += time.perf_counter() - tc
+                reps_o += 1
+            other_rate = ncpu * reps_o / t_o
             out["cpu_baseline"] = {
                 "value": round(strict, 1), "unit": "queries/s", "cores": cores, "kind": "port",
+                ("bmw_block128_value" if other == O.BMW else "wand_value"): round(other_rate, 1),
                 "sample": f"{ncpu} queries of query set 0 x {reps_c} reps, oracle "
                           f"{args.strategy} (C restatement of searchlite-core's scorer, "
                           f"pre-decoded postings, cached doc lengths and min_doc_len), "

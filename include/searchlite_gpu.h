@@ -94,10 +94,18 @@ typedef struct {
   uint32_t vec_rows;
 } slg_segment_desc;
 
-/* query/wand.rs:45-50 QueryStats, per query: brute-force accounting (wand.rs:472,500-503) of the
- * work the device did — scored_docs = candidates_examined = distinct docs that got a score (under
- * pruning: docs of the essential lists), postings_advanced = postings of the query's lists minus
- * those block skipping never loaded.  Not the reference's wand_loop pivot counters. */
+/* query/wand.rs:45-50 QueryStats, per query, with brute_force's accounting (wand.rs:472,500-503)
+ * applied to the work the device did:
+ *   scored_docs = candidates_examined = distinct docs that got a score.  SLG_STRATEGY_BM25: every
+ *     doc holding a query term (tombstoned docs included: accept() runs at top-k insertion) — the
+ *     count brute_force reports.  SLG_STRATEGY_WAND / _BMW: docs of the ESSENTIAL lists only (the
+ *     MaxScore classification never scores a doc found in non-essential lists alone);
+ *   postings_advanced = postings of the query's lists minus those block skipping never loaded.
+ * Under Wand / Bmw these are NOT the reference's wand_loop counters (wand.rs:826-835, 883-891 count
+ * the pivot sequence of its cursors, which the device does not walk): a caller that derives
+ * total_hits_estimate from them gets a different (larger, closer to the true match count) estimate
+ * than searchlite's CPU path, whose own figure under Wand / Bmw already depends on what pruning
+ * skipped.  Only the Bm25 numbers are comparable across the two paths. */
 typedef struct {
   uint64_t scored_docs;
   uint64_t candidates_examined;

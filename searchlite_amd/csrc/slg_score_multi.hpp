@@ -1,4 +1,4 @@
-// slg_score_multi.hpp — scoring kernel for queries with many terms (7..32 lists), the shape a
+// slg_score_multi.hpp — scoring kernel for queries with many terms (5..32 lists), the shape a
 // multi-field query string produces (one scored term per field and word, api/reader.rs:2971-3005).
 //
 // Same algorithm as slg_score_uni.hpp — exact pre-planned rounds, LDS bitmap + prefix popcount =
@@ -225,7 +225,11 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
         // list and cut at the smallest "last loaded doc" of the lists that were not taken whole
         float share = 1.0f;
         if (R_ess > (uint32_t)kMultiCap) share = (float)kMultiFill / (float)R_ess;
-        if (S_all > 60u) share = fminf(share, (float)(48 * 64) / (float)R);
+        // the slot descriptors of a chunk live in the wave's 64 lanes: list t takes
+        // ceil(c_t / 64) <= c_t / 64 + 1 slots with c_t <= max(1, rem_t * share), so a share of
+        // (63 - T) * 64 / R bounds the chunk by (63 - T) + T = 63 slots whatever the lists' mix
+        // (a bound in postings alone, 48 * 64 / R, let 18..32 lists reach 48 + T > 64 slots)
+        if (S_all > 60u) share = fminf(share, (float)((63u - T) * 64u) / (float)R);
         uint32_t c = (uint32_t)((float)rem * share);
         c = c < 1u ? 1u : c;
         chunk = rem < c ? rem : c;

@@ -334,6 +334,15 @@ class GpuIndex:
             self._h, nq, d_qvecs, d_alpha, d_cand_doc, d_cand_seg, d_cand_bm25, d_cand_count,
             max_cand, k_out, d_out_doc, d_out_seg, d_out_score, d_out_vec, d_out_count))
 
+    def rerank_multi_batch_device(self, nq, n_clauses, d_qvecs, d_alpha, d_boost, d_cand_doc, d_cand_seg,
+                                  d_cand_bm25, d_cand_count, max_cand, k_out, d_out_doc, d_out_seg,
+                                  d_out_score, d_out_vec, d_out_count) -> None:
+        """Device-pointer form of rerank_multi_batch (d_qvecs [nq, n_clauses, dim]; d_boost may be
+        None), asynchronous on the index stream.  >= 2 cosine clauses run on the matrix cores."""
+        N.check(self._lib.slg_rerank_multi_batch_device(
+            self._h, nq, n_clauses, d_qvecs, d_alpha, d_boost, d_cand_doc, d_cand_seg, d_cand_bm25,
+            d_cand_count, max_cand, k_out, d_out_doc, d_out_seg, d_out_score, d_out_vec, d_out_count))
+
     def merge_shards_device(self, n_shards, nq, k, d_doc, d_seg, d_score, d_count, seg_stride,
                             d_out_doc, d_out_seg, d_out_score, d_out_count) -> None:
         N.check(self._lib.slg_merge_shards_device(self._h, n_shards, nq, k, d_doc, d_seg, d_score,

@@ -377,3 +377,89 @@ def test_recipes_default_fields_golden(gpu):
             got = ix.search_plan(z["q_offsets"], z["q_terms"], z["q_weights"], int(z["k"]), q_leaf=z["q_leaf"],
                                  q_plan=np.zeros(nq, np.int32), q_nleaves=z["q_nleaves"], strategy=strat)
             assert_same_hits(got, golden_expected(z), 0.0, f"recipes default fields, strategy {strat}")
+
+
+# ---- config 5: 1M docs + 768-d vectors, BM25 top-1000 -> cosine rerank -> top-10, as ONE pipeline ----
+def test_config5_full_size_pipeline(gpu, oracle):
+    """BASELINE config 5 exactly as `bench.py --config c5` chains it (corpus seed 42, 768-d store seed
+    11, 1024 queries seed 7, query vectors seed 12, alpha 0.5): slg_batch_prepare(k = 1001) -> run ->
+    slg_batch_device_results -> slg_rerank_batch_device -> top-10, no host round trip between the two
+    stages (api/reader.rs:2786 rescoring right after the cross-segment sort; blend
+    api/reader.rs:225-254, similarity vectors/mod.rs:107-129).  Properties on all 1024 queries; 16
+    queries against oracle.search_batch + oracle.rerank (bit-exact BM25 block, rerank within 1e-5);
+    then the SAME device candidates through slg_rerank_multi_batch_device with 2 clauses (the
+    v_mfma_f32_16x16x4_f32 kernel) against oracle.rerank_multi."""
+    import torch
+    from searchlite_amd import corpus
+    n_docs, vocab, nq, T, dim = 1_000_000, 1 << 18, 1024, 3, 768
+    k, k_out = 1001, 10
+    seg = corpus.zipf_segment(n_docs, vocab, seed=42, n_threads=16)
+    vals = corpus.unit_vectors(n_docs, dim, seed=11)
+    seg.vec_dim, seg.vec_metric = dim, 0
+    seg.vec_offsets = np.arange(n_docs, dtype=np.uint32)
+    seg.vec_values = vals
+    offs, terms, w = corpus.zipf_queries(nq, T, seed=7, vocab=vocab)
+    qh = corpus.unit_vectors(nq, dim, seed=12)
+    q2h = np.stack([qh, corpus.unit_vectors(nq, dim, seed=13)], axis=1)  # [nq, 2, dim]
+    a2h = np.tile(np.array([0.5, 0.3], np.float32), (nq, 1))
+    stream = torch.cuda.current_stream()
+
+    def outs():
+        return (torch.empty((nq, k_out), dtype=torch.int32, device="cuda"),
+                torch.empty((nq, k_out), dtype=torch.int32, device="cuda"),
+                torch.empty((nq, k_out), dtype=torch.float32, device="cuda"),
+                torch.empty((nq, k_out), dtype=torch.float32, device="cuda"),
+                torch.empty((nq,), dtype=torch.int32, device="cuda"))
+
+    with gpu.GpuIndex([seg]) as ix:
+        ix.set_stream(stream.cuda_stream)
+        qv = torch.from_numpy(qh).cuda()
+        q2 = torch.from_numpy(q2h).cuda()
+        alpha = torch.full((nq,), 0.5, dtype=torch.float32, device="cuda")
+        alpha2 = torch.from_numpy(a2h).cuda()
+        b = ix.prepare(offs, terms, w, k, gpu.Wand)
+        b.run()
+        d = b.device_results()
+        r1, r2 = outs(), outs()
+        ix.rerank_batch_device(nq, qv.data_ptr(), alpha.data_ptr(), d[0], d[1], d[2], d[3], k, k_out,
+                               *[t.data_ptr() for t in r1])
+        ix.rerank_multi_batch_device(nq, 2, q2.data_ptr(), alpha2.data_ptr(), None, d[0], d[1], d[2], d[3],
+                                     k, k_out, *[t.data_ptr() for t in r2])
+        torch.cuda.synchronize()
+        cd, cs, csc, cc = b.fetch()       # the BM25 stage's block, for the checks below
+        b.close()
+        g1 = [t.cpu().numpy() for t in r1]
+        g2 = [t.cpu().numpy() for t in r2]
+    # ---- the BM25 stage: 1001 candidates per query, sorted, distinct ----
+    _properties(cd, cs, csc, cc, k, n_docs)
+    # ---- properties of both rerank outputs on all queries ----
+    for g, nc_ in ((g1, 1), (g2, 2)):
+        rd, rs, rsc, rv, rc = g[0].view(np.uint32), g[1].view(np.uint32), g[2], g[3], g[4].view(np.uint32)
+        assert (rc == k_out).all() and (rs == 0).all()
+        assert (rsc[:, :-1] >= rsc[:, 1:]).all()                      # blended score descending
+        for q in range(nq):
+            assert len(set(rd[q].tolist())) == k_out                  # distinct docs ...
+            pos = {int(x): i for i, x in enumerate(cd[q])}
+            assert all(int(x) in pos for x in rd[q])                  # ... out of this query's candidates
+            if nc_ == 1:  # blend_scores (vectors/mod.rs:122-129): alpha * bm25 + (1 - alpha) * sim
+                bm = np.array([csc[q, pos[int(x)]] for x in rd[q]], np.float32)
+                want = np.float32(0.5) * bm + np.float32(0.5) * rv[q]
+                assert np.abs(want - rsc[q]).max() <= 1e-5
+    # ---- 16 queries against the oracle ----
+    nchk = 16
+    want = oracle.search_batch([seg], offs[:nchk + 1], terms[:nchk * T], w[:nchk * T], k,
+                               strategy=oracle.BM25, n_threads=16)
+    assert_same_hits((cd[:nchk], cs[:nchk], csc[:nchk], cc[:nchk]), want, 0.0, "config 5 BM25 top-1000")
+    spec = importlib.util.spec_from_file_location("t_rerank", os.path.join(ROOT, "tests", "test_gpu_rerank.py"))
+    tr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tr)
+    wd, ws, wv, wd2, ws2 = [], [], [], [], []
+    for q in range(nchk):
+        n = int(want[3][q])
+        d_, s_, v_ = oracle.rerank(0, seg.vec_offsets, vals, qh[q], 0.5, want[0][q, :n], want[2][q, :n], k_out)
+        wd.append(d_), ws.append(s_), wv.append(v_)
+        d_, s_, _ = oracle.rerank_multi(0, seg.vec_offsets, vals, q2h[q], a2h[q], want[0][q, :n], want[2][q, :n], k_out)
+        wd2.append(d_), ws2.append(s_)
+    as_u = lambda g: (g[0].view(np.uint32), g[1].view(np.uint32), g[2], g[3], g[4].view(np.uint32))
+    tr._check(as_u(g1), wd, ws, wv, "config 5: device candidates -> slg_rerank_batch_device")
+    tr._check(as_u(g2), wd2, ws2, None, "config 5: device candidates -> 2-clause MFMA rerank")

@@ -477,6 +477,43 @@ def test_many_term_kernel_cut_paths(gpu, oracle, k):
         assert_same_hits(ix.search_plan(offs, terms, w, k, **kw), want_plan, 0.0, "multi kernel cuts + plans")
 
 
+@pytest.mark.parametrize("T", [20, 25, 32])
+def test_maxscore_chunk_slots_fit_the_wave(gpu, oracle, T):
+    """ADVICE r2 (slg_score_multi.hpp): a MaxScore-classified chunk keeps one slot descriptor per
+    lane, so it may use at most 64 slots.  One sparse, heavily weighted essential list and T - 1
+    dense non-essential lists packed into the doc range of ONE planned round: the chunk is cut in
+    proportion (round 2: to 3072 postings), which leaves T - 2 lists ~70 postings (2 slots each)
+    and one long list the rest: 66..77 slots unless the cut bounds the slots too.  Wand / Bmw must
+    still return the exhaustive top-k."""
+    n = 16_000_000
+    rng = np.random.default_rng(500 + T)
+    lo, span = 5_010_000, 100_000
+    ess = np.union1d(rng.choice(n, size=5000, replace=False), lo + np.arange(0, span, 3000))
+    lists = [ess]
+    for i in range(T - 1):
+        size = 3500 if i else 153_600 - 3500 * (T - 2)
+        lists.append(lo + np.sort(rng.choice(span, size=size, replace=False)))
+    seg = _skewed_segment(n, lists)
+    nq = 3
+    offs = (np.arange(nq + 1) * T).astype(np.uint32)
+    terms = np.tile(np.arange(T, dtype=np.uint32), nq)[:, None]
+    w = np.tile(np.concatenate([[50.0], np.full(T - 1, 0.05)]).astype(np.float32), nq)
+    w[T:2 * T] *= np.float32(1.5)
+    w[2 * T + 1:3 * T] = rng.random(T - 1).astype(np.float32) * np.float32(0.08)
+    for k in (11, 101):
+        want = _oracle_batch(oracle, [seg], offs, terms, w, k)
+        with gpu.GpuIndex([seg]) as ix:
+            for strat in (gpu.Wand, gpu.Bmw, gpu.Bm25):
+                b = ix.prepare(offs, terms, w, k, strat)
+                b.run()
+                got = b.fetch()
+                probed, _ = b.skip_counts()
+                b.close()
+                assert_same_hits(got, want, 0.0, f"T={T} k={k} strategy={strat}")
+                if strat != gpu.Bm25:
+                    assert probed > 0  # the dense lists really were classified non-essential
+
+
 def test_dismax_counts_leaves_without_postings_in_a_round(gpu, oracle):
     """DisMax takes the max over ALL leaves (planner.rs:138-150): with a negative-weight leaf, a doc
     found only in it scores max(0.0, x) + tie * (x - max) — also in rounds where the other leaf's

@@ -1,7 +1,8 @@
 """Randomised parity run (GPU box): random corpora, query shapes, k, weights (also zero / negative),
 tombstones, doc filters, score plans and strategies, each batch compared bit for bit with the CPU
 oracle.  usage: python tools/fuzz_parity.py [iterations] [seed]
-(SLG_MAXSCORE=1 / SLG_UNIFORM_MAX_TERMS=0 in the environment force pruning / the many-term kernel.)"""
+(SLG_MAXSCORE=1 / SLG_UNIFORM_MAX_TERMS=0 in the environment force pruning / the many-term kernel;
+FUZZ_MANY_LISTS=1 draws MaxScore-classified queries of 14..32 lists instead.)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -103,11 +104,44 @@ def run_case(seed0, it, tuning=None):
           raise
 
 
+def run_case_many_lists(seed0, it, tuning=None):
+    """MaxScore-classified queries of 14..32 lists (the chunk's slot descriptors must
+    fit the wave's 64 lanes): skewed corpora (clustered and spread lists), one or two heavily
+    weighted lists and many lightly weighted dense ones, strategies Wand / Bmw, no filters, so the
+    planner classifies most lists non-essential.  Keyed (seed0, it), bit for bit vs the oracle."""
+    rng = np.random.default_rng(seed0 * 7919 + it + 0x5EED)
+    vocab = int(rng.integers(34, 48))
+    n_docs = int(rng.choice([60_000, 500_000, 3_000_000]))
+    seg = skewed_segment(rng, n_docs, vocab)
+    if rng.random() < 0.3:
+        seg.set_deleted(np.nonzero(rng.random(n_docs) < 0.1)[0].tolist())
+    nq = int(rng.integers(1, 6))
+    k = int(rng.choice([1, 5, 11, 64, 101, 256]))
+    offs, terms, w = [0], [], []
+    for q in range(nq):
+        T = int(rng.integers(14, 33))
+        ids = rng.choice(vocab, size=T, replace=False)
+        heavy = set(rng.choice(T, size=int(rng.integers(1, 3)), replace=False).tolist())
+        for i in range(T):
+            terms.append([int(ids[i])])
+            w.append(np.float32(rng.random() * 40 + 10) if i in heavy else np.float32(rng.random() * 0.05))
+        offs.append(len(terms))
+    offs = np.array(offs, dtype=np.uint32)
+    terms = np.array(terms, dtype=np.uint32).reshape(-1, 1)
+    w = np.array(w, dtype=np.float32)
+    with sa.GpuIndex([seg], tuning=tuning) as ix:
+        strat = int(rng.choice([sa.Wand, sa.Bmw]))
+        got = ix.search_batch(offs, terms, w, k, strat)
+    want = O.search_batch([seg], offs, terms, w, k, strategy=O.BM25)
+    assert_same_hits(got, want, 0.0, f"fuzz many-lists it={it} seed={seed0} nq={nq} k={k} n_docs={n_docs}")
+
+
 def run(iters, seed0, verbose=True, tuning=None):
     O.build()
     t0 = time.time()
+    many = os.environ.get("FUZZ_MANY_LISTS", "0") != "0"
     for it in range(iters):
-        run_case(seed0, it, tuning)
+        (run_case_many_lists if many else run_case)(seed0, it, tuning)
         if verbose and it % 10 == 9:
             print(f"{it + 1} batches ok ({time.time() - t0:.0f} s)", flush=True)
     if verbose:
