@@ -191,75 +191,65 @@ def main():
         qs = query_sets(nq, T, vocab, per_rank, 7, max(2, args.rotate))
         n_flight = 2
         streams = [torch.cuda.Stream() for _ in range(n_flight)]
-        blk_words = (3 * k + 1) * nq
-        g_blocks = [torch.empty((world * blk_words,), dtype=torch.int32, device="cuda") for _ in range(n_flight)]
-        merged = [[torch.empty((nq, k), dtype=torch.int32, device="cuda"),
-                   torch.empty((nq, k), dtype=torch.int32, device="cuda"),
-                   torch.empty((nq, k), dtype=torch.float32, device="cuda"),
-                   torch.empty((nq,), dtype=torch.int32, device="cuda")] for _ in range(n_flight)]
-        host_out = [[torch.empty((nq, k), dtype=torch.int32).pin_memory(),
-                     torch.empty((nq, k), dtype=torch.int32).pin_memory(),
-                     torch.empty((nq, k), dtype=torch.float32).pin_memory(),
-                     torch.empty((nq,), dtype=torch.int32).pin_memory()] for _ in range(n_flight)]
+        # the shard group: RCCL behind the C ABI (slg_shard_group_create = ncclCommInitRank).  The
+        # 128-byte communicator id travels over the control plane once; the data path below has no
+        # torch.distributed call: slg_batch_run_sharded = kernels + ONE ncclAllGather + device merge
+        if use_dist:
+            box = [searcher.shard_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            uid = box[0]
+        else:
+            uid = searcher.shard_unique_id()
+        group = searcher.ShardGroup(index, rank, world, uid, per_rank)
         live = [None] * n_flight
-        done_ev = [None] * n_flight
         postings = []
+        last_res = [None]
 
         def step(i):
             f = i % n_flight
-            if live[f] is not None:  # the slot's previous batch: results are on the host by now
-                done_ev[f].synchronize()
+            if live[f] is not None:  # the slot's previous batch: wait, merged top-k to the host
+                last_res[0] = live[f].fetch_sharded()
                 live[f].close()
             offs, terms, w = qs[i % len(qs)]
             b = index.prepare(offs, terms, w, k, strategy)  # host planning + H2D of the descriptors
             b.set_stream(streams[f].cuda_stream)
-            b.run()
+            b.run_sharded(group, fetch=False)               # asynchronous: collected one lap later
             if len(postings) < len(qs):
                 postings.append(b.info())
             live[f] = b
-            ptr, nbytes = b.device_result_block()
-            blk = torch.as_tensor(_DevArray(ptr, (nbytes // 4,), "<i4"), device="cuda")
-            stream.wait_event(streams[f].record_event())
-            if use_dist:
-                dist.all_gather_into_tensor(g_blocks[f], blk)
-                gb = g_blocks[f].view(world, -1)
-            else:
-                gb = blk.view(1, -1)
-            n_ = nq * k
-            g_doc, g_seg = gb[:, :n_].contiguous(), gb[:, n_:2 * n_].contiguous()
-            g_score, g_count = gb[:, 2 * n_:3 * n_].contiguous(), gb[:, 3 * n_:].contiguous()
-            m = merged[f]
-            index.merge_shards_device(world, nq, k, g_doc.data_ptr(), g_seg.data_ptr(), g_score.data_ptr(),
-                                      g_count.data_ptr(), per_rank, m[0].data_ptr(), m[1].data_ptr(),
-                                      m[2].data_ptr(), m[3].data_ptr())
-            for h, d in zip(host_out[f], m):
-                h.copy_(d, non_blocking=True)
-            done_ev[f] = stream.record_event()
+
+        def drain():
+            order = sorted(range(n_flight), key=lambda f: 0 if live[f] is None else 1)
+            for f in range(n_flight):
+                ff = (drain.next + f) % n_flight
+                if live[ff] is not None:
+                    last_res[0] = live[ff].fetch_sharded()
+                    live[ff].close()
+                    live[ff] = None
+        drain.next = 0
 
         for i in range(warmup):
             step(i)
+        drain.next = warmup % n_flight
+        drain()
         fence()
         t1 = time.perf_counter()
         for i in range(steps):
             step(warmup + i)
-        for f in range(n_flight):
-            if done_ev[f] is not None:
-                done_ev[f].synchronize()
+        drain.next = (warmup + steps) % n_flight  # oldest batch first: the last step's result is collected last
+        drain()
         fence()
         elapsed = max_over_ranks(time.perf_counter() - t1)
-        last = (warmup + steps - 1) % n_flight
-        res = tuple(x.numpy().copy() for x in host_out[last])
+        res = tuple(np.asarray(x).copy() for x in last_res[0])
         last_q = qs[(warmup + steps - 1) % len(qs)]
-        for b in live:
-            if b is not None:
-                b.close()
         info = index.info()
+        group.close()
         index.close()
         out = {"workload": f"{C4_SEGMENTS} segments x {n_docs} synthetic Zipf docs (V={vocab}, seeds {cseed}.."
                            f"{cseed + C4_SEGMENTS - 1}) index-sharded over {world} GPU(s), {T}-term OR, "
                            f"batch={nq}, top-{limit} (k={k}), strategy={args.strategy}; fresh host query "
-                           f"batch per step, one all-gather of (3k+1)*Q*4 B per rank, device merge, merged "
-                           f"top-k copied to the host",
+                           f"batch per step, slg_batch_run_sharded (ONE ncclAllGather of (3k+1)*Q*4 B per rank "
+                           f"behind the C ABI + device merge), merged top-k copied to the host",
                "queries_per_s": round(nq / (elapsed / steps), 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
                "steps": steps, "scaling": "strong", "segments_per_rank": per_rank,
                "postings_per_batch_this_rank": int(np.mean([p["n_postings"] for p in postings])),

@@ -172,11 +172,22 @@ typedef struct {
   int32_t block_max;             /* !SLG_NO_BLOCK_MAX (1): block skipping — 64-posting blocks of
                                     pruning-classified lists whose doc range holds no candidate doc
                                     are not loaded (query/wand.rs:205-265) */
+  uint32_t pool_cap_mb;          /* SLG_POOL_CAP_MB (0 = auto): MiB of freed batch work buffers the
+                                    index keeps for reuse; auto = a quarter of the HBM free after
+                                    staging, within [1 GiB, 24 GiB].  The pool is drained whenever a
+                                    device allocation of the library fails (slg_index_trim_pool) */
+  uint32_t uniform_kernel;       /* SLG_UNIFORM_KERNEL (3): form of the few-term scoring kernel; 2 = the
+                                    round-2 kernel (kept for A/B timing on one device) */
 } slg_tuning;
 void slg_tuning_default(slg_tuning *out);
 slg_index *slg_index_create_tuned(const slg_segment_desc *segs, uint32_t n_segs, int device,
                                   const slg_tuning *tuning_or_null);
 int slg_index_get_tuning(const slg_index *index, slg_tuning *out);
+
+/* Gives the freed batch work buffers the index keeps for reuse back to the runtime (the library
+ * does the same by itself when one of its device allocations runs out of memory).  Call it before
+ * another consumer of the device (a second index, RCCL, the application) needs the memory. */
+int slg_index_trim_pool(slg_index *index, uint64_t *freed_bytes_or_null);
 
 /* Bytes of HBM held by the index; total postings; segments. */
 int slg_index_info(const slg_index *index, uint32_t *n_segs, uint64_t *n_postings,
@@ -292,6 +303,37 @@ int slg_batch_info(const slg_batch *batch, uint64_t *n_postings, uint32_t *n_sli
  * slg_tuning.block_max is off.  Waits for the batch. */
 int slg_batch_skip_counts(slg_batch *batch, uint64_t *probed_postings, uint64_t *skipped_postings);
 void slg_batch_destroy(slg_batch *batch);
+
+/* ---- index sharding over RCCL ------------------------------------------------------
+ * The reference scores every segment independently and merges by (score desc, segment_ord asc,
+ * doc asc) (api/reader.rs:2670-2778, query/sort.rs:80-93); with one shard of segments per GPU the
+ * merge spans ranks.  A shard group ties this rank's index to an RCCL communicator: one process
+ * (or host thread) per GPU creates its index over ITS segments and joins the group; rank 0 makes
+ * the 128-byte id with slg_shard_unique_id and hands it to the other ranks out of band (the way
+ * ncclGetUniqueId / ncclCommInitRank are used).  segs_per_rank = the largest shard's segment count:
+ * a hit's segment ordinal in the merged result is rank * segs_per_rank + its local ordinal.
+ * librccl is bound at run time; without it these calls fail with SLG_ERR_UNSUPPORTED. */
+#define SLG_SHARD_UNIQUE_ID_BYTES 128u
+typedef struct slg_shard_group slg_shard_group;
+int slg_shard_unique_id(void *out, size_t out_bytes);
+/* Collective: every rank of the group calls it (it returns when all have). */
+slg_shard_group *slg_shard_group_create(slg_index *index, int rank, int world, const void *unique_id,
+                                        uint32_t segs_per_rank);
+void slg_shard_group_destroy(slg_shard_group *group);
+/* slg_batch_run on this rank's segments, ONE ncclAllGather of the contiguous result blocks
+ * ((3k+1) * Q * 4 bytes per rank) on the batch's stream, merge of the world's rows on the device.
+ * Every rank prepares the SAME queries (same order, same k) and issues its sharded runs in the same
+ * order.  out_* (host, [nq*k] / [nq]) receive the merged top-k on every rank; pass NULL for all four
+ * to leave the result on the device (slg_batch_sharded_device_results) without waiting. */
+int slg_batch_run_sharded(slg_batch *batch, slg_shard_group *group, uint32_t *out_doc, uint32_t *out_seg,
+                          float *out_score, uint32_t *out_count);
+int slg_batch_sharded_device_results(slg_batch *batch, void **d_doc, void **d_seg, void **d_score,
+                                     void **d_count);
+/* Waits for the batch's sharded run and copies the merged top-k to host arrays (what
+ * slg_batch_run_sharded does itself when given output arrays): lets a caller keep several sharded
+ * batches in flight, each on its own stream, and collect them later. */
+int slg_batch_fetch_sharded(slg_batch *batch, uint32_t *out_doc, uint32_t *out_seg, float *out_score,
+                            uint32_t *out_count);
 
 /*
  * Merge per-shard results gathered from several indexes/GPUs (device arrays, as produced

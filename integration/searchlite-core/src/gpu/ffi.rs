@@ -8,6 +8,7 @@ use std::os::raw::{c_char, c_float, c_int, c_void};
 
 #[repr(C)] pub struct slg_index { _p: [u8; 0] }
 #[repr(C)] pub struct slg_batch { _p: [u8; 0] }
+#[repr(C)] pub struct slg_shard_group { _p: [u8; 0] }
 
 #[repr(C)]
 pub struct slg_segment_desc {
@@ -26,6 +27,7 @@ pub struct slg_tuning {
     pub uniform_max_terms: u32, pub uniform_round_target: u32, pub multi_round_target: u32,
     pub probe_target: u32, pub rounds_per_slice: u32, pub max_rounds_per_slice: u32,
     pub slices_per_subquery: u32, pub cand_mode: i32, pub slice_order: i32, pub block_max: i32,
+    pub pool_cap_mb: u32, pub uniform_kernel: u32,
 }
 #[repr(C)] pub struct slg_vector_field_desc {
     pub vec_dim: u32, pub vec_metric: i32, pub vec_offsets: *const u32, pub vec_values: *const c_float, pub vec_rows: u32,
@@ -46,6 +48,18 @@ extern "C" {
     pub fn slg_index_create(segs: *const slg_segment_desc, n_segs: u32, device: c_int) -> *mut slg_index;
     pub fn slg_index_destroy(index: *mut slg_index);
     pub fn slg_index_info(index: *const slg_index, n_segs: *mut u32, n_postings: *mut u64, device_bytes: *mut u64) -> c_int;
+    // index sharding over RCCL (api/reader.rs:2670-2778 across GPUs)
+    pub fn slg_shard_unique_id(out: *mut c_void, out_bytes: usize) -> c_int;
+    pub fn slg_shard_group_create(index: *mut slg_index, rank: c_int, world: c_int, unique_id: *const c_void,
+        segs_per_rank: u32) -> *mut slg_shard_group;
+    pub fn slg_shard_group_destroy(group: *mut slg_shard_group);
+    pub fn slg_batch_run_sharded(batch: *mut slg_batch, group: *mut slg_shard_group, out_doc: *mut u32,
+        out_seg: *mut u32, out_score: *mut c_float, out_count: *mut u32) -> c_int;
+    pub fn slg_batch_sharded_device_results(batch: *mut slg_batch, d_doc: *mut *mut c_void, d_seg: *mut *mut c_void,
+        d_score: *mut *mut c_void, d_count: *mut *mut c_void) -> c_int;
+    pub fn slg_batch_fetch_sharded(batch: *mut slg_batch, out_doc: *mut u32, out_seg: *mut u32,
+        out_score: *mut c_float, out_count: *mut u32) -> c_int;
+    pub fn slg_index_trim_pool(index: *mut slg_index, freed_bytes_or_null: *mut u64) -> c_int;
     pub fn slg_index_set_stream(index: *mut slg_index, hip_stream: *mut c_void) -> c_int;
     // doc filters: accept = !deleted && filter (api/reader.rs:3009-3018)
     pub fn slg_index_add_filter(index: *mut slg_index, seg_bitmaps: *const *const u8) -> c_int;

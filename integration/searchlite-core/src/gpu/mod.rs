@@ -53,7 +53,7 @@ pub struct GpuSegments {
   /// per segment: "field:term" key -> term id (rank of the key in the sorted dictionary)
   dict: Vec<HashMap<String, u32>>,
   /// filters already registered: serialized Filter -> filter id (slg_index_add_filter)
-  filters: Mutex<HashMap<String, i32>>,
+  filters: Mutex<FilterCache>,  // bounded LRU of registered doc filters
 }
 
 // The library serialises launches internally and planning takes no lock.
@@ -186,7 +186,7 @@ impl GpuSegments {
     if handle.is_null() {
       return Err(last_error());
     }
-    Ok(Self { handle, dict, filters: Mutex::new(HashMap::new()) })
+    Ok(Self { handle, dict, filters: Mutex::new(FilterCache::default()) })
   }
 
   pub(crate) fn raw(&self) -> *mut ffi::slg_index {
@@ -198,8 +198,23 @@ impl GpuSegments {
   /// serialized form.
   fn filter_id(&self, segments: &[SegmentReader], filter: &Filter) -> Result<i32> {
     let key = serde_json::to_string(filter)?;
-    if let Some(id) = self.filters.lock().unwrap().get(&key) {
-      return Ok(*id);
+    // the lock is held across lookup, evaluation and insert: two threads that miss on the same
+    // filter must not both register it (each registration is n_docs / 8 bytes of HBM per segment)
+    let mut cache = self.filters.lock().unwrap();
+    cache.tick += 1;
+    let now = cache.tick;
+    if let Some(e) = cache.map.get_mut(&key) {
+      e.1 = now;
+      return Ok(e.0);
+    }
+    // bounded: high-cardinality filters (per-user ranges) would otherwise grow the reject table
+    // and device memory without limit.  The least recently used filter leaves the device.
+    if cache.map.len() >= MAX_CACHED_FILTERS {
+      if let Some(old_key) = cache.map.iter().min_by_key(|(_, e)| e.1).map(|(k, _)| k.clone()) {
+        if let Some((old_id, _)) = cache.map.remove(&old_key) {
+          unsafe { ffi::slg_index_remove_filter(self.handle, old_id) };
+        }
+      }
     }
     let bitmaps: Vec<Vec<u8>> = segments
       .iter()
@@ -219,9 +234,19 @@ impl GpuSegments {
     if id < 0 {
       return Err(last_error());
     }
-    self.filters.lock().unwrap().insert(key, id);
+    cache.map.insert(key, (id, now));
     Ok(id)
   }
+}
+
+/// Filters kept on the device per index (LRU beyond this).
+const MAX_CACHED_FILTERS: usize = 256;
+
+/// filter (serialized) -> (device filter id, last use)
+#[derive(Default)]
+pub(crate) struct FilterCache {
+  map: HashMap<String, (i32, u64)>,
+  tick: u64,
 }
 
 /// One scored term of a request, folded as search_segment does (api/reader.rs:2971-2983):

@@ -16,6 +16,7 @@ MAX_QUERY_TERMS = 32
 MAX_K = 20001
 MAX_RERANK_K = 1024
 MAX_VECTOR_CLAUSES = 8
+SHARD_UNIQUE_ID_BYTES = 128
 
 OK, ERR_INVALID, ERR_DEVICE, ERR_OOM, ERR_UNSUPPORTED, ERR_INTERNAL = 0, -1, -2, -3, -4, -5
 STRATEGY_BM25, STRATEGY_WAND, STRATEGY_BMW = 0, 1, 2
@@ -60,7 +61,8 @@ class Tuning(C.Structure):
                 ("multi_round_target", C.c_uint32), ("probe_target", C.c_uint32),
                 ("rounds_per_slice", C.c_uint32), ("max_rounds_per_slice", C.c_uint32),
                 ("slices_per_subquery", C.c_uint32), ("cand_mode", C.c_int32),
-                ("slice_order", C.c_int32), ("block_max", C.c_int32)]
+                ("slice_order", C.c_int32), ("block_max", C.c_int32), ("pool_cap_mb", C.c_uint32),
+                ("uniform_kernel", C.c_uint32)]
 
 
 class Query(C.Structure):
@@ -112,6 +114,7 @@ def load():
         "slg_index_create": (vp, [vp, u32, i32]),
         "slg_index_destroy": (None, [vp]),
         "slg_index_info": (i32, [vp, vp, vp, vp]),
+        "slg_index_trim_pool": (i32, [vp, vp]),
         "slg_index_set_stream": (i32, [vp, vp]),
         "slg_search_batch": (i32, [vp, vp, u32, u32, i32, vp, vp, vp, vp, vp]),
         "slg_index_add_filter": (i32, [vp, vp]),
@@ -132,6 +135,12 @@ def load():
         "slg_batch_skip_counts": (i32, [vp, vp, vp]),
         "slg_batch_destroy": (None, [vp]),
         "slg_merge_shards_device": (i32, [vp, u32, u32, u32, vp, vp, vp, vp, u32, vp, vp, vp, vp]),
+        "slg_shard_unique_id": (i32, [vp, C.c_size_t]),
+        "slg_shard_group_create": (vp, [vp, i32, i32, vp, u32]),
+        "slg_shard_group_destroy": (None, [vp]),
+        "slg_batch_run_sharded": (i32, [vp, vp, vp, vp, vp, vp]),
+        "slg_batch_sharded_device_results": (i32, [vp, vp, vp, vp, vp]),
+        "slg_batch_fetch_sharded": (i32, [vp, vp, vp, vp, vp]),
         "slg_profile_enable": (i32, [vp, i32]),
         "slg_profile_read": (i32, [vp, vp, vp]),
         "slg_rerank_batch": (i32, [vp, u32, vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp, vp, vp]),

@@ -9,6 +9,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -91,14 +93,21 @@ int32_t env_i32(const char *name, int32_t dflt) {
 // Freed batch buffers are kept for the next batch: hipMalloc / hipFree cost ~100 us each and
 // hipFree synchronizes the device, which would serialize host threads that serve batches
 // concurrently.  Size classes: powers of two from 4 KiB to 1 MiB, above that eight steps per
-// octave (<= 12.5 % over-allocation).
+// octave (<= 12.5 % over-allocation).  The pool is bounded (slg_tuning.pool_cap_mb) and is the
+// first thing given back when the device runs out of memory: every allocation of the library that
+// fails with hipErrorOutOfMemory drains it and tries once more, so parked blocks of size classes
+// nobody asks for any more can never starve a new batch, a second index or the application.
 struct BufPool {
   std::mutex mu;
   std::multimap<size_t, void *> free_;
   size_t pooled = 0;
   // (config 4 on one GPU holds ~1 GB of work buffers per 8192-query batch and keeps three batches
   //  alive: with a 4 GB cap every batch ended in hipFree + hipMalloc, which synchronise the device)
-  static constexpr size_t kMaxPooled = 24ull << 30;
+  size_t cap = 24ull << 30;
+  // pinned staging images of slg_batch_prepare* (descriptor uploads), owned by the index: taken
+  // for one prepare call, handed back afterwards, released with the index (a thread_local image
+  // would outlive its thread's usefulness and leak when caller threads come and go)
+  std::vector<std::pair<void *, size_t>> images;
   static size_t size_class(size_t n) {  // powers of two up to 1 MiB, then eighths of an octave
     size_t c = 4096;
     while (c < n && c < (1u << 20)) c <<= 1;
@@ -120,31 +129,91 @@ struct BufPool {
   }
   bool put(void *p, size_t cls) {
     std::lock_guard<std::mutex> lk(mu);
-    if (pooled + cls > kMaxPooled) return false;
+    if (pooled + cls > cap) return false;
     free_.emplace(cls, p);
     pooled += cls;
     return true;
   }
+  // give every parked block back to the runtime (largest first); returns the bytes freed
+  size_t drain() {
+    std::multimap<size_t, void *> take;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      take.swap(free_);
+      pooled = 0;
+    }
+    size_t freed = 0;
+    for (auto it = take.rbegin(); it != take.rend(); ++it) {
+      (void)hipFree(it->second);
+      freed += it->first;
+    }
+    return freed;
+  }
+  // a pinned host image of at least n bytes (hipHostMallocPortable: usable from any device)
+  void *take_image(size_t n, size_t *got) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (size_t i = 0; i < images.size(); i++)
+        if (images[i].second >= n) {
+          void *p = images[i].first;
+          *got = images[i].second;
+          images[i] = images.back();
+          images.pop_back();
+          return p;
+        }
+      if (images.size() >= 16) {  // only too-small ones are parked: drop one
+        (void)hipHostFree(images.back().first);
+        images.pop_back();
+      }
+    }
+    const size_t want = std::max<size_t>((n * 5) / 4, 1u << 20);
+    void *p = nullptr;
+    if (hipHostMalloc(&p, want, hipHostMallocPortable) != hipSuccess) return nullptr;
+    *got = want;
+    return p;
+  }
+  void give_image(void *p, size_t bytes) {
+    std::lock_guard<std::mutex> lk(mu);
+    images.emplace_back(p, bytes);
+  }
   ~BufPool() {
     for (auto &kv : free_) (void)hipFree(kv.second);
+    for (auto &im : images) (void)hipHostFree(im.first);
   }
 };
+
+// hipMalloc that drains `pool` (may be null) and tries once more when the device is out of memory
+static void *device_alloc(size_t n, BufPool *pool) {
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, n);
+  if (e == hipErrorOutOfMemory && pool && pool->drain() > 0) {
+    (void)hipGetLastError();
+    e = hipMalloc(&p, n);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    throw SlgError(e == hipErrorOutOfMemory ? SLG_ERR_OOM : SLG_ERR_DEVICE,
+                   std::string("hipMalloc(") + std::to_string(n) + "): " + hipGetErrorString(e));
+  }
+  return p;
+}
 
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
   BufPool *pool = nullptr;  // set: bytes is a size class and the block goes back to the pool
-  void alloc(size_t n) {
+  // relief: a pool to drain if the device is out of memory (the block itself is not pooled)
+  void alloc(size_t n, BufPool *relief = nullptr) {
     release();
     if (n == 0) n = 16;
-    SLG_HIP(hipMalloc(&p, n));
+    p = device_alloc(n, relief);
     bytes = n;
   }
   void alloc_pooled(BufPool *pl, size_t n) {
     release();
     size_t cls = BufPool::size_class(n ? n : 16);
     p = pl->get(cls, &cls);
-    if (!p) SLG_HIP(hipMalloc(&p, cls));
+    if (!p) p = device_alloc(cls, pl);
     bytes = cls;
     pool = pl;
   }
@@ -184,7 +253,8 @@ struct DevBuf {
 struct SegHost {
   uint32_t n_docs = 0, n_terms = 0;
   uint64_t n_postings = 0;
-  std::vector<uint64_t> term_offsets;
+  uint64_t null_idx = 0;               // SegDev::null_idx
+  std::vector<uint64_t> term_offsets;  // as given (unpadded); device position = + kListPad * term
   std::vector<float> champ;  // host mirror of d_champ [V * kChampions] (query planning)
   DevBuf d_docs, d_imps, d_deleted, d_champ;
   // vectors
@@ -263,6 +333,9 @@ struct slg_batch {
   float *d_out_score = nullptr;
   DevBuf d_stamps;  // SLG_STAMPS diagnostic builds
   DevBuf d_blk_skip;  // block skipping: postings of non-essential lists that were never loaded (u64)
+  // index-sharded runs (slg_batch_run_sharded): the gathered result blocks of all ranks and the merged
+  // top-k doc | seg | score | count
+  DevBuf d_gather, d_merged;
   uint64_t n_postings_nonessential = 0;  // postings of the pruning-classified (non-essential) lists
 };
 
@@ -300,8 +373,8 @@ template <> void launch_score_kregs<16>(const RoundScoreParams &, int, hipStream
 }  // namespace slg
 namespace {
 
-// kind: 1 few-term kernel (slg_score_uni.hpp), 2 many-term kernel (slg_score_multi.hpp),
-// 3 many-term kernel with pruning-classified lists
+// kind: 1 few-term kernel (slg_score_uni3.hpp), 2 many-term kernel (slg_score_multi.hpp),
+// 3 many-term kernel with pruning-classified lists, 4 the round-2 few-term kernel (slg_score_uni.hpp)
 void launch_score(const slg::RoundScoreParams &sp, int kind, hipStream_t st) {
 #ifdef SLG_STAMPS  // diagnostic build: only the k <= 64 variant is compiled
   if (kregs_for(sp.k) != 1) throw SlgError(SLG_ERR_UNSUPPORTED, "stamps build supports k <= 64 only");
@@ -406,12 +479,14 @@ void stage_segment(slg_index *ix, SegHost &sh, const slg_segment_desc &d) {
   const uint64_t P = sh.term_offsets[d.n_terms];
   sh.n_postings = P;
 
-  // + 64 entries: the scoring kernels load whole 64-lane slots (lanes past a slot's count are
-  // masked after the load), so a slot that starts near the end of the arrays reads past P
-  sh.d_docs.alloc((P + 64) * 4);
-  sh.d_imps.alloc((P + 64) * 4);
-  SLG_HIP(hipMemsetAsync(static_cast<char *>(sh.d_docs.p) + P * 4, 0xFF, 64 * 4, st));
-  SLG_HIP(hipMemsetAsync(static_cast<char *>(sh.d_imps.p) + P * 4, 0, 64 * 4, st));
+  // padded layout (SegDev): every list is followed by kListPad sentinel entries, + one more run at
+  // the end (null_idx): the scoring kernels load whole 64-lane slots starting at any posting
+  const uint64_t P_pad = P + (uint64_t)slg::kListPad * ((uint64_t)d.n_terms + 1);
+  sh.null_idx = P + (uint64_t)slg::kListPad * d.n_terms;
+  sh.d_docs.alloc(P_pad * 4, &ix->pool);
+  sh.d_imps.alloc(P_pad * 4, &ix->pool);
+  SLG_HIP(hipMemsetAsync(sh.d_docs.p, 0xFF, P_pad * 4, st));
+  SLG_HIP(hipMemsetAsync(sh.d_imps.p, 0, P_pad * 4, st));
   ix->device_bytes += sh.d_docs.bytes + sh.d_imps.bytes;
   if (d.deleted) {
     const size_t words = ((size_t)d.n_docs + 31) / 32;
@@ -423,10 +498,11 @@ void stage_segment(slg_index *ix, SegHost &sh, const slg_segment_desc &d) {
   }
   if (P > 0) {
     // temporaries used only by the staging kernel
-    DevBuf d_tfs, d_offs, d_idf, d_tfield, d_avgdl, d_lenptrs;
+    DevBuf d_docs_in, d_tfs, d_offs, d_idf, d_tfield, d_avgdl, d_lenptrs;
     std::vector<DevBuf> d_lens(d.n_fields);
+    d_docs_in.alloc(P * 4);
     d_tfs.alloc(P * 4);
-    SLG_HIP(hipMemcpyAsync(sh.d_docs.p, d.doc_ids, P * 4, hipMemcpyHostToDevice, st));
+    SLG_HIP(hipMemcpyAsync(d_docs_in.p, d.doc_ids, P * 4, hipMemcpyHostToDevice, st));
     SLG_HIP(hipMemcpyAsync(d_tfs.p, d.tfs, P * 4, hipMemcpyHostToDevice, st));
     d_offs.alloc(((size_t)d.n_terms + 1) * 8);
     SLG_HIP(hipMemcpyAsync(d_offs.p, sh.term_offsets.data(), ((size_t)d.n_terms + 1) * 8,
@@ -464,7 +540,8 @@ void stage_segment(slg_index *ix, SegHost &sh, const slg_segment_desc &d) {
     sp.n_terms = d.n_terms;
     sp.n_docs = d.n_docs;
     sp.term_offsets = d_offs.as<uint64_t>();
-    sp.docs = sh.d_docs.as<uint32_t>();
+    sp.docs = d_docs_in.as<uint32_t>();
+    sp.docs_out = sh.d_docs.as<uint32_t>();
     sp.tfs = d_tfs.as<uint32_t>();
     sp.term_idf = d_idf.as<float>();
     sp.term_field = d.term_field ? d_tfield.as<uint16_t>() : nullptr;
@@ -557,6 +634,8 @@ void slg_tuning_default(slg_tuning *t) {
   t->cand_mode = env_i32("SLG_NO_CAND_MODE", 0) == 0;
   t->slice_order = env_i32("SLG_NO_SLICE_ORDER", 0) == 0;
   t->block_max = env_i32("SLG_NO_BLOCK_MAX", 0) == 0;
+  t->pool_cap_mb = env_u32("SLG_POOL_CAP_MB", 0);
+  t->uniform_kernel = env_u32("SLG_UNIFORM_KERNEL", 3);
 }
 
 slg_index *slg_index_create(const slg_segment_desc *segs, uint32_t n_segs, int device) {
@@ -608,12 +687,23 @@ slg_index *slg_index_create_tuned(const slg_segment_desc *segs, uint32_t n_segs,
       sd[s].champ = ix->segs[s]->d_champ.as<float>();
       sd[s].n_docs = ix->segs[s]->n_docs;
       sd[s].pad = 0;
+      sd[s].null_idx = ix->segs[s]->null_idx;
       vd[s].offsets = ix->segs[s]->d_vec_offsets.as<uint32_t>();
       vd[s].values = ix->segs[s]->d_vec_values.as<float>();
       vd[s].n_docs = ix->segs[s]->n_docs;
       vd[s].dim = ix->segs[s]->vec_dim;
       vd[s].metric = ix->segs[s]->vec_metric;
       vd[s].pad = 0;
+    }
+    {  // bound of the work-buffer pool (BufPool): a quarter of what staging left free
+      size_t cap = (size_t)tune.pool_cap_mb << 20;
+      if (tune.pool_cap_mb == 0) {
+        size_t free_b = 0, total_b = 0;
+        SLG_HIP(hipMemGetInfo(&free_b, &total_b));
+        cap = std::min<size_t>(24ull << 30, std::max<size_t>(1ull << 30, free_b / 4));
+        ix->tune.pool_cap_mb = (uint32_t)(cap >> 20);
+      }
+      ix->pool.cap = cap;
     }
     ix->d_segs.alloc(n_segs * sizeof(slg::SegDev));
     SLG_HIP(hipMemcpy(ix->d_segs.p, sd.data(), n_segs * sizeof(slg::SegDev), hipMemcpyHostToDevice));
@@ -637,7 +727,7 @@ namespace {
 void release_batch_buffers(slg_batch *b, bool to_pool) {
   DevBuf *bufs[] = {&b->d_desc, &b->d_bounds, &b->d_rdoc, &b->d_slice_desc, &b->d_slice_tk, &b->d_slice_doc,
                     &b->d_q_scored, &b->d_q_filter, &b->d_cand, &b->d_slice_cbeg, &b->d_slice_ccnt,
-                    &b->d_out, &b->d_stamps, &b->d_blk_skip};
+                    &b->d_out, &b->d_stamps, &b->d_blk_skip, &b->d_gather, &b->d_merged};
   for (DevBuf *d : bufs) {
     if (!to_pool) d->pool = nullptr;
     d->release();
@@ -683,6 +773,15 @@ int slg_index_get_tuning(const slg_index *ix, slg_tuning *out) {
   });
 }
 
+int slg_index_trim_pool(slg_index *ix, uint64_t *freed_bytes) {
+  return guarded([&] {
+    SLG_REQUIRE(ix != nullptr, "index is NULL");
+    DeviceGuard g(ix->device);
+    const size_t freed = ix->pool.drain();
+    if (freed_bytes) *freed_bytes = freed;
+  });
+}
+
 int slg_index_info(const slg_index *ix, uint32_t *n_segs, uint64_t *n_postings,
                    uint64_t *device_bytes) {
   return guarded([&] {
@@ -722,7 +821,7 @@ int add_filter_impl(slg_index *ix, const uint8_t *const *seg_bitmaps, const void
     for (size_t s = 0; s < n_segs; s++) {
       const SegHost &sh = *ix->segs[s];
       const size_t words = ((size_t)sh.n_docs + 31) / 32;
-      bufs[s].alloc((words ? words : 1) * 4);
+      bufs[s].alloc((words ? words : 1) * 4, &ix->pool);
       slg::FilterBuildParams fp{};
       fp.deleted = sh.d_deleted.as<uint32_t>();
       fp.n_docs = sh.n_docs;
@@ -730,7 +829,7 @@ int add_filter_impl(slg_index *ix, const uint8_t *const *seg_bitmaps, const void
       fp.column_kind = 0;
       if (column_kind) {
         SLG_REQUIRE(seg_columns && seg_columns[s], "filter column of a segment is NULL");
-        tmp[s].alloc((size_t)std::max<uint32_t>(sh.n_docs, 1) * 8);
+        tmp[s].alloc((size_t)std::max<uint32_t>(sh.n_docs, 1) * 8, &ix->pool);
         SLG_HIP(hipMemcpyAsync(tmp[s].p, seg_columns[s], (size_t)sh.n_docs * 8, hipMemcpyHostToDevice, st));
         fp.column = tmp[s].p;
         fp.column_kind = column_kind;
@@ -741,7 +840,7 @@ int add_filter_impl(slg_index *ix, const uint8_t *const *seg_bitmaps, const void
       } else if (seg_bitmaps && seg_bitmaps[s]) {
         std::vector<uint32_t> w(words ? words : 1, 0u);
         std::memcpy(w.data(), seg_bitmaps[s], ((size_t)sh.n_docs + 7) / 8);
-        tmp[s].alloc(w.size() * 4);
+        tmp[s].alloc(w.size() * 4, &ix->pool);
         SLG_HIP(hipMemcpy(tmp[s].p, w.data(), w.size() * 4, hipMemcpyHostToDevice));
         fp.pass = tmp[s].as<uint32_t>();
       }
@@ -760,7 +859,7 @@ int add_filter_impl(slg_index *ix, const uint8_t *const *seg_bitmaps, const void
       for (size_t s = 0; s < ix->filters[f].size(); s++)
         ix->reject_host[f * n_segs + s] = ix->filters[f][s].as<uint32_t>();
     DevBuf nt;
-    nt.alloc(std::max<size_t>(ix->reject_host.size(), 1) * sizeof(void *));
+    nt.alloc(std::max<size_t>(ix->reject_host.size(), 1) * sizeof(void *), &ix->pool);
     SLG_HIP(hipMemcpy(nt.p, ix->reject_host.data(), ix->reject_host.size() * sizeof(void *),
                       hipMemcpyHostToDevice));
     SLG_HIP(hipDeviceSynchronize());  // no kernel may still read the old table
@@ -846,9 +945,18 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     std::vector<uint64_t> sq_postings, sq_postings_all;
     std::vector<uint32_t> q_sq_begin(nq + 1, 0);
     bool any_filter = false, any_plan = false;
+    // cheap validation first: every later loop indexes q_term_ids / q_weights / q_leaf through
+    // these offsets (and the leaf scan below is quadratic in a query's term count)
     uint32_t batch_max_nt = 0;
-    for (uint32_t q = 0; q < nq; q++)
-      if (q_offsets[q + 1] >= q_offsets[q]) batch_max_nt = std::max(batch_max_nt, q_offsets[q + 1] - q_offsets[q]);
+    for (uint32_t q = 0; q < nq; q++) {
+      SLG_REQUIRE(q_offsets[q + 1] >= q_offsets[q] && q_offsets[q + 1] <= total_terms,
+                  "q_offsets not monotone");
+      const uint32_t nt = q_offsets[q + 1] - q_offsets[q];
+      if (nt > SLG_MAX_QUERY_TERMS)
+        throw SlgError(SLG_ERR_UNSUPPORTED, "query " + std::to_string(q) + " has more than " +
+                                                std::to_string(SLG_MAX_QUERY_TERMS) + " terms");
+      batch_max_nt = std::max(batch_max_nt, nt);
+    }
     const slg_tuning &tn = ix->tune;
     const bool maxscore_on = tn.pruning >= 0 ? tn.pruning != 0 : batch_max_nt > tn.uniform_max_terms;
     // Score plans run on the multi kernel only, which has no MaxScore path: if any query of the
@@ -928,8 +1036,8 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
             const uint32_t tid = q_term_ids[(size_t)(t0 + i) * n_segs + s];
             if (tid == SLG_NO_TERM) continue;
             SLG_REQUIRE(tid < sh.n_terms, "term id out of range in query " + std::to_string(q));
-            const uint64_t off = sh.term_offsets[tid];
-            const uint32_t df = (uint32_t)(sh.term_offsets[tid + 1] - off);
+            const uint32_t df = (uint32_t)(sh.term_offsets[tid + 1] - sh.term_offsets[tid]);
+            const uint64_t off = sh.term_offsets[tid] + (uint64_t)slg::kListPad * tid;  // padded layout
             if (df == 0) continue;  // wand.rs:441 filter(postings.len() > 0)
             const float w = q_weights[t0 + i];
             SLG_REQUIRE(std::isfinite(w), "non-finite weight in query " + std::to_string(q));
@@ -1275,26 +1383,24 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     }
     const size_t o_bc = place<uint32_t>(cur, bnd_coarse.size());
     const size_t total = (cur + 15) & ~(size_t)15;
-    // (a copy from pageable memory that the caller waits for, outside any lock, on a stream of its
-    // own.  Measured against a pinned image copied asynchronously on the batch's stream in front
-    // of the kernels: that variant served 5.2-7.4M queries/s from 4-8 caller threads where this
-    // one serves 8.0-8.8M — the stream-ordered copy delays each batch's first kernel)
-    // (staging image kept per caller thread: a fresh 26 MB vector per config-4 batch spent half of
-    // its 5 ms in page faults)
-    // Pinned, so the copy is one DMA at PCIe speed (26 MB: 0.6 ms; from pageable memory 1-6 ms).
-    // Never freed: a thread's image lives as long as the process (freeing from a thread_local
-    // destructor would race the HIP runtime's own teardown).
-    static thread_local void *h_image = nullptr;
-    static thread_local size_t h_image_bytes = 0;
-    if (h_image_bytes < (total ? total : 16)) {
-      if (h_image) (void)hipHostFree(h_image);
-      h_image = nullptr;
-      h_image_bytes = 0;
-      const size_t want = std::max<size_t>((total * 5) / 4, 1u << 20);
-      SLG_HIP(hipHostMalloc(&h_image, want, hipHostMallocDefault));
-      h_image_bytes = want;
-    }
-    void *hbuf = h_image;
+    // (a copy the caller waits for, outside any lock, on a stream of its own.  Measured against an
+    // image copied asynchronously on the batch's stream in front of the kernels: that variant
+    // served 5.2-7.4M queries/s from 4-8 caller threads where this one serves 8.0-8.8M — the
+    // stream-ordered copy delays each batch's first kernel)
+    // The staging image is pinned, so the copy is one DMA at PCIe speed (26 MB: 0.6 ms; from
+    // pageable memory 1-6 ms), and comes from the index's free list (a fresh 26 MB vector per
+    // config-4 batch spent half of its 5 ms in page faults); it goes back when prepare returns.
+    struct ImageLease {
+      BufPool *pool;
+      void *p = nullptr;
+      size_t bytes = 0;
+      ~ImageLease() {
+        if (p) pool->give_image(p, bytes);
+      }
+    } lease{&ix->pool};
+    lease.p = ix->pool.take_image(total ? total : 16, &lease.bytes);
+    if (!lease.p) throw SlgError(SLG_ERR_OOM, "pinned staging image: hipHostMalloc failed");
+    void *hbuf = lease.p;
     unsigned char *hb = static_cast<unsigned char *>(hbuf);
     if (!sqs.empty()) std::memcpy(hb + o_sq, sqs.data(), sqs.size() * sizeof(slg::RoundQuery));
     if (!terms.empty()) std::memcpy(hb + o_terms, terms.data(), terms.size() * sizeof(slg::TermRef));
@@ -1437,7 +1543,7 @@ int slg_batch_run(slg_batch *b) {
         ev = &ix->prof_events[ix->prof_used++];
         SLG_HIP(hipEventRecord(ev->first, st));
       }
-      launch_score(sp, b->uniform ? 1 : (b->pruned ? 3 : 2), st);
+      launch_score(sp, b->uniform ? (ix->tune.uniform_kernel == 2 ? 4 : 1) : (b->pruned ? 3 : 2), st);
       if (ev) SLG_HIP(hipEventRecord(ev->second, st));
     }
     if (b->k > 0 && b->cand_mode && b->n_slices > 0) {
@@ -1695,7 +1801,215 @@ int slg_merge_shards_device(slg_index *ix, uint32_t n_shards, uint32_t nq, uint3
     mp.nq = nq;
     mp.k = k;
     mp.seg_stride = seg_stride;
+    mp.arr_stride = (uint64_t)nq * k;
+    mp.cnt_stride = nq;
     launch_shard_merge(mp, ix->stream);
+  });
+}
+
+// ---- index sharding over RCCL (api/reader.rs:2670-2778 with segment = shard) --------
+// One process (or host thread) per GPU holds the segments of its shard; every rank scores the same
+// query batch, ONE ncclAllGather exchanges the contiguous per-rank result blocks
+// doc | seg | score | count ((3k+1) * Q * 4 bytes) over xGMI, and every rank merges the world's rows
+// by (score desc, segment_ord asc, doc asc), segment_ord = rank * segs_per_rank + local segment
+// (query/sort.rs:80-93).  RCCL is bound at run time (dlopen): a single-GPU user of the library does
+// not need it, and inside a PyTorch process the librccl torch has loaded is the one used.
+extern "C++" {
+namespace {
+typedef int (*nccl_get_uid_fn)(void *);
+struct NcclUid {  // ncclUniqueId (rccl.h): passed to ncclCommInitRank BY VALUE
+  char internal[128];
+};
+typedef int (*nccl_destroy_fn)(void *);
+typedef int (*nccl_allgather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef const char *(*nccl_errstr_fn)(int);
+struct RcclApi {
+  void *handle = nullptr;
+  nccl_get_uid_fn get_uid = nullptr;
+  int (*init_rank)(void **, int, NcclUid, int) = nullptr;
+  nccl_destroy_fn destroy = nullptr;
+  nccl_allgather_fn allgather = nullptr;
+  nccl_errstr_fn errstr = nullptr;
+  std::string error;
+};
+RcclApi &rccl() {
+  static RcclApi api = [] {
+    RcclApi a;
+    const char *names[] = {"librccl.so", "librccl.so.1"};
+    for (const char *n : names)  // a copy that is already resident (PyTorch's) first
+      if (!a.handle) a.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    for (const char *n : {"librccl.so.1", "librccl.so"})
+      if (!a.handle) a.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!a.handle) {
+      a.error = std::string("librccl not found: ") + (dlerror() ? dlerror() : "");
+      return a;
+    }
+    a.get_uid = (nccl_get_uid_fn)dlsym(a.handle, "ncclGetUniqueId");
+    a.init_rank = (int (*)(void **, int, NcclUid, int))dlsym(a.handle, "ncclCommInitRank");
+    a.destroy = (nccl_destroy_fn)dlsym(a.handle, "ncclCommDestroy");
+    a.allgather = (nccl_allgather_fn)dlsym(a.handle, "ncclAllGather");
+    a.errstr = (nccl_errstr_fn)dlsym(a.handle, "ncclGetErrorString");
+    if (!a.get_uid || !a.init_rank || !a.destroy || !a.allgather || !a.errstr) a.error = "librccl lacks a required symbol";
+    return a;
+  }();
+  if (!api.error.empty()) throw SlgError(SLG_ERR_UNSUPPORTED, api.error);
+  return api;
+}
+void nccl_check(int rc, const char *what) {
+  if (rc != 0) throw SlgError(SLG_ERR_DEVICE, std::string(what) + ": " + rccl().errstr(rc));
+}
+constexpr int kNcclInt32 = 2;  // ncclDataType_t ncclInt32 (rccl.h)
+}  // namespace
+}  // extern "C++"
+
+struct slg_shard_group {
+  slg_index *idx = nullptr;
+  int rank = 0, world = 1;
+  uint32_t segs_per_rank = 1;
+  void *comm = nullptr;  // ncclComm_t
+};
+
+int slg_shard_unique_id(void *out, size_t out_bytes) {
+  return guarded([&] {
+    SLG_REQUIRE(out != nullptr && out_bytes >= SLG_SHARD_UNIQUE_ID_BYTES, "unique id buffer is NULL or too small");
+    NcclUid id;
+    nccl_check(rccl().get_uid(&id), "ncclGetUniqueId");
+    std::memcpy(out, id.internal, sizeof(id.internal));
+  });
+}
+
+slg_shard_group *slg_shard_group_create(slg_index *ix, int rank, int world, const void *unique_id,
+                                        uint32_t segs_per_rank) {
+  slg_shard_group *g = nullptr;
+  const int rc = guarded([&] {
+    SLG_REQUIRE(ix != nullptr && unique_id != nullptr, "index or unique id is NULL");
+    SLG_REQUIRE(world >= 1 && rank >= 0 && rank < world, "rank outside [0, world)");
+    SLG_REQUIRE(segs_per_rank >= ix->segs.size(), "segs_per_rank is smaller than this shard's segment count");
+    DeviceGuard dg(ix->device);
+    NcclUid id;
+    std::memcpy(id.internal, unique_id, sizeof(id.internal));
+    g = new slg_shard_group();
+    g->idx = ix;
+    g->rank = rank;
+    g->world = world;
+    g->segs_per_rank = segs_per_rank;
+    nccl_check(rccl().init_rank(&g->comm, world, id, rank), "ncclCommInitRank");
+  });
+  if (rc != SLG_OK) {
+    const std::string keep = g_last_error;
+    delete g;
+    g_last_error = keep;
+    g_last_code = rc;
+    return nullptr;
+  }
+  return g;
+}
+
+void slg_shard_group_destroy(slg_shard_group *g) {
+  if (!g) return;
+  if (g->comm) {
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(g->idx->device);
+    (void)hipDeviceSynchronize();
+    try {
+      (void)rccl().destroy(g->comm);
+    } catch (...) {
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  delete g;
+}
+
+int slg_batch_run_sharded(slg_batch *b, slg_shard_group *g, uint32_t *out_doc, uint32_t *out_seg,
+                          float *out_score, uint32_t *out_count) {
+  int rc = guarded([&] {
+    SLG_REQUIRE_LIVE(b);
+    SLG_REQUIRE(g != nullptr && g->idx == b->idx, "shard group is NULL or belongs to another index");
+  });
+  if (rc != SLG_OK) return rc;
+  rc = slg_batch_run(b);  // this rank's segments: partition + score + merge, on the batch's stream
+  if (rc != SLG_OK) return rc;
+  rc = guarded([&] {
+    slg_index *ix = b->idx;
+    const size_t n = (size_t)b->nq * b->k, blk = 3 * n + b->nq;  // words of one rank's block
+    if (b->nq == 0) return;
+    hipStream_t st;
+    {
+      std::lock_guard<std::mutex> lk(ix->mu);
+      DeviceGuard dg(ix->device);
+      st = batch_stream(b);
+      if (!b->d_gather.p) b->d_gather.alloc_pooled(&ix->pool, (size_t)g->world * blk * 4);
+      if (!b->d_merged.p) b->d_merged.alloc_pooled(&ix->pool, blk * 4);
+      // ONE collective: every rank's contiguous block, in rank order
+      nccl_check(rccl().allgather(b->d_out.p, b->d_gather.p, blk, kNcclInt32, g->comm, st), "ncclAllGather");
+      uint32_t *m = b->d_merged.as<uint32_t>();
+      const uint32_t *gb = b->d_gather.as<uint32_t>();
+      if (b->k == 0) {
+        SLG_HIP(hipMemsetAsync(m, 0, blk * 4, st));
+      } else {
+        slg::ShardMergeParams mp{};
+        mp.doc = gb;
+        mp.seg = gb + n;
+        mp.score = reinterpret_cast<const float *>(gb + 2 * n);
+        mp.count = gb + 3 * n;
+        mp.out_doc = m;
+        mp.out_seg = m + n;
+        mp.out_score = reinterpret_cast<float *>(m + 2 * n);
+        mp.out_count = m + 3 * n;
+        mp.n_shards = (uint32_t)g->world;
+        mp.nq = b->nq;
+        mp.k = b->k;
+        mp.seg_stride = g->segs_per_rank;
+        mp.arr_stride = blk;
+        mp.cnt_stride = blk;
+        launch_shard_merge(mp, st);
+      }
+    }
+  });
+  // merged top-k to the caller's host arrays (else: slg_batch_fetch_sharded / _device_results later)
+  if (rc == SLG_OK && out_count) rc = slg_batch_fetch_sharded(b, out_doc, out_seg, out_score, out_count);
+  return rc;
+}
+
+int slg_batch_fetch_sharded(slg_batch *b, uint32_t *out_doc, uint32_t *out_seg, float *out_score,
+                            uint32_t *out_count) {
+  return guarded([&] {
+    SLG_REQUIRE_LIVE(b);
+    SLG_REQUIRE(b->nq == 0 || out_count != nullptr, "out_count is NULL");
+    SLG_REQUIRE(b->nq == 0 || b->k == 0 || (out_doc && out_seg && out_score), "output array is NULL");
+    if (b->nq == 0) return;
+    SLG_REQUIRE(b->d_merged.p != nullptr, "slg_batch_run_sharded has not run on this batch");
+    slg_index *ix = b->idx;
+    DeviceGuard dg(ix->device);
+    hipStream_t st;
+    {
+      std::lock_guard<std::mutex> lk(ix->mu);
+      st = batch_stream(b);
+    }
+    const size_t n = (size_t)b->nq * b->k, blk = 3 * n + b->nq;
+    std::vector<uint32_t> h(blk);
+    SLG_HIP(hipMemcpyAsync(h.data(), b->d_merged.p, blk * 4, hipMemcpyDeviceToHost, st));
+    SLG_HIP(hipStreamSynchronize(st));
+    if (n) {
+      std::memcpy(out_doc, h.data(), n * 4);
+      std::memcpy(out_seg, h.data() + n, n * 4);
+      std::memcpy(out_score, h.data() + 2 * n, n * 4);
+    }
+    std::memcpy(out_count, h.data() + 3 * n, (size_t)b->nq * 4);
+  });
+}
+
+int slg_batch_sharded_device_results(slg_batch *b, void **d_doc, void **d_seg, void **d_score, void **d_count) {
+  return guarded([&] {
+    SLG_REQUIRE_LIVE(b);
+    SLG_REQUIRE(b->d_merged.p != nullptr || b->nq == 0, "slg_batch_run_sharded has not run on this batch");
+    const size_t n = (size_t)b->nq * b->k;
+    uint32_t *m = b->d_merged.as<uint32_t>();
+    if (d_doc) *d_doc = m;
+    if (d_seg) *d_seg = m ? m + n : nullptr;
+    if (d_score) *d_score = m ? m + 2 * n : nullptr;
+    if (d_count) *d_count = m ? m + 3 * n : nullptr;
   });
 }
 
@@ -1862,16 +2176,16 @@ int slg_index_add_vector_field(slg_index *ix, const slg_vector_field_desc *per_s
       vd[s] = slg::VecSegDev{nullptr, nullptr, ix->segs[s]->n_docs, 0u, vf->metric, 0u};
       if (!d.vec_dim) continue;
       const size_t ob = (size_t)ix->segs[s]->n_docs * 4, vb = (size_t)d.vec_rows * d.vec_dim * 4;
-      vf->offsets[s].alloc(ob);
+      vf->offsets[s].alloc(ob, &ix->pool);
       if (ob) SLG_HIP(hipMemcpy(vf->offsets[s].p, d.vec_offsets, ob, hipMemcpyHostToDevice));
-      vf->values[s].alloc(vb);
+      vf->values[s].alloc(vb, &ix->pool);
       if (vb) SLG_HIP(hipMemcpy(vf->values[s].p, d.vec_values, vb, hipMemcpyHostToDevice));
       ix->device_bytes += vf->offsets[s].bytes + vf->values[s].bytes;
       vd[s].offsets = vf->offsets[s].as<uint32_t>();
       vd[s].values = vf->values[s].as<float>();
       vd[s].dim = d.vec_dim;
     }
-    vf->d_vsegs.alloc(n_segs * sizeof(slg::VecSegDev));
+    vf->d_vsegs.alloc(n_segs * sizeof(slg::VecSegDev), &ix->pool);
     SLG_HIP(hipMemcpy(vf->d_vsegs.p, vd.data(), n_segs * sizeof(slg::VecSegDev), hipMemcpyHostToDevice));
     ix->vfields.push_back(std::move(vf));
     id = (int)ix->vfields.size();
@@ -1986,18 +2300,18 @@ int slg_rerank_fields_batch(slg_index *ix, uint32_t nq, uint32_t n_clauses, cons
   rc = guarded([&] {
     DeviceGuard g(ix->device);
     hipStream_t st = ix->stream;
-    dq.alloc((size_t)nq * qf * 4);
-    da.alloc(nqc * 4);
-    if (boost) db.alloc(nqc * 4);
-    dcd.alloc(nc * 4);
-    dcs.alloc(nc * 4);
-    dcb.alloc(nc * 4);
-    dcc.alloc((size_t)nq * 4);
-    dod.alloc(no * 4);
-    dos.alloc(no * 4);
-    dosc.alloc(no * 4);
-    dov.alloc(no * 4);
-    doc_.alloc((size_t)nq * 4);
+    dq.alloc_pooled(&ix->pool, (size_t)nq * qf * 4);
+    da.alloc_pooled(&ix->pool, nqc * 4);
+    if (boost) db.alloc_pooled(&ix->pool, nqc * 4);
+    dcd.alloc_pooled(&ix->pool, nc * 4);
+    dcs.alloc_pooled(&ix->pool, nc * 4);
+    dcb.alloc_pooled(&ix->pool, nc * 4);
+    dcc.alloc_pooled(&ix->pool, (size_t)nq * 4);
+    dod.alloc_pooled(&ix->pool, no * 4);
+    dos.alloc_pooled(&ix->pool, no * 4);
+    dosc.alloc_pooled(&ix->pool, no * 4);
+    dov.alloc_pooled(&ix->pool, no * 4);
+    doc_.alloc_pooled(&ix->pool, (size_t)nq * 4);
     SLG_HIP(hipMemcpyAsync(dq.p, qvecs, (size_t)nq * qf * 4, hipMemcpyHostToDevice, st));
     SLG_HIP(hipMemcpyAsync(da.p, alpha, nqc * 4, hipMemcpyHostToDevice, st));
     if (boost) SLG_HIP(hipMemcpyAsync(db.p, boost, nqc * 4, hipMemcpyHostToDevice, st));
@@ -2056,18 +2370,18 @@ int slg_rerank_multi_batch(slg_index *ix, uint32_t nq, uint32_t n_clauses, const
   rc = guarded([&] {
     DeviceGuard g(ix->device);
     hipStream_t st = ix->stream;
-    dq.alloc(nqc * dim * 4);
-    da.alloc(nqc * 4);
-    if (boost) db.alloc(nqc * 4);
-    dcd.alloc(nc * 4);
-    dcs.alloc(nc * 4);
-    dcb.alloc(nc * 4);
-    dcc.alloc((size_t)nq * 4);
-    dod.alloc(no * 4);
-    dos.alloc(no * 4);
-    dosc.alloc(no * 4);
-    dov.alloc(no * 4);
-    doc_.alloc((size_t)nq * 4);
+    dq.alloc_pooled(&ix->pool, nqc * dim * 4);
+    da.alloc_pooled(&ix->pool, nqc * 4);
+    if (boost) db.alloc_pooled(&ix->pool, nqc * 4);
+    dcd.alloc_pooled(&ix->pool, nc * 4);
+    dcs.alloc_pooled(&ix->pool, nc * 4);
+    dcb.alloc_pooled(&ix->pool, nc * 4);
+    dcc.alloc_pooled(&ix->pool, (size_t)nq * 4);
+    dod.alloc_pooled(&ix->pool, no * 4);
+    dos.alloc_pooled(&ix->pool, no * 4);
+    dosc.alloc_pooled(&ix->pool, no * 4);
+    dov.alloc_pooled(&ix->pool, no * 4);
+    doc_.alloc_pooled(&ix->pool, (size_t)nq * 4);
     SLG_HIP(hipMemcpyAsync(dq.p, qvecs, nqc * dim * 4, hipMemcpyHostToDevice, st));
     SLG_HIP(hipMemcpyAsync(da.p, alpha, nqc * 4, hipMemcpyHostToDevice, st));
     if (boost) SLG_HIP(hipMemcpyAsync(db.p, boost, nqc * 4, hipMemcpyHostToDevice, st));
@@ -2123,17 +2437,17 @@ int slg_rerank_batch(slg_index *ix, uint32_t nq, const float *qvecs, const float
   rc = guarded([&] {
     DeviceGuard g(ix->device);
     hipStream_t st = ix->stream;
-    dq.alloc((size_t)nq * dim * 4);
-    da.alloc((size_t)nq * 4);
-    dcd.alloc(nc * 4);
-    dcs.alloc(nc * 4);
-    dcb.alloc(nc * 4);
-    dcc.alloc((size_t)nq * 4);
-    dod.alloc(no * 4);
-    dos.alloc(no * 4);
-    dosc.alloc(no * 4);
-    dov.alloc(no * 4);
-    doc_.alloc((size_t)nq * 4);
+    dq.alloc_pooled(&ix->pool, (size_t)nq * dim * 4);
+    da.alloc_pooled(&ix->pool, (size_t)nq * 4);
+    dcd.alloc_pooled(&ix->pool, nc * 4);
+    dcs.alloc_pooled(&ix->pool, nc * 4);
+    dcb.alloc_pooled(&ix->pool, nc * 4);
+    dcc.alloc_pooled(&ix->pool, (size_t)nq * 4);
+    dod.alloc_pooled(&ix->pool, no * 4);
+    dos.alloc_pooled(&ix->pool, no * 4);
+    dosc.alloc_pooled(&ix->pool, no * 4);
+    dov.alloc_pooled(&ix->pool, no * 4);
+    doc_.alloc_pooled(&ix->pool, (size_t)nq * 4);
     SLG_HIP(hipMemcpyAsync(dq.p, qvecs, (size_t)nq * dim * 4, hipMemcpyHostToDevice, st));
     SLG_HIP(hipMemcpyAsync(da.p, alpha, (size_t)nq * 4, hipMemcpyHostToDevice, st));
     if (nc) {

@@ -31,13 +31,21 @@ __host__ __device__ inline int champ_index(uint32_t k) {
 }
 
 // ---- device-side descriptors (built on the host per batch) ---------------------------
+// Posting arrays are PADDED per list: list t starts at term_offsets[t] + kListPad * t and is
+// followed by kListPad sentinel entries (doc = kDocEnd, impact = 0), so a whole 64-lane slot
+// loaded at ANY posting of a list never reads another list's postings: lanes past the list's end
+// see sentinels, lanes past a round's cut see later postings of the same list (docs >= the round's
+// end).  The scoring kernels therefore need no per-slot lane count to tell real postings from
+// foreign ones.  null_idx = a 64-entry run of sentinels (the slot unused descriptor lanes load).
+constexpr uint32_t kListPad = 64;
 struct SegDev {
-  const uint32_t *docs;     // [P] doc ids
-  const float *imps;        // [P] precomputed bm25 (weight == 1) per posting
+  const uint32_t *docs;     // [P + kListPad * (V + 1)] doc ids
+  const float *imps;        // same layout: precomputed bm25 (weight == 1) per posting
   const uint32_t *deleted;  // bitmap words or nullptr
   const float *champ;       // [V * kChampions] per-term descending impact lower bounds
   uint32_t n_docs;
   uint32_t pad;
+  uint64_t null_idx;        // index of kListPad sentinel entries
 };
 
 struct TermRef {  // one scored term of one sub-query
@@ -373,15 +381,16 @@ struct StageParams {
   uint64_t n_postings;
   uint32_t n_terms;
   uint32_t n_docs;
-  const uint64_t *term_offsets;  // [V+1]
-  const uint32_t *docs;          // [P]
+  const uint64_t *term_offsets;  // [V+1] (unpadded: positions in docs / tfs)
+  const uint32_t *docs;          // [P] as uploaded
   const uint32_t *tfs;           // [P]
   const float *term_idf;         // [V]
   const uint16_t *term_field;    // [V] or nullptr
   const float *const *field_doc_len;  // [F] device pointers (or nullptr entries)
   const float *field_avgdl;           // [F]
   float k1, b;
-  float *imps;  // out [P]
+  uint32_t *docs_out;  // out, padded layout: posting i of term t -> i + kListPad * t
+  float *imps;         // out, padded layout
 };
 
 static __global__ void __launch_bounds__(256) stage_impacts_kernel(StageParams p) {
@@ -417,7 +426,9 @@ static __global__ void __launch_bounds__(256) stage_impacts_kernel(StageParams p
     float idf = p.term_idf[t];
     float norm_dl = avgdl > 0.0f ? norm_len / avgdl : 1.0f;
     float denom = tf + p.k1 * (1.0f - p.b + p.b * norm_dl);
-    p.imps[i] = idf * (tf * (p.k1 + 1.0f)) / fmaxf(denom, 1e-6f);
+    const uint64_t at = i + (uint64_t)kListPad * t;
+    p.docs_out[at] = doc;
+    p.imps[at] = idf * (tf * (p.k1 + 1.0f)) / fmaxf(denom, 1e-6f);
   }
 }
 
@@ -430,9 +441,9 @@ static __global__ void __launch_bounds__(256) stage_impacts_kernel(StageParams p
 // statistics, but valid lower bounds, which is all the threshold seed needs: a doc's total
 // score is >= any one of its (non-negative) per-term contributions.
 struct ChampParams {
-  const uint64_t *term_offsets;  // [V+1]
-  const float *imps;             // [P]
-  const uint32_t *docs;          // [P]
+  const uint64_t *term_offsets;  // [V+1] (unpadded)
+  const float *imps;             // padded layout (SegDev)
+  const uint32_t *docs;          // padded layout
   const uint32_t *deleted;       // bitmap words or nullptr: deleted docs never count (accept())
   float *champ;                  // [V * kChampions]
   uint32_t n_terms;
@@ -443,7 +454,8 @@ static __global__ void __launch_bounds__(256) stage_champions_kernel(ChampParams
   const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const uint32_t n_waves = gridDim.x * kWavesPerBlock;
   for (uint32_t t = wave; t < p.n_terms; t += n_waves) {
-    const uint64_t a = p.term_offsets[t], b = p.term_offsets[t + 1];
+    const uint64_t a = p.term_offsets[t] + (uint64_t)kListPad * t;
+    const uint64_t b = a + (p.term_offsets[t + 1] - p.term_offsets[t]);
     float m[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) m[r] = 0.0f;
@@ -544,14 +556,18 @@ __global__ void __launch_bounds__(256) merge_topk_kernel(MergeParams p) {
 
 // ---- merge of per-shard results gathered over RCCL (api/reader.rs:2776-2778 across shards) --
 struct ShardMergeParams {
-  const uint32_t *doc;    // [n_shards][nq*k]
+  const uint32_t *doc;    // shard sh's rows start at doc + sh * arr_stride ([nq*k] each)
   const uint32_t *seg;
   const float *score;
-  const uint32_t *count;  // [n_shards][nq]
+  const uint32_t *count;  // shard sh's counts start at count + sh * cnt_stride ([nq])
   uint32_t *out_doc, *out_seg;
   float *out_score;
   uint32_t *out_count;
   uint32_t n_shards, nq, k, seg_stride;
+  // elements between two shards' arrays: nq*k / nq for separate shard-major arrays; (3k+1)*nq for
+  // both when the shards' contiguous result blocks doc|seg|score|count lie one after another, as an
+  // all-gather delivers them
+  uint64_t arr_stride, cnt_stride;
 };
 
 template <int KREGS>
@@ -563,8 +579,8 @@ __global__ void __launch_bounds__(256) merge_shards_kernel(ShardMergeParams p) {
   WaveTopK<KREGS, true> top;
   top.init();
   for (uint32_t sh = 0; sh < p.n_shards; sh++) {
-    const size_t row = ((size_t)sh * p.nq + q) * k;
-    const uint32_t cnt = rfl(p.count[(size_t)sh * p.nq + q]);
+    const size_t row = (size_t)sh * p.arr_stride + (size_t)q * k;
+    const uint32_t cnt = rfl(p.count[(size_t)sh * p.cnt_stride + q]);
     for (uint32_t base = 0; base < cnt; base += 64) {
       const uint32_t i = base + lane;
       int32_t ctk = kSentinelTk;
@@ -611,22 +627,22 @@ static __global__ void __launch_bounds__(256) merge_shards_large_kernel(ShardMer
   const uint32_t k = p.k;
   uint32_t total = 0;
   for (uint32_t sh = 0; sh < p.n_shards; sh++) {
-    const uint32_t c = p.count[(size_t)sh * p.nq + q];
+    const uint32_t c = p.count[(size_t)sh * p.cnt_stride + q];
     total += c < k ? c : k;
   }
   const uint32_t nout = total < k ? total : k;
   for (uint32_t e = threadIdx.x; e < p.n_shards * k; e += blockDim.x) {
     const uint32_t sh = e / k, i = e % k;
-    const uint32_t cnt_s = p.count[(size_t)sh * p.nq + q] < k ? p.count[(size_t)sh * p.nq + q] : k;
+    const uint32_t cnt_s = p.count[(size_t)sh * p.cnt_stride + q] < k ? p.count[(size_t)sh * p.cnt_stride + q] : k;
     if (i >= cnt_s) continue;
-    const size_t row = ((size_t)sh * p.nq + q) * k;
+    const size_t row = (size_t)sh * p.arr_stride + (size_t)q * k;
     const int32_t tk = total_key(p.score[row + i]);
     const uint32_t doc = p.doc[row + i], seg = sh * p.seg_stride + p.seg[row + i];
     uint32_t rank = i;
     for (uint32_t t = 0; t < p.n_shards; t++) {
       if (t == sh) continue;
-      const size_t rt = ((size_t)t * p.nq + q) * k;
-      uint32_t lo = 0, hi = p.count[(size_t)t * p.nq + q] < k ? p.count[(size_t)t * p.nq + q] : k;
+      const size_t rt = (size_t)t * p.arr_stride + (size_t)q * k;
+      uint32_t lo = 0, hi = p.count[(size_t)t * p.cnt_stride + q] < k ? p.count[(size_t)t * p.cnt_stride + q] : k;
       while (lo < hi) {  // first entry of shard t that is NOT better than mine
         const uint32_t mid = (lo + hi) >> 1;
         if (better<true>(total_key(p.score[rt + mid]), t * p.seg_stride + p.seg[rt + mid], p.doc[rt + mid], tk, seg, doc))

@@ -5,6 +5,7 @@
 
 #include "slg_score.hpp"
 #include "slg_score_uni.hpp"
+#include "slg_score_uni3.hpp"
 #include "slg_score_multi.hpp"
 
 #ifndef SLG_INST_KREGS
@@ -20,7 +21,12 @@ void launch_score_kregs(const RoundScoreParams &sp, int kind, hipStream_t st);
 // wave: a finished wave frees its wave slot and its LDS at once.
 template <>
 void launch_score_kregs<SLG_INST_KREGS>(const RoundScoreParams &sp, int kind, hipStream_t st) {
-  if (kind == 1) {  // <= 4 lists (slg_score_uni.hpp)
+  if (kind == 1) {  // <= 4 lists (slg_score_uni3.hpp)
+    hipLaunchKernelGGL((score_uniform3_kernel<SLG_INST_KREGS>), dim3(sp.n_slices), dim3(64),
+                       u3_wave_lds(SLG_INST_KREGS), st, sp);
+    return;
+  }
+  if (kind == 4) {  // the round-2 form of the same kernel (slg_tuning.uniform_kernel = 2: A/B timing)
     hipLaunchKernelGGL((score_uniform_kernel<SLG_INST_KREGS>), dim3(sp.n_slices), dim3(64),
                        uni_wave_lds(SLG_INST_KREGS), st, sp);
     return;

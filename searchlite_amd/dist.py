@@ -1,4 +1,6 @@
-"""Multi-GPU layer: one process per GPU, torch.distributed (backend "nccl" == RCCL over xGMI).
+"""Multi-GPU layer: one process per GPU.  The index-sharded data path (RCCL all-gather + device
+merge) lives behind the C ABI (slg_shard_group, include/searchlite_gpu.h); the helpers below are
+the host-side mirrors used by tests and by bench.py's query-sharded leg.
 
 The path shards in two ways:
   * index sharding  — rank r holds shard r of the index (a searchlite segment, with its own
@@ -112,40 +114,39 @@ def merge_shards_host(g_doc, g_seg, g_score, g_count, k: int, seg_stride: int = 
     return out_doc, out_seg, out_score, out_count
 
 
-class ShardedSearcher:
-    """Index-sharded search: this rank's GpuIndex is shard `rank` of the logical index."""
+def exchange_unique_id(rank: int, group=None) -> bytes:
+    """Control plane only: rank 0 makes the shard group's 128-byte id (slg_shard_unique_id) and the
+    others receive it through torch.distributed's object broadcast (any backend; a file, an
+    environment variable or MPI would do as well).  The DATA path never touches torch."""
+    import torch.distributed as dist
+    from . import searcher
+    box = [searcher.shard_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    return box[0]
 
-    def __init__(self, index, seg_stride: Optional[int] = None, group=None):
-        import torch
-        import torch.distributed as dist
-        self.index = index
-        self.group = group
-        self.world = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
-        self.seg_stride = seg_stride if seg_stride is not None else index.n_segs
-        index.set_stream(torch.cuda.current_stream().cuda_stream)
+
+class ShardedSearcher:
+    """Index-sharded search: this rank's GpuIndex is shard `rank` of the logical index.  The
+    exchange and the merge run behind the C ABI (slg_shard_group / slg_batch_run_sharded: one
+    ncclAllGather of the result blocks + merge_shards_kernel); torch.distributed, if present at all,
+    only carried the communicator id."""
+
+    def __init__(self, index, rank: int, world: int, unique_id: bytes, segs_per_rank: Optional[int] = None):
+        from . import searcher
+        self.index, self.rank, self.world = index, rank, world
+        self.group = searcher.ShardGroup(index, rank, world, unique_id, segs_per_rank)
+        self.seg_stride = self.group.segs_per_rank
+
+    def close(self) -> None:
+        self.group.close()
 
     def prepare(self, q_offsets, q_terms, q_weights, k: int, strategy=None):
         from . import searcher
         return self.index.prepare(q_offsets, q_terms, q_weights, k,
                                   searcher.Wand if strategy is None else strategy)
 
-    def run(self, batch) -> Tuple["object", "object", "object", "object"]:
-        """score locally -> all-gather -> device merge.  Returns device tensors
-        (doc[nq,k], seg[nq,k] = shard*seg_stride+seg, score[nq,k], count[nq])."""
-        import torch
-        batch.run()
-        nq, k = batch.nq, batch.k
-        g = all_gather_block(batch_result_block(batch), group=self.group)  # one exchange
-        g_doc, g_seg, g_score, g_count = split_result_block(g, nq, k)
-        g_doc, g_seg, g_score, g_count = (g_doc.contiguous(), g_seg.contiguous(),
-                                          g_score.contiguous(), g_count.contiguous())
-        m_doc = torch.empty((nq, k), dtype=torch.int32, device="cuda")
-        m_seg = torch.empty_like(m_doc)
-        m_score = torch.empty((nq, k), dtype=torch.float32, device="cuda")
-        m_count = torch.empty((nq,), dtype=torch.int32, device="cuda")
-        self.index.merge_shards_device(self.world, nq, k, g_doc.data_ptr(), g_seg.data_ptr(),
-                                       g_score.data_ptr(), g_count.data_ptr(), self.seg_stride,
-                                       m_doc.data_ptr(), m_seg.data_ptr(), m_score.data_ptr(),
-                                       m_count.data_ptr())
-        return m_doc, m_seg, m_score, m_count
+    def run(self, batch, fetch: bool = True):
+        """score locally -> all-gather -> device merge.  fetch=True: merged host arrays
+        (doc[nq,k], seg[nq,k] = shard*seg_stride+seg, score[nq,k], count[nq]); fetch=False: the
+        merged block stays on the device (batch.sharded_device_results())."""
+        return batch.run_sharded(self.group, fetch=fetch)

@@ -163,12 +163,16 @@ def read_fast_fields(buf: bytes, want_prefix: Optional[str] = None) -> Dict[str,
         d = []
         for _ in range(int(dl)):
             (sl,) = u32s(1)
+            if cur + int(sl) > len(buf):
+                raise SegFileError("fast-field dictionary is truncated")
             d.append(buf[cur:cur + int(sl)].decode("utf-8", "replace"))
             cur += int(sl)
         return d
 
     for _ in range(nf):
         (nl,) = u32s(1)
+        if cur + int(nl) + 1 > len(buf):
+            raise SegFileError("fast-field column header is truncated")
         name = buf[cur:cur + int(nl)].decode("utf-8", "replace")
         cur += int(nl)
         ty = buf[cur]
@@ -227,6 +231,8 @@ def read_vector_file(buf: bytes, n_docs: int):
         raise SegFileError(f"vector doc count mismatch: expected {n_docs}, found {docs}")
     if metric not in (0, 1):
         raise SegFileError(f"unknown vector metric code {metric}")
+    if 24 + 4 * docs + 4 * rows * dim > len(buf):
+        raise SegFileError("vector file is truncated")
     off = np.frombuffer(buf, dtype="<u4", count=docs, offset=24)
     vals = np.frombuffer(buf, dtype="<f4", count=rows * dim, offset=24 + 4 * docs).reshape(rows, dim)
     return int(dim), int(metric), off.copy(), vals.copy()

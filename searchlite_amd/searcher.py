@@ -97,6 +97,12 @@ class GpuIndex:
                                          C.addressof(nbytes)))
         return {"n_segs": ns.value, "n_postings": npost.value, "device_bytes": nbytes.value}
 
+    def trim_pool(self) -> int:
+        """Give the pooled work buffers of finished batches back to the runtime -> bytes freed."""
+        freed = C.c_uint64()
+        N.check(self._lib.slg_index_trim_pool(self._h, C.addressof(freed)))
+        return freed.value
+
     def set_stream(self, hip_stream) -> None:
         """Run on an external hipStream_t (e.g. torch.cuda.current_stream().cuda_stream; 0 is the
         HIP null stream = PyTorch's default stream).  None restores the index's own stream."""
@@ -350,6 +356,46 @@ class GpuIndex:
                                                   d_out_score, d_out_count))
 
 
+def shard_unique_id() -> bytes:
+    """slg_shard_unique_id: the 128-byte id rank 0 creates and hands to the other ranks of a shard
+    group out of band (ncclGetUniqueId)."""
+    buf = C.create_string_buffer(N.SHARD_UNIQUE_ID_BYTES)
+    N.check(N.load().slg_shard_unique_id(buf, N.SHARD_UNIQUE_ID_BYTES))
+    return buf.raw
+
+
+class ShardGroup:
+    """This rank's membership in an index-sharded search (slg_shard_group): its GpuIndex holds the
+    segments of shard `rank`; the RCCL communicator lives behind the C ABI, no torch involved.
+    Creation is collective: every rank constructs its ShardGroup with the same unique_id."""
+
+    def __init__(self, index: GpuIndex, rank: int, world: int, unique_id: bytes, segs_per_rank: Optional[int] = None):
+        self.index, self.rank, self.world = index, rank, world
+        self.segs_per_rank = index.n_segs if segs_per_rank is None else int(segs_per_rank)
+        self._lib = index._lib
+        assert len(unique_id) == N.SHARD_UNIQUE_ID_BYTES
+        self._h = self._lib.slg_shard_group_create(index._h, rank, world, unique_id, self.segs_per_rank)
+        if not self._h:
+            raise N.SlgError(N.last_error_code() or N.ERR_INVALID, N.last_error())
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.slg_shard_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 class PreparedBatch:
     """A planned query batch with device-resident descriptors and work buffers."""
 
@@ -391,6 +437,39 @@ class PreparedBatch:
 
     def run(self) -> None:
         N.check(self._lib.slg_batch_run(self._h))
+
+    def run_sharded(self, group: "ShardGroup", fetch: bool = True):
+        """slg_batch_run_sharded: this rank's segments, ONE ncclAllGather of the result blocks,
+        device merge.  fetch=True -> merged (doc, seg, score, count) host arrays (waits);
+        fetch=False -> None, the merged block stays on the device (sharded_device_results)."""
+        if not fetch:
+            N.check(self._lib.slg_batch_run_sharded(self._h, group._h, None, None, None, None))
+            return None
+        nq, k = self.nq, self.k
+        out_doc = np.zeros((nq, k), dtype=np.uint32)
+        out_seg = np.zeros((nq, k), dtype=np.uint32)
+        out_score = np.zeros((nq, k), dtype=np.float32)
+        out_count = np.zeros(nq, dtype=np.uint32)
+        N.check(self._lib.slg_batch_run_sharded(self._h, group._h, _ptr(out_doc), _ptr(out_seg),
+                                                _ptr(out_score), _ptr(out_count)))
+        return out_doc, out_seg, out_score, out_count
+
+    def fetch_sharded(self):
+        """Waits for run_sharded(fetch=False) -> merged (doc, seg, score, count) host arrays."""
+        nq, k = self.nq, self.k
+        out_doc = np.zeros((nq, k), dtype=np.uint32)
+        out_seg = np.zeros((nq, k), dtype=np.uint32)
+        out_score = np.zeros((nq, k), dtype=np.float32)
+        out_count = np.zeros(nq, dtype=np.uint32)
+        N.check(self._lib.slg_batch_fetch_sharded(self._h, _ptr(out_doc), _ptr(out_seg), _ptr(out_score),
+                                                  _ptr(out_count)))
+        return out_doc, out_seg, out_score, out_count
+
+    def sharded_device_results(self):
+        """-> (d_doc, d_seg, d_score, d_count) raw device addresses of the merged top-k."""
+        ptrs = [C.c_void_p() for _ in range(4)]
+        N.check(self._lib.slg_batch_sharded_device_results(self._h, *[C.addressof(p) for p in ptrs]))
+        return tuple(p.value for p in ptrs)
 
     def set_stream(self, hip_stream) -> None:
         """Run this batch on its own hipStream_t so several batches can be in flight at once

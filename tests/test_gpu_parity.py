@@ -700,34 +700,43 @@ def test_merge_shards_device_matches_multi_segment_oracle(gpu, oracle):
 
 
 def test_sharded_searcher_one_rank_rccl(gpu, oracle):
-    """ShardedSearcher end to end on one rank: RCCL all-gather of the result block + device merge."""
-    import os
-    import socket
-    import torch
-    import torch.distributed as tdist
-    from searchlite_amd import dist as sdist
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        rng = np.random.default_rng(32)
-        segs = [random_segment(rng, 1200, 30, 15), random_segment(rng, 900, 30, 15)]
-        offs, terms, w = random_queries(rng, 10, 3, 30, n_segs=2)
-        want = _oracle_batch(oracle, segs, offs, terms, w, 11)
+    """ShardedSearcher end to end on one rank, NO torch.distributed anywhere: the library binds
+    librccl itself (slg_shard_unique_id -> slg_shard_group_create = ncclCommInitRank), ONE
+    ncclAllGather of the contiguous result block on the batch's stream, merge_shards_kernel over
+    the gathered blocks in place (slg_batch_run_sharded).  Two segments on the rank, so segment
+    ordinals in the merged rows are rank * segs_per_rank + local ordinal (api/reader.rs:2776-2778)."""
+    from searchlite_amd import dist as sdist, searcher
+    rng = np.random.default_rng(32)
+    segs = [random_segment(rng, 1200, 30, 15), random_segment(rng, 900, 30, 15)]
+    offs, terms, w = random_queries(rng, 10, 3, 30, n_segs=2)
+    uid = searcher.shard_unique_id()
+    assert len(uid) == 128 and any(uid)
+    for k in (11, 1500):  # register merge, and merge_shards_large_kernel (k > 1024)
+        want = _oracle_batch(oracle, segs, offs, terms, w, k)
         with gpu.GpuIndex(segs) as ix:
-            ss = sdist.ShardedSearcher(ix)
-            b = ss.prepare(offs, terms, w, 11)
-            m_doc, m_seg, m_score, m_count = ss.run(b)
-            torch.cuda.synchronize()
-            got = (m_doc.cpu().numpy().view(np.uint32), m_seg.cpu().numpy().view(np.uint32),
-                   m_score.cpu().numpy(), m_count.cpu().numpy().view(np.uint32))
+            ss = sdist.ShardedSearcher(ix, 0, 1, uid if k == 11 else searcher.shard_unique_id())
+            b = ss.prepare(offs, terms, w, k)
+            got = ss.run(b)                      # run + gather + merge + D2H
+            assert_same_hits(got, want, 0.0, f"sharded searcher, one rank, k={k}")
+            assert ss.run(b, fetch=False) is None  # asynchronous form, collected later
+            again = b.fetch_sharded()
+            assert_same_hits(again, want, 0.0, "sharded searcher, fetch_sharded")
+            assert all(p for p in b.sharded_device_results())
             b.close()
-        assert_same_hits(got, want, 0.0, "sharded searcher, one rank")
-    finally:
-        tdist.destroy_process_group()
+            ss.close()
+
+
+def test_shard_group_argument_checks(gpu):
+    from searchlite_amd import _native as N, searcher
+    rng = np.random.default_rng(3)
+    seg = random_segment(rng, 100, 20, 8)
+    with gpu.GpuIndex([seg, seg]) as ix:
+        with pytest.raises(N.SlgError) as e:
+            searcher.ShardGroup(ix, 2, 2, searcher.shard_unique_id())
+        assert e.value.code == N.ERR_INVALID          # rank outside [0, world)
+        with pytest.raises(N.SlgError) as e:
+            searcher.ShardGroup(ix, 0, 1, searcher.shard_unique_id(), segs_per_rank=1)
+        assert e.value.code == N.ERR_INVALID          # fewer ordinals per rank than segments held
 
 
 # ---- the C++ host mirror (include/searchlite_gpu.hpp) ---------------------------------------------

@@ -23,8 +23,10 @@ L.slg_debug_read_stamps.restype = C.c_int
 L.slg_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 assert L.slg_debug_read_stamps(b._h, out.ctypes.data, n) == 0
 T_ = int(os.environ.get("TERMS", "3"))
-names = ["0 plan/issue next", "1 chunk setup", "2 P0+P1 clear+or", "3 P2 read back", "4 P3 queue",
-         "5 singles", "6 P4 join", "7 wait loads+copy"] if T_ <= 4 else \
+names = (["0 describe + issue next", "1 chunk setup / loop", "2 P0+P1 clear+or", "3 P2+P3 read back + flags", "4 queue build",
+          "5 -", "6 join + candidates", "7 wait loads + settle"] if os.environ.get("SLG_UNIFORM_KERNEL", "3") != "2" else
+         ["0 plan/issue next", "1 chunk setup", "2 P0+P1 clear+or", "3 P2 read back", "4 P3 queue",
+          "5 singles", "6 P4 join", "7 wait loads+copy"]) if T_ <= 4 else \
         ["0 round setup (bounds, describe)", "1 P0 clear", "2 sweep A (bits)", "3 P2 prefix", "4 sweep C (accumulate)",
          "5 P4 top-k", "6 advance / tail", "7 -"]
 ins = out[:, 8] & np.uint64(0xFFFFFFFF); queued = out[:, 8] >> np.uint64(32)
