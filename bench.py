@@ -15,12 +15,13 @@ kernel's own duration (HIP events on its stream, batches rotating, one at a time
 
 N > 1 (launched by the driver through torch.distributed.run, or by `--gpus N` itself, which starts
 the N ranks as a child torchrun before touching any GPU): query batches shard across replicas of
-the index (weak scaling, no data-path collective; the device-resident leg exchanges the per-rank
-top-k with ONE RCCL all-gather per step).  In addition the BASELINE configs[3] shape is timed
+the index (weak scaling, no data-path collective: every rank serves its own queries).  In addition the BASELINE configs[3] shape is timed
 (`c4` object; `--config c4` makes it the main workload): the 10M-doc corpus as 8 segments of
 1.25M docs (seeds 43..50) index-sharded over the N ranks, batch 8192 x 5 terms, top-100; every
-rank scores all queries against its segments, ONE all-gather of the (3k+1)*Q*4-byte result
-blocks over xGMI, device merge (strong scaling: the same 8 segments at every N).
+rank scores all queries against its segments, ONE ncclAllGather of the (3k+1)*Q*4-byte result
+blocks over xGMI behind the C ABI (slg_batch_run_sharded), device merge (strong scaling: the same 8
+segments at every N).  torch.distributed carries only the control plane (rendezvous, the 128-byte
+communicator id, barriers and the max-over-ranks of the timings).
 
 Prints ONE JSON line on rank 0.
 """
@@ -395,12 +396,6 @@ def main():
     if inflight > 1:
         for j, b in enumerate(batches):
             b.set_stream(streams[j % inflight].cuda_stream)
-    if use_dist:
-        t_blocks, g_blocks = [], []
-        for b in batches:
-            ptr, nbytes = b.device_result_block()
-            t_blocks.append(torch.as_tensor(_DevArray(ptr, (nbytes // 4,), "<i4"), device="cuda"))
-            g_blocks.append(torch.empty((world * (nbytes // 4),), dtype=torch.int32, device="cuda"))
     if rerank:
         seg.vec_values = None  # staged in HBM; free the host copy
         k_out = 10
@@ -415,15 +410,12 @@ def main():
         r_count = torch.empty((nq,), dtype=torch.int32, device="cuda")
         ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
         ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    gathered = [None] * n_sets
     turn = [0]
 
     def resident_step(timed_idx=None):
         j = turn[0] % n_sets
         turn[0] += 1
         b = batches[j]
-        if inflight > 1 and use_dist and gathered[j] is not None:
-            streams[j % inflight].wait_event(gathered[j])  # the previous gather of this block is done
         b.run()
         if rerank:  # candidates = the BM25 pass's device results (no host round trip)
             if timed_idx is not None:
@@ -434,13 +426,6 @@ def main():
                                       r_vec.data_ptr(), r_count.data_ptr())
             if timed_idx is not None:
                 ev_b[timed_idx].record()
-        if use_dist:
-            # per-rank top-k exchanged over xGMI in ONE all-gather: the contiguous block
-            # doc|seg|score|count = (3k+1)*Q*4 bytes per rank (RCCL stays on the default stream)
-            if inflight > 1:
-                stream.wait_event(streams[j % inflight].record_event())
-            dist.all_gather_into_tensor(g_blocks[j], t_blocks[j])
-            gathered[j] = stream.record_event()
 
     for _ in range(args.warmup):
         resident_step()
@@ -511,8 +496,7 @@ def main():
                        "posting_working_set_bytes": int(8 * sum(i["n_postings"] for i in infos)),
                        "kernel_only_qps": round(resident_qps, 1),
                        "kernel_only_ms_per_step": round(res_elapsed / args.steps * 1e3, 4),
-                       "kernel_only_is": f"pre-planned device-resident batches, {inflight} in flight"
-                                         + (", + one all-gather of the result block per step" if use_dist else ""),
+                       "kernel_only_is": f"pre-planned device-resident batches, {inflight} in flight",
                        "postings_per_batch": int(np.mean([i["n_postings"] for i in infos])),
                        "slices": int(np.mean([i["n_slices"] for i in infos])),
                        "all_ranks_postings": int(total_postings),

@@ -272,6 +272,32 @@ slg_batch *slg_batch_prepare_plan(slg_index *index, uint32_t nq, const uint32_t 
                                   const uint32_t *q_leaf, const int32_t *q_plan, const float *q_tie,
                                   const uint32_t *q_nleaves, const int32_t *q_filter, uint32_t k,
                                   int strategy);
+
+/* Two-level score plans.  ScoreExpr::evaluate is recursive (query/planner.rs:122-153) and real
+ * requests build two-level trees: `dis_max{queries}` = a DisMax of sub-scorers
+ * (planner.rs:470-487), `bool{should:[multi_match ...]}` = a Sum of DisMax groups
+ * (planner.rs:670-690).  Here the ROOT (q_plan / q_tie) combines GROUPS, a group (group_plan /
+ * group_tie) combines LEAVES, a leaf sums the scored terms that name it (wand.rs:488-497).
+ * Leaves are numbered in the plan's traversal order, so a group's leaves are consecutive:
+ * leaf_group is non-decreasing within a query and names every group 0 .. n_groups-1.  A leaf that
+ * hangs off the root directly is a SLG_PLAN_SUM group of one leaf (Sum of one child is the child,
+ * bit for bit).  With leaf_group == NULL this is slg_batch_prepare_plan.  Every DisMax counts all
+ * of its children, the ones without a posting for a doc as 0.0, as the reference does. */
+typedef struct {
+  const uint32_t *q_leaf;           /* [total terms] leaf of every query term; NULL: term i = leaf i */
+  const int32_t *q_plan;            /* [nq] root: SLG_PLAN_SUM | SLG_PLAN_DISMAX; NULL: Sum */
+  const float *q_tie;               /* [nq] root tie breaker in [0, 1]; NULL: 0 */
+  const uint32_t *q_nleaves;        /* [nq] leaves of the plan; NULL: 1 + the largest leaf named */
+  const uint32_t *q_leaf_offsets;   /* [nq + 1] into leaf_group (two-level plans only) */
+  const uint32_t *leaf_group;       /* group of every leaf of every query; NULL: flat plans */
+  const uint32_t *q_group_offsets;  /* [nq + 1] into group_plan / group_tie */
+  const int32_t *group_plan;        /* SLG_PLAN_SUM | SLG_PLAN_DISMAX per group */
+  const float *group_tie;           /* tie breaker per group, in [0, 1] */
+} slg_score_plans;
+slg_batch *slg_batch_prepare_plans(slg_index *index, uint32_t nq, const uint32_t *q_offsets,
+                                   const uint32_t *q_term_ids, const float *q_weights,
+                                   const slg_score_plans *plans_or_null, const int32_t *q_filter_or_null,
+                                   uint32_t k, int strategy);
 /* Enqueue the partition / score / merge kernels on the batch's stream (asynchronous). */
 int slg_batch_run(slg_batch *batch);
 /* Run this batch on its own HIP stream instead of the index stream, so several prepared

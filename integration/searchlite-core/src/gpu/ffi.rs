@@ -32,6 +32,11 @@ pub struct slg_tuning {
 #[repr(C)] pub struct slg_vector_field_desc {
     pub vec_dim: u32, pub vec_metric: i32, pub vec_offsets: *const u32, pub vec_values: *const c_float, pub vec_rows: u32,
 }
+#[repr(C)] pub struct slg_score_plans {
+    pub q_leaf: *const u32, pub q_plan: *const i32, pub q_tie: *const c_float, pub q_nleaves: *const u32,
+    pub q_leaf_offsets: *const u32, pub leaf_group: *const u32, pub q_group_offsets: *const u32,
+    pub group_plan: *const i32, pub group_tie: *const c_float,
+}
 #[repr(C)] pub struct slg_stats { pub scored_docs: u64, pub candidates_examined: u64, pub postings_advanced: u64 }
 #[repr(C)] pub struct slg_query { pub n_terms: u32, pub term_ids: *const u32, pub weights: *const c_float }
 
@@ -83,6 +88,9 @@ extern "C" {
         q_term_ids: *const u32, q_weights: *const c_float, q_leaf: *const u32, q_plan: *const i32,
         q_tie: *const c_float, q_nleaves: *const u32, q_filter: *const i32, k: u32,
         strategy: c_int) -> *mut slg_batch;
+    pub fn slg_batch_prepare_plans(index: *mut slg_index, nq: u32, q_offsets: *const u32, q_term_ids: *const u32,
+        q_weights: *const c_float, plans_or_null: *const slg_score_plans, q_filter_or_null: *const i32,
+        k: u32, strategy: c_int) -> *mut slg_batch;
     pub fn slg_batch_set_stream(batch: *mut slg_batch, hip_stream: *mut c_void) -> c_int;
     pub fn slg_batch_run(batch: *mut slg_batch) -> c_int;
     pub fn slg_batch_sync(batch: *mut slg_batch) -> c_int;

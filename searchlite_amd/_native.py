@@ -65,6 +65,13 @@ class Tuning(C.Structure):
                 ("uniform_kernel", C.c_uint32)]
 
 
+class ScorePlans(C.Structure):
+    """slg_score_plans: flat (leaf_group NULL) or two-level score plans."""
+    _fields_ = [("q_leaf", C.c_void_p), ("q_plan", C.c_void_p), ("q_tie", C.c_void_p), ("q_nleaves", C.c_void_p),
+                ("q_leaf_offsets", C.c_void_p), ("leaf_group", C.c_void_p), ("q_group_offsets", C.c_void_p),
+                ("group_plan", C.c_void_p), ("group_tie", C.c_void_p)]
+
+
 class Query(C.Structure):
     _fields_ = [("n_terms", C.c_uint32), ("term_ids", C.c_void_p), ("weights", C.c_void_p)]
 
@@ -125,6 +132,7 @@ def load():
         "slg_batch_prepare": (vp, [vp, u32, vp, vp, vp, u32, i32]),
         "slg_batch_prepare_filtered": (vp, [vp, u32, vp, vp, vp, vp, u32, i32]),
         "slg_batch_prepare_plan": (vp, [vp, u32, vp, vp, vp, vp, vp, vp, vp, vp, u32, i32]),
+        "slg_batch_prepare_plans": (vp, [vp, u32, vp, vp, vp, vp, vp, u32, i32]),
         "slg_batch_run": (i32, [vp]),
         "slg_batch_set_stream": (i32, [vp, vp]),
         "slg_batch_sync": (i32, [vp]),

@@ -3,6 +3,7 @@
 * lib/libsearchlite_gpu.so — the product: HIP kernels + C ABI for gfx950 (hipcc).
 * lib/libslg_corpus.so     — harness tool: synthetic Zipf corpus generator (g++, host only).
 * lib/libslg_segfile.so    — host-only decoder of searchlite's segment files (g++).
+* lib/libslg_plan.so       — the host planner behind a test C ABI (g++; CPU unit tests).
 
 hipcc cross-compiles gfx950 without a GPU, so this runs in the build container; the built
 .so files travel to the GPU box with the repo snapshot.
@@ -52,13 +53,15 @@ def build_gpu(force: bool = False, verbose: bool = False, stamps: bool = False, 
     objdir = os.path.join(LIBDIR, f"obj_{tag}" if tag else "obj")
     out_lib = os.path.join(LIBDIR, f"libsearchlite_gpu_{tag}.so") if tag else GPU_LIB
     os.makedirs(objdir, exist_ok=True)
-    hdrs = [os.path.join(CSRC, h) for h in ("slg_kernels.hpp", "slg_rerank.hpp", "slg_score.hpp", "slg_score_uni.hpp", "slg_score_uni3.hpp",
-                                           "slg_score_multi.hpp")]
+    hdrs = [os.path.join(CSRC, h) for h in ("slg_desc.hpp", "slg_kernels.hpp", "slg_rerank.hpp", "slg_score.hpp", "slg_score_uni.hpp", "slg_score_uni3.hpp",
+                                           "slg_score_multi.hpp", "slg_plan.hpp")]
     hdrs.append(os.path.join(_HERE, "..", "include", "searchlite_gpu.h"))
     compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"] + (["-DSLG_STAMPS"] if stamps else []) \
         + [f"-D{d}" for d in defines]
     kregs = (1,) if stamps else SCORE_KREGS
-    jobs = [(os.path.join(CSRC, "slg_api.hip"), os.path.join(objdir, "slg_api.o"), [])]
+    jobs = [(os.path.join(CSRC, "slg_api.hip"), os.path.join(objdir, "slg_api.o"), []),
+            # the host planner: plain C++ (the same source builds with g++ for the CPU unit tests)
+            (os.path.join(CSRC, "slg_plan.cpp"), os.path.join(objdir, "slg_plan.o"), ["-x", "c++"])]
     for kr in kregs:
         jobs.append((os.path.join(CSRC, "slg_score_inst.hip"),
                      os.path.join(objdir, f"slg_score_k{kr}.o"), [f"-DSLG_INST_KREGS={kr}"]))
@@ -104,10 +107,28 @@ def build_segfile(force: bool = False) -> str:
     return SEGFILE_LIB
 
 
+PLAN_LIB = os.path.join(LIBDIR, "libslg_plan.so")
+
+
+def build_plan_lib(force: bool = False, extra_flags=(), out: str | None = None) -> str:
+    """The host planner (csrc/slg_plan.cpp: the same source libsearchlite_gpu.so links) behind a
+    small C ABI for the CPU unit tests (tests/test_plan.py).  g++, host only."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    out = out or PLAN_LIB
+    srcs = [os.path.join(CSRC, "slg_plan.cpp"), os.path.join(CSRC, "slg_plan_capi.cpp")]
+    hdrs = [os.path.join(CSRC, "slg_plan.hpp"), os.path.join(CSRC, "slg_desc.hpp"),
+            os.path.join(_HERE, "..", "include", "searchlite_gpu.h")]
+    if force or _newer(out, srcs + hdrs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", *extra_flags,
+                               "-o", out, *srcs])
+    return out
+
+
 def build_all(force: bool = False, verbose: bool = False) -> None:
     build_gpu(force, verbose)
     build_corpus_tool(force)
     build_segfile(force)
+    build_plan_lib(force)
 
 
 if __name__ == "__main__":

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "slg_kernels.hpp"
+#include "slg_plan.hpp"
 #include "slg_rerank.hpp"
 #include "slg_score.hpp"
 #include "slg_score_uni.hpp"
@@ -36,10 +37,7 @@ namespace {
 thread_local std::string g_last_error;
 thread_local int g_last_code = SLG_OK;
 
-struct SlgError : std::runtime_error {
-  int code;
-  SlgError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
-};
+using slgplan::SlgError;  // {code, message}; also what the host planner throws
 
 #define SLG_HIP(expr)                                                                     \
   do {                                                                                    \
@@ -309,6 +307,7 @@ struct slg_batch {
   uint32_t n_sq = 0, n_slices = 0, n_terms = 0, n_boundaries = 0, max_terms = 0;
   bool uniform = false;  // every sub-query fits the one-list-per-slot kernel
   bool plan_batch = false;  // some sub-query has a score plan (multi kernel only)
+  bool nested = false;      // some sub-query has a two-level plan (groups of leaves)
   bool pruned = false;      // some sub-query has non-essential lists (MaxScore)
   bool multi = false;    // many-term form of it (slg_score_multi.hpp); else the packed kernel
   uint64_t n_postings = 0, n_postings_essential = 0, n_rounds = 0;
@@ -589,13 +588,6 @@ void stage_segment(slg_index *ix, SegHost &sh, const slg_segment_desc &d) {
   }
 }
 
-template <typename T>
-size_t place(size_t &cursor, size_t count) {
-  cursor = (cursor + 15) & ~(size_t)15;
-  size_t at = cursor;
-  cursor += count * sizeof(T);
-  return at;
-}
 
 }  // namespace
 
@@ -909,487 +901,83 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
                                   const uint32_t *q_leaf, const int32_t *q_plan, const float *q_tie,
                                   const uint32_t *q_nleaves, const int32_t *q_filter, uint32_t k,
                                   int strategy) {
+  slg_score_plans pl{};
+  pl.q_leaf = q_leaf;
+  pl.q_plan = q_plan;
+  pl.q_tie = q_tie;
+  pl.q_nleaves = q_nleaves;
+  return slg_batch_prepare_plans(ix, nq, q_offsets, q_term_ids, q_weights, &pl, q_filter, k, strategy);
+}
+
+slg_batch *slg_batch_prepare_plans(slg_index *ix, uint32_t nq, const uint32_t *q_offsets,
+                                   const uint32_t *q_term_ids, const float *q_weights,
+                                   const slg_score_plans *plans, const int32_t *q_filter, uint32_t k,
+                                   int strategy) {
   slg_batch *b = nullptr;
   int rc = guarded([&] {
     SLG_REQUIRE(ix != nullptr, "index is NULL");
-    SLG_REQUIRE(nq == 0 || q_offsets != nullptr, "q_offsets is NULL");
-    SLG_REQUIRE(strategy == SLG_STRATEGY_BM25 || strategy == SLG_STRATEGY_WAND ||
-                    strategy == SLG_STRATEGY_BMW,
-                "unknown strategy");
-    if (k > SLG_MAX_K)
-      throw SlgError(SLG_ERR_UNSUPPORTED, "k > SLG_MAX_K (" + std::to_string(SLG_MAX_K) + ")");
-    const uint32_t n_segs = (uint32_t)ix->segs.size();
-    const uint32_t total_terms = nq ? q_offsets[nq] : 0;
-    SLG_REQUIRE(total_terms == 0 || (q_term_ids && q_weights), "q_term_ids/q_weights is NULL");
-    // Planning reads only immutable index data (segments are fixed at create), so host threads
-    // may prepare batches for one index concurrently; the index mutex is held just to look at
-    // the filter table.
+    // Planning (slg_plan.cpp: a pure host function) reads only immutable index data — segments are
+    // fixed at create — so host threads may prepare batches for one index concurrently; the index
+    // mutex is held just to look at the filter table.
     std::vector<char> filter_live;
     {
       std::lock_guard<std::mutex> lk(ix->mu);
       filter_live.resize(ix->filters.size());
       for (size_t f = 0; f < ix->filters.size(); f++) filter_live[f] = !ix->filters[f].empty();
     }
-    DeviceGuard g(ix->device);
+    std::vector<slgplan::SegView> views(ix->segs.size());
+    for (size_t s = 0; s < ix->segs.size(); s++) {
+      const SegHost &sh = *ix->segs[s];
+      views[s].n_docs = sh.n_docs;
+      views[s].n_terms = sh.n_terms;
+      views[s].term_offsets = sh.term_offsets.data();
+      views[s].champ = sh.champ.empty() ? nullptr : sh.champ.data();
+    }
+    slgplan::BatchIn in;
+    in.nq = nq;
+    in.q_offsets = q_offsets;
+    in.q_term_ids = q_term_ids;
+    in.q_weights = q_weights;
+    if (plans) in.plans = *plans;
+    in.q_filter = q_filter;
+    in.k = k;
+    in.strategy = strategy;
+    in.filter_live = filter_live.data();
+    in.n_filters = filter_live.size();
+    slgplan::Plan plan;
+    slgplan::plan_batch(views, ix->tune, in, plan);
 
+    DeviceGuard g(ix->device);
     b = new slg_batch();
     b->idx = ix;
     b->nq = nq;
     b->k = k;
     b->strategy = strategy;
-    b->q_postings.assign(nq, 0);
+    b->q_postings.swap(plan.q_postings);
+    b->n_postings = plan.n_postings;
+    b->n_postings_essential = plan.n_postings_essential;
+    b->n_postings_nonessential = plan.n_postings_nonessential;
+    b->n_rounds = plan.n_rounds;
+    b->max_terms = plan.max_terms;
+    b->uniform = plan.uniform;
+    b->multi = plan.multi;
+    b->plan_batch = plan.plan_batch;
+    b->nested = plan.nested;
+    b->pruned = plan.pruned;
+    b->cand_mode = plan.cand_mode;
+    b->n_sq = (uint32_t)plan.sqs.size();
+    b->n_terms = (uint32_t)plan.terms.size();
+    b->n_slices = (uint32_t)plan.slice_sq.size();
+    b->n_boundaries = (uint32_t)plan.n_bnd;
 
-    // ---- pass 1: sub-queries and their terms (api/reader.rs:2986-3005) ----
-    std::vector<slg::RoundQuery> sqs;
-    std::vector<slg::TermRef> terms;
-    std::vector<uint64_t> sq_postings, sq_postings_all;
-    std::vector<uint32_t> q_sq_begin(nq + 1, 0);
-    bool any_filter = false, any_plan = false;
-    // cheap validation first: every later loop indexes q_term_ids / q_weights / q_leaf through
-    // these offsets (and the leaf scan below is quadratic in a query's term count)
-    uint32_t batch_max_nt = 0;
-    for (uint32_t q = 0; q < nq; q++) {
-      SLG_REQUIRE(q_offsets[q + 1] >= q_offsets[q] && q_offsets[q + 1] <= total_terms,
-                  "q_offsets not monotone");
-      const uint32_t nt = q_offsets[q + 1] - q_offsets[q];
-      if (nt > SLG_MAX_QUERY_TERMS)
-        throw SlgError(SLG_ERR_UNSUPPORTED, "query " + std::to_string(q) + " has more than " +
-                                                std::to_string(SLG_MAX_QUERY_TERMS) + " terms");
-      batch_max_nt = std::max(batch_max_nt, nt);
-    }
-    const slg_tuning &tn = ix->tune;
-    const bool maxscore_on = tn.pruning >= 0 ? tn.pruning != 0 : batch_max_nt > tn.uniform_max_terms;
-    // Score plans run on the multi kernel only, which has no MaxScore path: if any query of the
-    // batch can need a plan (a DisMax, or two terms sharing a leaf), nothing is classified.
-    bool plans_requested = false;
-    for (uint32_t q = 0; q < nq && !plans_requested; q++) {
-      if (q_plan && q_plan[q] == SLG_PLAN_DISMAX) plans_requested = true;
-      if (q_leaf && q_offsets[q + 1] >= q_offsets[q]) {
-        const uint32_t t0 = q_offsets[q], nt = q_offsets[q + 1] - t0;
-        for (uint32_t i = 0; i < nt && !plans_requested; i++)
-          for (uint32_t j = 0; j < i; j++)
-            if (q_leaf[t0 + i] == q_leaf[t0 + j]) {
-              plans_requested = true;
-              break;
-            }
-      }
-    }
-    // Pass 1 is per query: large batches (config 4: 8192 queries x 8 segments = 65K sub-queries,
-    // 15 ms on one thread, mostly cache misses in the champion tables) are planned by several
-    // threads, each into its own vectors, stitched together in query order afterwards.
-    struct Pass1Out {
-      std::vector<slg::RoundQuery> sqs;
-      std::vector<slg::TermRef> terms;
-      std::vector<uint64_t> sq_postings, sq_postings_all;
-      uint64_t n_postings = 0, n_ess = 0, n_noness = 0;
-      uint32_t max_terms = 0;
-      bool any_plan = false, any_filter = false;
-      std::exception_ptr err;
-    };
-    auto plan_range = [&](const uint32_t q_lo, const uint32_t q_hi, Pass1Out &o) {
-      auto &sqs = o.sqs;
-      auto &terms = o.terms;
-      auto &sq_postings = o.sq_postings;
-      auto &sq_postings_all = o.sq_postings_all;
-      bool &any_plan = o.any_plan;
-      bool &any_filter = o.any_filter;
-      for (uint32_t q = q_lo; q < q_hi; q++) {
-        q_sq_begin[q] = (uint32_t)sqs.size();
-        SLG_REQUIRE(q_offsets[q + 1] >= q_offsets[q], "q_offsets not monotone");
-        const uint32_t t0 = q_offsets[q], nt = q_offsets[q + 1] - t0;
-        if (nt > SLG_MAX_QUERY_TERMS)
-          throw SlgError(SLG_ERR_UNSUPPORTED, "query " + std::to_string(q) + " has more than " +
-                                                  std::to_string(SLG_MAX_QUERY_TERMS) + " terms");
-        uint32_t fq = 0;  // doc filter of the query (0 none, id + 1)
-        if (q_filter && q_filter[q] >= 0) {
-          SLG_REQUIRE((size_t)q_filter[q] < filter_live.size() && filter_live[q_filter[q]],
-                      "unknown filter id in query " + std::to_string(q));
-          fq = (uint32_t)q_filter[q] + 1u;
-          any_filter = true;
-        }
-        // score plan of the query (query/planner.rs:113-153)
-        const int plan_kind = q_plan ? q_plan[q] : SLG_PLAN_SUM;
-        SLG_REQUIRE(plan_kind == SLG_PLAN_SUM || plan_kind == SLG_PLAN_DISMAX,
-                    "unknown score plan in query " + std::to_string(q));
-        const float tie = q_tie ? q_tie[q] : 0.0f;
-        // validate_tie_breaker (query/planner.rs:850-856); the threshold seed and the pruning bounds
-        // also rely on it: with tie in [0, 1] a DisMax is >= each of its non-negative leaves
-        SLG_REQUIRE(tie >= 0.0f && tie <= 1.0f,
-                    "tie breaker outside [0, 1] in query " + std::to_string(q));
-        uint32_t n_leaves = q_nleaves ? q_nleaves[q] : 0;
-        for (uint32_t i = 0; i < nt; i++) {
-          const uint32_t lf = q_leaf ? q_leaf[t0 + i] : i;
-          SLG_REQUIRE(lf < 0x80000000u, "leaf index >= 2^31 in query " + std::to_string(q));
-          n_leaves = std::max(n_leaves, lf + 1u);
-        }
-        if (k == 0) continue;  // wand.rs:413-416: k == 0 and no collector => no work
-        for (uint32_t s = 0; s < n_segs; s++) {
-          const SegHost &sh = *ix->segs[s];
-          slg::RoundQuery sq{};
-          sq.q = q;
-          sq.seg = s;
-          sq.filter = fq;
-          sq.term_begin = (uint32_t)terms.size();
-          uint64_t P = 0;
-          uint32_t longest = 0, longest_df = 0;
-          for (uint32_t i = 0; i < nt; i++) {
-            const uint32_t tid = q_term_ids[(size_t)(t0 + i) * n_segs + s];
-            if (tid == SLG_NO_TERM) continue;
-            SLG_REQUIRE(tid < sh.n_terms, "term id out of range in query " + std::to_string(q));
-            const uint32_t df = (uint32_t)(sh.term_offsets[tid + 1] - sh.term_offsets[tid]);
-            const uint64_t off = sh.term_offsets[tid] + (uint64_t)slg::kListPad * tid;  // padded layout
-            if (df == 0) continue;  // wand.rs:441 filter(postings.len() > 0)
-            const float w = q_weights[t0 + i];
-            SLG_REQUIRE(std::isfinite(w), "non-finite weight in query " + std::to_string(q));
-            const uint32_t local = (uint32_t)terms.size() - sq.term_begin;
-            if (df > longest_df) {
-              longest_df = df;
-              longest = local;
-            }
-            terms.push_back(slg::TermRef{off, df, w, tid, q_leaf ? q_leaf[t0 + i] : i});
-            P += df;
-          }
-          sq.n_terms = (uint32_t)terms.size() - sq.term_begin;
-          if (sq.n_terms == 0) continue;
-          {
-            // Lists go to the device sorted by leaf (stable: a leaf's terms keep the term order in
-            // which the reference adds them, wand.rs:488-497).  plan 0 = the flat term-order sum,
-            // which is what Sum gives when no leaf holds two terms.
-            auto first = terms.begin() + sq.term_begin;
-            std::stable_sort(first, terms.end(),
-                             [](const slg::TermRef &a, const slg::TermRef &c) { return a.leaf < c.leaf; });
-            bool shared = false;
-            uint32_t present = 0;
-            for (uint32_t i = 0; i < sq.n_terms; i++) {
-              const bool fresh = i == 0 || first[i].leaf != first[i - 1].leaf;
-              present += fresh ? 1u : 0u;
-              shared = shared || !fresh;
-            }
-            sq.plan = plan_kind == SLG_PLAN_DISMAX ? 2u : (shared ? 1u : 0u);
-            sq.tie = tie;
-            sq.max_init = present < n_leaves ? 0.0f : -INFINITY;
-            sq.n_leaves = n_leaves;
-            if (sq.plan) any_plan = true;
-          }
-          // ---- threshold seed (kernels: RoundQuery::theta0) = max_t w_t * champ[t][rank(k)]: an
-          // exact lower bound of the k-th best score whenever no weight is negative (a doc's total
-          // is then >= each of its contributions) and no doc filter can reject the champions ----
-          float seed = 0.0f;
-          if (!sh.champ.empty() && k <= 1024u && fq == 0) {
-            bool nonneg = true;
-            for (uint32_t i = 0; i < sq.n_terms; i++) {
-              const slg::TermRef &tr = terms[sq.term_begin + i];
-              if (!(tr.weight >= 0.0f)) nonneg = false;
-              if (tr.weight > 0.0f)
-                seed = std::max(seed, tr.weight * sh.champ[(size_t)tr.term * slg::kChampions + slg::champ_index(k)]);
-            }
-            if (!nonneg) seed = 0.0f;
-          }
-          sq.theta0 = seed;
-          // ---- MaxScore classification (strategies Wand / Bmw; exact).  On by default for batches
-          // that run on the multi kernel (a query with >= 5 terms), where probing the non-essential
-          // lists is cheaper than scoring them; SLG_MAXSCORE=1 / 0 forces it on / off ----
-          // theta0 = max_t w_t * champ[t][k-1] is a lower bound of the final k-th score
-          // (slg_score.hpp sets the same floor on the device).  Lists taken in ascending order of
-          // their maximum contribution ub_t = w_t * champ[t][0] are non-essential while the running
-          // sum of ub stays below theta0: a doc found only in them totals < theta0.
-          uint32_t ess_mask = sq.n_terms >= 32 ? 0xFFFFFFFFu : ((1u << sq.n_terms) - 1u);
-          if (strategy != SLG_STRATEGY_BM25 && seed > 0.0f && !plans_requested && sq.n_terms > 1 && maxscore_on) {
-            const float theta0 = seed;
-            std::vector<std::pair<float, uint32_t>> ub(sq.n_terms);
-            for (uint32_t i = 0; i < sq.n_terms; i++) {
-              const slg::TermRef &tr = terms[sq.term_begin + i];
-              ub[i] = {tr.weight * sh.champ[(size_t)tr.term * slg::kChampions], i};
-            }
-            {
-              std::sort(ub.begin(), ub.end());
-              double acc = 0.0;
-              for (uint32_t i = 0; i + 1 < sq.n_terms; i++) {  // at least one list stays essential
-                acc += (double)ub[i].first;
-                // margin: f32 sums of the real contributions may round up by a few ulps
-                if (acc * (1.0 + 1e-5) < (double)theta0)
-                  ess_mask &= ~(1u << ub[i].second);
-                else
-                  break;
-              }
-            }
-          }
-          sq.ess_mask = ess_mask;
-          // the round planner works on the essential lists only
-          P = 0;
-          longest = 0;
-          longest_df = 0;
-          uint64_t P_all = 0;
-          for (uint32_t i = 0; i < sq.n_terms; i++) {
-            const uint32_t df = terms[sq.term_begin + i].df;
-            P_all += df;
-            if (!((ess_mask >> i) & 1u)) continue;
-            P += df;
-            if (df > longest_df) {
-              longest_df = df;
-              longest = i;
-            }
-          }
-          // block skipping pays where a 64-posting block of a non-essential list usually holds no
-          // candidate doc: a block spans 64 * N / df docs, which hold 64 * P / df essential postings
-          // on average; blocks are tested only below 2 (>= e^-2 = 13 % of them can be skipped).
-          // Config 3's lists are all of similar density (>= 64 per block): no test, no cost.
-          sq.skip_mask = 0;
-          if (tn.block_max)
-            for (uint32_t i = 0; i < sq.n_terms && i < 32; i++) {
-              const uint64_t df = terms[sq.term_begin + i].df;
-              if (!((ess_mask >> i) & 1u) && 64ull * P < 2ull * df) sq.skip_mask |= 1u << i;
-            }
-          o.n_noness += P_all - P;
-          b->q_postings[q] += P_all;
-          o.n_postings += P_all;
-          o.n_ess += P;
-          sq.longest = longest;
-          o.max_terms = std::max(o.max_terms, sq.n_terms);
-          sqs.push_back(sq);
-          sq_postings.push_back(P);
-          sq_postings_all.push_back(P_all);
-        }
-      }
-    };
-    {
-      const uint64_t work = (uint64_t)nq * n_segs;
-      uint32_t n_thr = 1;
-      if (work >= 16384) n_thr = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(8, std::max(1u, std::thread::hardware_concurrency())), nq / 512);
-      n_thr = std::max(1u, n_thr);
-      std::vector<Pass1Out> parts(n_thr);
-      if (n_thr == 1) {
-        plan_range(0, nq, parts[0]);
-      } else {
-        std::vector<std::thread> pool;
-        for (uint32_t t = 0; t < n_thr; t++)
-          pool.emplace_back([&, t] {
-            try {
-              plan_range((uint32_t)((uint64_t)nq * t / n_thr), (uint32_t)((uint64_t)nq * (t + 1) / n_thr), parts[t]);
-            } catch (...) {
-              parts[t].err = std::current_exception();
-            }
-          });
-        for (auto &th : pool) th.join();
-        for (auto &pt : parts)
-          if (pt.err) std::rethrow_exception(pt.err);
-      }
-      for (uint32_t t = 0; t < n_thr; t++) {
-        Pass1Out &pt = parts[t];
-        const uint32_t sq_base = (uint32_t)sqs.size(), term_base = (uint32_t)terms.size();
-        const uint32_t q_lo = n_thr == 1 ? 0u : (uint32_t)((uint64_t)nq * t / n_thr);
-        const uint32_t q_hi = n_thr == 1 ? nq : (uint32_t)((uint64_t)nq * (t + 1) / n_thr);
-        for (uint32_t q = q_lo; q < q_hi; q++) q_sq_begin[q] += sq_base;
-        if (t == 0 && n_thr == 1) {
-          sqs.swap(pt.sqs);
-          terms.swap(pt.terms);
-          sq_postings.swap(pt.sq_postings);
-          sq_postings_all.swap(pt.sq_postings_all);
-        } else {
-          for (auto &sq : pt.sqs) sq.term_begin += term_base;
-          sqs.insert(sqs.end(), pt.sqs.begin(), pt.sqs.end());
-          terms.insert(terms.end(), pt.terms.begin(), pt.terms.end());
-          sq_postings.insert(sq_postings.end(), pt.sq_postings.begin(), pt.sq_postings.end());
-          sq_postings_all.insert(sq_postings_all.end(), pt.sq_postings_all.begin(), pt.sq_postings_all.end());
-        }
-        b->n_postings += pt.n_postings;
-        b->n_postings_essential += pt.n_ess;
-        b->n_postings_nonessential += pt.n_noness;
-        b->max_terms = std::max(b->max_terms, pt.max_terms);
-        any_plan = any_plan || pt.any_plan;
-        any_filter = any_filter || pt.any_filter;
-      }
-    }
-    q_sq_begin[nq] = (uint32_t)sqs.size();
-
-    // ---- pass 2: rounds of about one register set of postings, slices of consecutive rounds ----
-    const uint32_t probe_target = std::max<uint32_t>(slg::kMultiCap, tn.probe_target);
-    std::vector<uint32_t> slice_sq, slice_seg;
-    uint64_t n_bounds = 0, n_bnd = 0;
-    // one-list-per-slot kernel (slg_score_uni.hpp): few terms, no non-essential lists
-    b->uniform = b->max_terms <= tn.uniform_max_terms && !any_plan;
-    for (size_t i = 0; i < sqs.size() && b->uniform; i++) {
-      const uint32_t full = sqs[i].n_terms >= 32 ? 0xFFFFFFFFu : ((1u << sqs[i].n_terms) - 1u);
-      if (sqs[i].ess_mask != full) b->uniform = false;
-    }
-    // more terms (the multi-field shape): the same slots-of-one-list design, 8 slots at a time
-    // (the multi kernel also runs MaxScore-classified batches: non-essential lists are only probed)
-    b->multi = !b->uniform;
-    b->plan_batch = any_plan;
-    for (size_t i = 0; i < sqs.size(); i++) {
-      const uint32_t full = sqs[i].n_terms >= 32 ? 0xFFFFFFFFu : ((1u << sqs[i].n_terms) - 1u);
-      if (sqs[i].ess_mask != full) b->pruned = true;
-    }
-    // rounds per slice: short slices pack the tail of the launch better (one wave per slice,
-    // ~5 generations of waves per SIMD on config 2).  The uniform kernel's slices are cheap to
-    // start (threshold seed + buffered top-k) as long as k is small: every slice writes k
-    // candidates for the merge (measured: config 2 k=11 best at 4, config 3 k=101 best at 8).
-    const bool rps_pinned = tn.rounds_per_slice != 0;
-    const uint32_t max_rps = std::max<uint32_t>(1, std::min<uint32_t>(
-        rps_pinned ? tn.rounds_per_slice
-                   : (b->uniform && k <= 64 ? slg::kUniRoundsPerSlice : slg::kDefaultRoundsPerSlice),
-        slg::kMaxRoundsPerSlice));
-    // longest slices: 8 rounds on the few-term kernel (measured on config 2: the heaviest
-    // sub-queries' 16-round slices were the tail of the launch), 16 on the many-term kernel
-    const uint32_t rps_cap = std::max<uint32_t>(
-        max_rps, tn.max_rounds_per_slice ? tn.max_rounds_per_slice
-                                         : (b->uniform ? 8u : (uint32_t)slg::kMaxRoundsPerSlice));
-    const uint32_t slices_per_sq = tn.slices_per_subquery;
-    for (size_t i = 0; i < sqs.size(); i++) {
-      slg::RoundQuery &sq = sqs[i];
-      const uint32_t dfL = terms[sq.term_begin + sq.longest].df;
-      uint32_t round_target;
-      if (b->uniform) {
-        // every list is padded to a 64-lane slot (half a slot wasted per list on average): aim
-        // at (slots - terms + 1) slots of postings; measured optimum on config 2 (384 for 3 terms)
-        const uint32_t t = sq.n_terms;
-        uint32_t dflt = 64u * (slg::kUniSlots > t ? slg::kUniSlots - t : 0u) + 64u;
-        if (!tn.uniform_round_target && t > 1) {
-          // A round that needs more than 8 slots is streamed in chunks at 2-3x the cost, so the
-          // target follows the sub-query's own mix of list lengths: the largest R (steps of 16)
-          // whose expected slots stay under 8 with 1.6 sigma to spare.  The longest list is cut at
-          // exact strides (its count is R * f); every other list's count c is roughly Poisson
-          // around R * f: ceil(c / 64) has mean c/64 + 1/2 and variance c/4096 + 1/12.
-          const double Pd = (double)sq_postings[i];
-          uint32_t best = 64;
-          for (uint32_t R = 96; R <= (uint32_t)slg::kUniCap; R += 16) {
-            double mu = 0.0, var = 0.0;
-            for (uint32_t j = 0; j < t; j++) {
-              const double c = (double)R * (double)terms[sq.term_begin + j].df / Pd;
-              if (j == sq.longest) {
-                mu += std::ceil(c / 64.0);
-              } else {
-                mu += c / 64.0 + 0.5;
-                var += c / 4096.0 + 1.0 / 12.0;
-              }
-            }
-            if (mu + 1.6 * std::sqrt(var) > 8.3) break;  // (1.0 / 1.3 / 1.6 / 2.0 / 2.5 sigma: 0.1024 / 0.1011 /
-                                                         //  0.1006 / 0.1019 / 0.1039 ms on config 2; fixed 384: 0.1042)
-            best = R;
-          }
-          dflt = best;
-        }
-        round_target = std::max<uint32_t>(48, std::min<uint32_t>(
-            tn.uniform_round_target ? tn.uniform_round_target : dflt, slg::kUniCap));
-      } else {
-        round_target = std::max<uint32_t>(64, std::min<uint32_t>(tn.multi_round_target, slg::kMultiCap));
-        // the many-term kernel's bitmap covers a window of kSpan docs: a round whose essential
-        // postings are spread over more is cut into chunks, each paying the round's fixed costs.
-        // Sparse sub-queries get rounds that fit the window (postings per round <= 0.85 * kSpan *
-        // density of the essential lists)
-        const double dens = (double)sq_postings[i] / (double)std::max<uint32_t>(1u, ix->segs[sq.seg]->n_docs);
-        const double fit = 0.85 * (double)slg::kSpan * dens;  // (0.65 / 0.75 / 0.85 / 0.95 / 1.0 measured on config 3:
-                                                               //  7.88 / 7.54 / 7.35 / 7.76 / 8.20 ms; no rule: 8.69)
-        if (fit < (double)round_target) round_target = (uint32_t)std::max(64.0, fit);
-      }
-      // a round holds <= ~round_target postings of the essential lists (register slots) and
-      // <= ~probe_target postings overall (non-essential lists are streamed per round), so
-      // slices stay balanced whatever the mix
-      uint64_t nr = (sq_postings[i] + round_target - 1) / round_target;
-      nr = std::max<uint64_t>(nr, (sq_postings_all[i] + probe_target - 1) / probe_target);
-      nr = std::max<uint64_t>(1, std::min<uint64_t>(nr, dfL));
-      // sub-queries with many rounds get longer slices (fewer candidate lists for the merge,
-      // whose time is set by the heaviest query); they are launched first (slice_order below)
-      uint32_t want_rps = max_rps;
-      if (!rps_pinned) want_rps = (uint32_t)std::min<uint64_t>(
-          std::max<uint64_t>(max_rps, (nr + slices_per_sq - 1) / slices_per_sq), rps_cap);
-      // (the uniform / packed kernels keep a slice's cut points in one register: (rps+1)*T <= 64)
-      const uint32_t rps = b->multi ? std::max<uint32_t>(1, want_rps)
-                                    : std::max<uint32_t>(1, std::min<uint32_t>(want_rps, 64 / sq.n_terms - 1));
-      const uint64_t S = (nr + rps - 1) / rps;
-      // (the per-slice candidate lists, n_slices * k entries indexed with 32 bits, exist only for
-      //  k <= 256; larger k goes through the candidate array, one slot per posting)
-      const bool slice_lists = !(k > 256 && (k > 1024 || tn.cand_mode));  // == !cand_mode
-      SLG_REQUIRE(nr < 0x7FFFFFFFull && slice_sq.size() + S < 0x7FFFFFFFull &&
-                      (!slice_lists ||
-                       (slice_sq.size() + S) * (uint64_t)std::max<uint32_t>(k, 1) < 0xFFFFFFFFull),
-                  "batch too large (rounds)");
-      sq.n_rounds = (uint32_t)nr;
-      sq.rounds_per_slice = rps;
-      sq.slice_begin = (uint32_t)slice_sq.size();
-      sq.n_slices = (uint32_t)S;
-      SLG_REQUIRE(n_bounds + (nr + 1) * sq.n_terms < 0xFFFFFFFFull, "batch too large (bounds)");
-      sq.bounds_begin = (uint32_t)n_bounds;
-      sq.rdoc_begin = (uint32_t)n_bnd;
-      sq.bnd_begin = (uint32_t)n_bnd;
-      n_bounds += (nr + 1) * sq.n_terms;
-      n_bnd += nr + 1;
-      b->n_rounds += nr;
-      slice_sq.insert(slice_sq.end(), (size_t)S, (uint32_t)i);
-      slice_seg.insert(slice_seg.end(), (size_t)S, sq.seg);
-    }
-    // large k: per-slice top-k lists would be mostly the slice itself; keep every doc above the
-    // seed threshold instead (one candidate slot per posting) and select per query afterwards
-    b->cand_mode = k > 256 && (k > 1024 || tn.cand_mode);
-    uint64_t cand_total = 0;
-    if (b->cand_mode)
-      for (size_t i = 0; i < sqs.size(); i++) {
-        sqs[i].cand_lo = (uint32_t)cand_total;
-        sqs[i].cand_hi = (uint32_t)(cand_total >> 32);
-        cand_total += sq_postings_all[i];
-      }
-    std::vector<slg::QueryRef> qrefs(nq);
-    for (uint32_t q = 0; q < nq; q++) {
-      const uint32_t a = q_sq_begin[q], e = q_sq_begin[q + 1];
-      if (a == e) {
-        qrefs[q] = slg::QueryRef{0, 0};
-      } else {
-        qrefs[q].slice_begin = sqs[a].slice_begin;
-        qrefs[q].slice_end = sqs[e - 1].slice_begin + sqs[e - 1].n_slices;
-      }
-    }
-    // launch order: slices with the most rounds first (counting sort, stable), so the short
-    // ones fill the tail of the launch
-    std::vector<uint32_t> slice_order(slice_sq.size());
-    {
-      std::vector<uint32_t> nrounds(slice_sq.size());
-      uint32_t hist[slg::kMaxRoundsPerSlice + 2] = {0};
-      for (size_t i = 0; i < sqs.size(); i++) {
-        const slg::RoundQuery &sq = sqs[i];
-        for (uint32_t j = 0; j < sq.n_slices; j++) {
-          const uint32_t r0 = j * sq.rounds_per_slice;
-          const uint32_t n = std::min<uint32_t>(sq.rounds_per_slice, sq.n_rounds - r0);
-          nrounds[sq.slice_begin + j] = n;
-          hist[slg::kMaxRoundsPerSlice - n + 1]++;  // bucket 0 = most rounds
-        }
-      }
-      for (int i = 1; i <= slg::kMaxRoundsPerSlice + 1; i++) hist[i] += hist[i - 1];
-      const bool lpt = tn.slice_order != 0;
-      for (size_t sidx = 0; sidx < slice_sq.size(); sidx++)
-        slice_order[lpt ? hist[slg::kMaxRoundsPerSlice - nrounds[sidx]]++ : sidx] = (uint32_t)sidx;
-    }
-    b->n_sq = (uint32_t)sqs.size();
-    b->n_terms = (uint32_t)terms.size();
-    b->n_slices = (uint32_t)slice_sq.size();
-    b->n_boundaries = (uint32_t)n_bnd;
-
-    // ---- pack descriptors, one H2D copy ----
-    size_t cur = 0;
-    const size_t o_sq = place<slg::RoundQuery>(cur, sqs.size());
-    const size_t o_terms = place<slg::TermRef>(cur, terms.size());
-    const size_t o_slice = place<uint32_t>(cur, slice_sq.size());
-    const size_t o_sseg = place<uint32_t>(cur, slice_seg.size());
-    const size_t o_sord = place<uint32_t>(cur, slice_order.size());
-    const size_t o_q = place<slg::QueryRef>(cur, qrefs.size());
-    // sub-query of every 32nd round boundary (partition_rounds_kernel walks from there)
-    std::vector<uint32_t> bnd_coarse((size_t)((n_bnd + 31) / 32));
-    {
-      size_t i = 0;
-      for (size_t c = 0; c < bnd_coarse.size(); c++) {
-        const uint64_t bb = (uint64_t)c * 32;
-        while (i + 1 < sqs.size() && sqs[i + 1].bnd_begin <= bb) i++;
-        bnd_coarse[c] = (uint32_t)i;
-      }
-    }
-    const size_t o_bc = place<uint32_t>(cur, bnd_coarse.size());
-    const size_t total = (cur + 15) & ~(size_t)15;
-    // (a copy the caller waits for, outside any lock, on a stream of its own.  Measured against an
-    // image copied asynchronously on the batch's stream in front of the kernels: that variant
-    // served 5.2-7.4M queries/s from 4-8 caller threads where this one serves 8.0-8.8M — the
-    // stream-ordered copy delays each batch's first kernel)
-    // The staging image is pinned, so the copy is one DMA at PCIe speed (26 MB: 0.6 ms; from
-    // pageable memory 1-6 ms), and comes from the index's free list (a fresh 26 MB vector per
-    // config-4 batch spent half of its 5 ms in page faults); it goes back when prepare returns.
+    // ---- the descriptor image: one H2D copy the caller waits for, outside any lock, on an upload
+    // stream of its own.  (Measured against an image copied asynchronously on the batch's stream in
+    // front of the kernels: that variant served 5.2-7.4M queries/s from 4-8 caller threads where
+    // this one serves 8.0-8.8M — the stream-ordered copy delays each batch's first kernel.)  The
+    // staging image is pinned, so the copy is one DMA at PCIe speed (26 MB: 0.6 ms; from pageable
+    // memory 1-6 ms), and comes from the index's free list (a fresh 26 MB vector per config-4
+    // batch spent half of its 5 ms in page faults); it goes back when prepare returns.
+    const size_t total = plan.image_bytes;
     struct ImageLease {
       BufPool *pool;
       void *p = nullptr;
@@ -1400,35 +988,27 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     } lease{&ix->pool};
     lease.p = ix->pool.take_image(total ? total : 16, &lease.bytes);
     if (!lease.p) throw SlgError(SLG_ERR_OOM, "pinned staging image: hipHostMalloc failed");
-    void *hbuf = lease.p;
-    unsigned char *hb = static_cast<unsigned char *>(hbuf);
-    if (!sqs.empty()) std::memcpy(hb + o_sq, sqs.data(), sqs.size() * sizeof(slg::RoundQuery));
-    if (!terms.empty()) std::memcpy(hb + o_terms, terms.data(), terms.size() * sizeof(slg::TermRef));
-    if (!slice_sq.empty()) std::memcpy(hb + o_slice, slice_sq.data(), slice_sq.size() * 4);
-    if (!slice_seg.empty()) std::memcpy(hb + o_sseg, slice_seg.data(), slice_seg.size() * 4);
-    if (!slice_order.empty()) std::memcpy(hb + o_sord, slice_order.data(), slice_order.size() * 4);
-    if (!qrefs.empty()) std::memcpy(hb + o_q, qrefs.data(), qrefs.size() * sizeof(slg::QueryRef));
-    if (!bnd_coarse.empty()) std::memcpy(hb + o_bc, bnd_coarse.data(), bnd_coarse.size() * 4);
+    plan.pack(static_cast<unsigned char *>(lease.p));
     b->d_desc.alloc_pooled(&ix->pool, total);
     {
       hipStream_t us = ix->upload_streams[std::hash<std::thread::id>()(std::this_thread::get_id()) %
                                           slg_index::kUploadStreams];
-      SLG_HIP(hipMemcpyAsync(b->d_desc.p, hbuf, total, hipMemcpyHostToDevice, us));
+      SLG_HIP(hipMemcpyAsync(b->d_desc.p, lease.p, total, hipMemcpyHostToDevice, us));
       SLG_HIP(hipStreamSynchronize(us));
     }
     unsigned char *db = b->d_desc.as<unsigned char>();
-    b->d_sq = reinterpret_cast<const slg::RoundQuery *>(db + o_sq);
-    b->d_terms = reinterpret_cast<const slg::TermRef *>(db + o_terms);
-    b->d_slice_sq = reinterpret_cast<const uint32_t *>(db + o_slice);
-    b->d_slice_seg = reinterpret_cast<const uint32_t *>(db + o_sseg);
-    b->d_slice_order = reinterpret_cast<const uint32_t *>(db + o_sord);
-    b->d_queries = reinterpret_cast<const slg::QueryRef *>(db + o_q);
-    b->d_bnd_coarse = reinterpret_cast<const uint32_t *>(db + o_bc);
-    b->d_bounds.alloc_pooled(&ix->pool, (size_t)n_bounds * 4);
-    b->d_rdoc.alloc_pooled(&ix->pool, (size_t)n_bnd * 4);
+    b->d_sq = reinterpret_cast<const slg::RoundQuery *>(db + plan.o_sq);
+    b->d_terms = reinterpret_cast<const slg::TermRef *>(db + plan.o_terms);
+    b->d_slice_sq = reinterpret_cast<const uint32_t *>(db + plan.o_slice);
+    b->d_slice_seg = reinterpret_cast<const uint32_t *>(db + plan.o_sseg);
+    b->d_slice_order = reinterpret_cast<const uint32_t *>(db + plan.o_sord);
+    b->d_queries = reinterpret_cast<const slg::QueryRef *>(db + plan.o_q);
+    b->d_bnd_coarse = reinterpret_cast<const uint32_t *>(db + plan.o_bc);
+    b->d_bounds.alloc_pooled(&ix->pool, (size_t)plan.n_bounds * 4);
+    b->d_rdoc.alloc_pooled(&ix->pool, (size_t)plan.n_bnd * 4);
     b->d_slice_desc.alloc_pooled(&ix->pool, (size_t)b->n_slices * sizeof(slg::SliceDesc));
     if (b->cand_mode) {
-      b->d_cand.alloc_pooled(&ix->pool, (size_t)(cand_total + 1) * 8);
+      b->d_cand.alloc_pooled(&ix->pool, (size_t)(plan.cand_total + 1) * 8);
       b->d_slice_cbeg.alloc_pooled(&ix->pool, (size_t)b->n_slices * 8);
       b->d_slice_ccnt.alloc_pooled(&ix->pool, (size_t)b->n_slices * 4);
     } else {
@@ -1438,13 +1018,10 @@ slg_batch *slg_batch_prepare_plan(slg_index *ix, uint32_t nq, const uint32_t *q_
     b->d_q_scored.alloc_pooled(&ix->pool, (size_t)nq * 4);
     // (from the pool like every per-batch buffer: a raw hipMalloc / hipFree per batch synchronises
     // the device and cost config 4's two-in-flight pipeline 60 %)
-    if (b->pruned && !b->uniform && tn.block_max) b->d_blk_skip.alloc_pooled(&ix->pool, ((size_t)nq + 1) * 8);
-    if (any_filter) {
-      std::vector<uint32_t> qf(nq, 0u);
-      for (uint32_t q = 0; q < nq; q++)
-        if (q_filter[q] >= 0) qf[q] = (uint32_t)q_filter[q] + 1u;
+    if (b->pruned && !b->uniform && ix->tune.block_max) b->d_blk_skip.alloc_pooled(&ix->pool, ((size_t)nq + 1) * 8);
+    if (!plan.q_filter.empty()) {
       b->d_q_filter.alloc_pooled(&ix->pool, (size_t)nq * 4);
-      SLG_HIP(hipMemcpy(b->d_q_filter.p, qf.data(), (size_t)nq * 4, hipMemcpyHostToDevice));
+      SLG_HIP(hipMemcpy(b->d_q_filter.p, plan.q_filter.data(), (size_t)nq * 4, hipMemcpyHostToDevice));
     }
     b->d_out.alloc_pooled(&ix->pool, ((size_t)nq * k * 3 + nq) * 4);
     b->d_out_doc = b->d_out.as<uint32_t>();

@@ -21,11 +21,7 @@
 
 namespace slg {
 
-constexpr int kMaxRoundsPerSlice = 16;  // and (rounds+1)*T <= 64: cut points live in one VGPR
-constexpr int kDefaultRoundsPerSlice = 8;
-constexpr int kUniRoundsPerSlice = 4;     // uniform kernel (slg_score_uni.hpp)
-constexpr int kSpanWords = 512;           // bitmap words per window
-constexpr uint32_t kSpan = kSpanWords * 32;  // docs per window
+// (planning constants: slg_desc.hpp)
 // per-wave LDS: bitmap words, exclusive prefix popcounts, accumulators
 
 // ---- partition: exact per-list cut points of every round --------------------------------------

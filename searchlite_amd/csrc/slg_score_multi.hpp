@@ -44,8 +44,7 @@
 
 namespace slg {
 
-constexpr int kMultiCap = 512;       // accumulators (= distinct docs) per chunk
-constexpr int kMultiTarget = 448;    // planned postings per round (host; measured optimum 448-480)
+// (kMultiCap = 512 accumulators per chunk, kMultiTarget: slg_desc.hpp)
 constexpr int kMultiFill = 448;      // postings taken when a round has to be cut
 constexpr int multi_wave_lds(int kregs) {
   return kSpanWords * 4 + kSpanWords * 4 + (kMultiCap + 64) * 4 + kMultiCap * 4 +

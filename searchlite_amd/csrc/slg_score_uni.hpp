@@ -40,9 +40,7 @@
 
 namespace slg {
 
-constexpr int kUniSlots = 8;                 // 64-posting slots per round
-constexpr int kUniCap = kUniSlots * 64;      // postings per round
-constexpr int kUniMaxLists = 4;              // lists per sub-query (one filter bit each)
+// (kUniSlots = 8 slots per round, kUniCap, kUniMaxLists = 4 lists: slg_desc.hpp)
 constexpr int kJoinWords = 1024;             // filter words = 8192 doc fields; also the join queue
 constexpr int kJoinPairs = 24;               // queue sizes up to this are joined all-pairs in registers
                                              // (16 / 40 / 64 measured: no better)

@@ -43,7 +43,7 @@ constexpr int u3_desc_off(int kregs) { return uni_plan_off(kregs) + kUniPlanLds;
 constexpr int u3_wave_lds(int kregs) { return u3_desc_off(kregs) + kU3DescBytes + ((kU3EndBytes + 15) & ~15); }
 
 #ifndef SLG_U3_WAVES
-#define SLG_U3_WAVES 5  // 88 VGPRs without a spill (6 waves = 80 VGPRs: 28 spills)
+#define SLG_U3_WAVES 6  // 80 VGPRs, no spill; 24 waves x 6.6 KB of LDS per CU
 #endif
 
 template <int KREGS>
