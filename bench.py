@@ -7,8 +7,9 @@ A "step" is one pass of the hot path over one batch of synthetic queries.
 the SURVEY section 8(d) figure: the index is resident in HBM, every step takes a FRESH query
 batch as host arrays through the C ABI — slg_batch_prepare (plan + H2D) -> slg_batch_run (three
 kernels) -> slg_batch_fetch (D2H into host arrays) -> destroy — from `--host-threads` caller
-threads, each on its own HIP stream (the reference serves one request per thread,
-searchlite-http/src/lib.rs:640-643).  The batches rotate over `--rotate` distinct query sets, so
+threads (the reference serves one request per thread, searchlite-http/src/lib.rs:640-643), each
+keeping two batches going on two HIP streams of its own (it launches the next batch before it
+collects the previous one).  The batches rotate over `--rotate` distinct query sets, so
 the posting working set (8 x 262 MB for config 2) is far beyond the 256 MiB Infinity Cache.
 Reported beside it (config.*): the device-resident rate of pre-planned batches, and the scoring
 kernel's own duration (HIP events on its stream, batches rotating, one at a time) for `roofline`.
@@ -314,51 +315,71 @@ def main():
 
     # ---- leg 1 (`value`): host arrays in -> prepare -> run -> fetch -> host arrays out ----
     n_thr = max(1, args.host_threads)
-    thr_streams = [torch.cuda.Stream() for _ in range(n_thr)]
+    thr_streams = [torch.cuda.Stream() for _ in range(2 * n_thr)]
     first_results = {}
 
     import queue
 
     class HostPool:
         """Persistent caller threads (a server's request threads): created and warmed before the
-        timed region, fed step numbers through a queue; run(n) returns when n steps are done."""
+        timed region, fed step numbers round-robin; run(n) returns when n steps are done.  A thread
+        keeps TWO batches going, each on a stream of its own: it plans and launches step i + n_thr
+        before it collects step i, so the host round trip of one batch (D2H, Python, planning the
+        next one) never leaves the GPU without queued work."""
 
         def __init__(self):
-            self.todo, self.done, self.errors = queue.Queue(), queue.Queue(), []
+            self.todo = [queue.Queue() for _ in range(n_thr)]
+            self.done, self.errors = queue.Queue(), []
             self.threads = [threading.Thread(target=self._worker, args=(t,), daemon=True) for t in range(n_thr)]
             for t in self.threads:
                 t.start()
 
+        def _collect(self, prev):
+            b, i = prev
+            res = b.fetch()
+            b.close()
+            if (i % n_sets) not in first_results:
+                first_results[i % n_sets] = res
+            self.done.put(i)
+
         def _worker(self, tid):
             torch.cuda.set_device(local_rank)
+            prev, lap = None, 0
             while True:
-                i = self.todo.get()
+                i = self.todo[tid].get()
                 if i is None:
                     return
                 try:
+                    if i == "flush":
+                        if prev is not None:
+                            self._collect(prev)
+                            prev = None
+                        continue
                     offs, terms, w = qs[i % n_sets]
                     b = index.prepare(offs, terms, w, k, strategy)
-                    b.set_stream(thr_streams[tid].cuda_stream)
+                    b.set_stream(thr_streams[2 * tid + (lap & 1)].cuda_stream)
+                    lap += 1
                     b.run()
-                    res = b.fetch()
-                    b.close()
-                    if (i % n_sets) not in first_results:
-                        first_results[i % n_sets] = res
+                    if prev is not None:
+                        self._collect(prev)
+                    prev = (b, i)
                 except Exception as e:  # noqa: BLE001
                     self.errors.append(e)
-                self.done.put(i)
+                    self.done.put(-1)
 
         def run(self, n_steps, first):
             for i in range(first, first + n_steps):
-                self.todo.put(i)
+                self.todo[i % n_thr].put(i)
+            for q_ in self.todo:
+                q_.put("flush")
             for _ in range(n_steps):
                 self.done.get()
             if self.errors:
                 raise self.errors[0]
 
         def close(self):
-            for _ in self.threads:
-                self.todo.put(None)
+            for q_ in self.todo:
+                q_.put(None)
             for t in self.threads:
                 t.join()
 

@@ -272,24 +272,87 @@ pub(crate) fn fold_terms<'a>(qualified: impl Iterator<Item = (&'a str, f32, usiz
   order
 }
 
-/// The shape of ScorePlan the device evaluates (query/planner.rs:113-153).
+/// The shape of ScorePlan the device evaluates (query/planner.rs:113-153): a root over leaves, or
+/// (two levels) a root over groups of consecutive leaves.
 pub(crate) enum GpuScorePlan {
   /// no plan, `Leaf`, or `Sum` of leaves: per-leaf sums added in leaf order
   Sum,
   /// `DisMax { children: leaves, tie_breaker }`
   DisMax { tie_breaker: f32 },
+  /// root `Sum` | `DisMax` whose children are leaves or `Sum` / `DisMax` of leaves: what
+  /// `dis_max{queries}` (planner.rs:470-487) and `bool{should: [multi_match ...]}` (:670-690) build.
+  /// leaf_group[l] = group of leaf l; a bare leaf child is a Sum group of one leaf.
+  Tree { root_dismax: bool, root_tie: f32, leaf_group: Vec<u32>, group_plan: Vec<i32>, group_tie: Vec<f32> },
 }
 
-fn flat_plan(plan: &QueryPlan) -> Option<(GpuScorePlan, u32)> {
+fn plan_shape(plan: &QueryPlan) -> Option<(GpuScorePlan, u32)> {
   let Some(sp) = plan.scorer.as_ref() else { return Some((GpuScorePlan::Sum, 0)) };
   let all_leaves = |cs: &[ScoreExpr]| cs.iter().all(|c| matches!(c, ScoreExpr::Leaf(_)));
-  match &sp.root {
-    ScoreExpr::Leaf(_) => Some((GpuScorePlan::Sum, sp.leaf_count as u32)),
-    ScoreExpr::Sum(cs) if all_leaves(cs) => Some((GpuScorePlan::Sum, sp.leaf_count as u32)),
+  let n_leaves = sp.leaf_count as u32;
+  let (children, root_dismax, root_tie) = match &sp.root {
+    ScoreExpr::Leaf(_) => return Some((GpuScorePlan::Sum, n_leaves)),
+    ScoreExpr::Sum(cs) if all_leaves(cs) => return Some((GpuScorePlan::Sum, n_leaves)),
     ScoreExpr::DisMax { children, tie_breaker } if all_leaves(children) && !children.is_empty() => {
-      Some((GpuScorePlan::DisMax { tie_breaker: *tie_breaker }, sp.leaf_count as u32))
+      return Some((GpuScorePlan::DisMax { tie_breaker: *tie_breaker }, n_leaves));
     }
-    _ => None, // nested expressions stay on the CPU scorer
+    ScoreExpr::Sum(cs) => (cs.as_slice(), false, 0.0f32),
+    ScoreExpr::DisMax { children, tie_breaker } => (children.as_slice(), true, *tie_breaker),
+  };
+  // two levels: every child a leaf or a Sum / DisMax of leaves, the leaves numbered in traversal
+  // order (so a group's leaves are consecutive and every leaf belongs to exactly one group)
+  let mut leaf_group = vec![u32::MAX; sp.leaf_count];
+  let (mut group_plan, mut group_tie) = (Vec::new(), Vec::new());
+  let mut next_leaf = 0usize;
+  for (g, child) in children.iter().enumerate() {
+    let (leaves, kind, tie): (Vec<usize>, i32, f32) = match child {
+      ScoreExpr::Leaf(i) => (vec![*i], ffi::SLG_PLAN_SUM, 0.0),
+      ScoreExpr::Sum(cs) if all_leaves(cs) && !cs.is_empty() => {
+        (cs.iter().map(|c| if let ScoreExpr::Leaf(i) = c { *i } else { unreachable!() }).collect(), ffi::SLG_PLAN_SUM, 0.0)
+      }
+      ScoreExpr::DisMax { children: cs, tie_breaker } if all_leaves(cs) && !cs.is_empty() => (
+        cs.iter().map(|c| if let ScoreExpr::Leaf(i) = c { *i } else { unreachable!() }).collect(),
+        ffi::SLG_PLAN_DISMAX,
+        *tie_breaker,
+      ),
+      _ => return None, // three levels or more stay on the CPU scorer
+    };
+    for l in leaves {
+      if l != next_leaf || l >= leaf_group.len() {
+        return None;
+      }
+      leaf_group[l] = g as u32;
+      next_leaf += 1;
+    }
+    group_plan.push(kind);
+    group_tie.push(tie);
+  }
+  if next_leaf != sp.leaf_count || group_plan.len() > MAX_QUERY_TERMS {
+    return None;
+  }
+  Some((GpuScorePlan::Tree { root_dismax, root_tie, leaf_group, group_plan, group_tie }, n_leaves))
+}
+
+/// "the doc has a posting of some scored term" implies the matcher (QueryEvaluator::matches,
+/// api/reader.rs:1486-1518): a term, a query string of term groups, or a dis_max / bool.should of such
+fn pure_disjunction(m: &QueryMatcher) -> bool {
+  match m {
+    QueryMatcher::Term(_) => true,
+    QueryMatcher::QueryString(qs) => {
+      !qs.term_groups.is_empty()
+        && qs.phrase_groups.is_empty()
+        && qs.not_term_groups.is_empty()
+        && qs.minimum_should_match.unwrap_or(1) <= 1
+    }
+    QueryMatcher::DisMax(children) => !children.is_empty() && children.iter().all(pure_disjunction),
+    QueryMatcher::Bool { must, should, must_not, filter, minimum_should_match } => {
+      must.is_empty()
+        && must_not.is_empty()
+        && filter.is_empty()
+        && !should.is_empty()
+        && minimum_should_match.unwrap_or(1) <= 1
+        && should.iter().all(pure_disjunction)
+    }
+    _ => false,
   }
 }
 
@@ -320,26 +383,14 @@ pub(crate) fn gpu_eligible(
   if n_folded_terms == 0 || n_folded_terms > MAX_QUERY_TERMS {
     return None;
   }
-  // the matcher must be implied by "the doc has a posting of some scored term":
-  // a pure disjunction (QueryEvaluator::matches, api/reader.rs:1486-1518)
-  let pure_disjunction = match &plan.matcher {
-    QueryMatcher::Term(_) => true,
-    QueryMatcher::QueryString(m) => {
-      !m.term_groups.is_empty()
-        && m.phrase_groups.is_empty()
-        && m.not_term_groups.is_empty()
-        && m.minimum_should_match.unwrap_or(1) <= 1
-    }
-    _ => false,
-  };
-  if !pure_disjunction || !plan.phrase_specs.is_empty() {
+  if !pure_disjunction(&plan.matcher) || !plan.phrase_specs.is_empty() {
     return None;
   }
   // every matching term group must also score, else a doc could match without a scored posting
   if plan.term_groups.iter().any(|g| !g.score) {
     return None;
   }
-  flat_plan(plan)
+  plan_shape(plan)
 }
 
 /// Replaces the per-segment loop + cross-segment sort of IndexReader::search
@@ -368,6 +419,34 @@ pub(crate) fn gpu_top_k(
   let (plan_kind, tie) = match score_plan {
     GpuScorePlan::Sum => (ffi::SLG_PLAN_SUM, 0.0f32),
     GpuScorePlan::DisMax { tie_breaker } => (ffi::SLG_PLAN_DISMAX, *tie_breaker),
+    GpuScorePlan::Tree { root_dismax, root_tie, .. } => {
+      (if *root_dismax { ffi::SLG_PLAN_DISMAX } else { ffi::SLG_PLAN_SUM }, *root_tie)
+    }
+  };
+  // two-level plans: CSR of one query (slg_score_plans)
+  let (leaf_offsets, group_offsets) = match score_plan {
+    GpuScorePlan::Tree { leaf_group, group_plan, .. } => ([0u32, leaf_group.len() as u32], [0u32, group_plan.len() as u32]),
+    _ => ([0u32, 0], [0u32, 0]),
+  };
+  let plans = ffi::slg_score_plans {
+    q_leaf: leaves.as_ptr(),
+    q_plan: &plan_kind,
+    q_tie: &tie,
+    q_nleaves: if n_leaves > 0 { &n_leaves } else { std::ptr::null() },
+    q_leaf_offsets: leaf_offsets.as_ptr(),
+    leaf_group: match score_plan {
+      GpuScorePlan::Tree { leaf_group, .. } => leaf_group.as_ptr(),
+      _ => std::ptr::null(),
+    },
+    q_group_offsets: group_offsets.as_ptr(),
+    group_plan: match score_plan {
+      GpuScorePlan::Tree { group_plan, .. } => group_plan.as_ptr(),
+      _ => std::ptr::null(),
+    },
+    group_tie: match score_plan {
+      GpuScorePlan::Tree { group_tie, .. } => group_tie.as_ptr(),
+      _ => std::ptr::null(),
+    },
   };
   let filter_id = match filter {
     Some(f) => gpu.filter_id(segments, f)?,
@@ -380,16 +459,13 @@ pub(crate) fn gpu_top_k(
   };
   let k = top_k as u32;
   let batch = unsafe {
-    ffi::slg_batch_prepare_plan(
+    ffi::slg_batch_prepare_plans(
       gpu.raw(),
       1,
       offsets.as_ptr(),
       term_ids.as_ptr(),
       weights.as_ptr(),
-      leaves.as_ptr(),
-      &plan_kind,
-      &tie,
-      if n_leaves > 0 { &n_leaves } else { std::ptr::null() },
+      &plans,
       &filter_id,
       k,
       strategy,

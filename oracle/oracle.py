@@ -87,6 +87,12 @@ def lib():
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.slo_search_batch_tree.restype = C.c_int
+        L.slo_search_batch_tree.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.slo_normalize_in_place.restype = None
         L.slo_normalize_in_place.argtypes = [C.c_void_p, C.c_uint32]
         L.slo_metric_similarity.restype = f32
@@ -183,13 +189,16 @@ PLAN_SUM, PLAN_DISMAX = 0, 1
 
 def search_batch(segments, q_offsets, q_terms, q_weights, k, strategy=WAND, block_size=None,
                  n_threads=1, cache_min_len=False, want_stats=False, q_leaf=None, q_plan=None,
-                 q_tie=None, q_nleaves=None):
+                 q_tie=None, q_nleaves=None, q_leaf_offsets=None, leaf_group=None, q_group_offsets=None,
+                 group_plan=None, group_tie=None):
     """api/reader.rs search() over segments for a batch of pure-disjunction queries.
 
     q_terms has shape [total_query_terms, n_segs] (per-segment term ids, NO_TERM if absent).
     Score plans (query/planner.rs:113-153): q_leaf[i] = leaf of query term i (default: term i of
     a query is leaf i), q_plan[q] = PLAN_SUM | PLAN_DISMAX over the leaves, q_tie[q] = DisMax
-    tie breaker, q_nleaves[q] = leaves of the plan.
+    tie breaker, q_nleaves[q] = leaves of the plan.  Two-level plans (ScoreExpr::evaluate recursion,
+    planner.rs:122-153): leaf_group / group_plan / group_tie with their per-query CSR offsets — the
+    root combines groups, a group combines its consecutive leaves.
     Returns (doc[nq,k], seg[nq,k], score[nq,k], count[nq]).
     """
     segs, keep = _pack_segments(segments)
@@ -206,8 +215,14 @@ def search_batch(segments, q_offsets, q_terms, q_weights, k, strategy=WAND, bloc
     qp = None if q_plan is None else np.ascontiguousarray(q_plan, dtype=np.int32)
     qt = None if q_tie is None else np.ascontiguousarray(q_tie, dtype=np.float32)
     qn = None if q_nleaves is None else np.ascontiguousarray(q_nleaves, dtype=np.uint32)
-    rc = lib().slo_search_batch_plan(segs, len(segments), nq, _ptr(q_offsets), _ptr(q_terms),
-                                     _ptr(q_weights), _ptr(ql), _ptr(qp), _ptr(qt), _ptr(qn), k,
+    qlo = None if q_leaf_offsets is None else np.ascontiguousarray(q_leaf_offsets, dtype=np.uint32)
+    lg = None if leaf_group is None else np.ascontiguousarray(leaf_group, dtype=np.uint32)
+    qgo = None if q_group_offsets is None else np.ascontiguousarray(q_group_offsets, dtype=np.uint32)
+    gp = None if group_plan is None else np.ascontiguousarray(group_plan, dtype=np.int32)
+    gt = None if group_tie is None else np.ascontiguousarray(group_tie, dtype=np.float32)
+    rc = lib().slo_search_batch_tree(segs, len(segments), nq, _ptr(q_offsets), _ptr(q_terms),
+                                     _ptr(q_weights), _ptr(ql), _ptr(qp), _ptr(qt), _ptr(qn),
+                                     _ptr(qlo), _ptr(lg), _ptr(qgo), _ptr(gp), _ptr(gt), k,
                                      strategy, block_size or 0, n_threads, int(cache_min_len),
                                      _ptr(out_doc), _ptr(out_seg), _ptr(out_score), _ptr(out_count),
                                      None if stats is None else C.addressof(stats))
@@ -253,6 +268,14 @@ def search_batch_filtered(segments, q_offsets, q_terms, q_weights, k, q_filter, 
         for name in ("q_plan", "q_tie", "q_nleaves"):
             if kq.get(name) is not None:
                 kq[name] = np.asarray(kq[name])[q:q + 1]
+        if kq.get("leaf_group") is not None:  # two-level plans: this query's leaves and groups
+            la, lb = int(kw["q_leaf_offsets"][q]), int(kw["q_leaf_offsets"][q + 1])
+            ga, gb = int(kw["q_group_offsets"][q]), int(kw["q_group_offsets"][q + 1])
+            kq["leaf_group"] = np.asarray(kw["leaf_group"])[la:lb]
+            kq["group_plan"] = np.asarray(kw["group_plan"])[ga:gb]
+            kq["group_tie"] = np.asarray(kw["group_tie"])[ga:gb]
+            kq["q_leaf_offsets"] = np.array([0, lb - la], dtype=np.uint32)
+            kq["q_group_offsets"] = np.array([0, gb - ga], dtype=np.uint32)
         r = search_batch(segs, np.array([0, b - a], dtype=np.uint32), q_terms[a:b], q_weights[a:b], k,
                          strategy=strategy, **kq)
         if out is None:

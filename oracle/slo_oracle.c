@@ -234,32 +234,93 @@ static int finalize_heap(bheap *heap, uint32_t *out_doc, float *out_score) {
   return (int)heap->len;
 }
 
-/* ScorePlan root over the leaves (query/planner.rs:113-153).
- * SLO_PLAN_SUM: Sum([Leaf(0..n)]) => iterator .sum::<f32>() (:126); since Rust 1.83 the f32 Sum
- * identity is -0.0 (toolchain pin is 1.92, rust-toolchain.toml:2).
- * SLO_PLAN_DISMAX: DisMax{children: leaves, tie_breaker} (:127-151): empty => 0.0; max starts
- * at -inf, sum at 0.0; every child counts (a leaf without contributions evaluates to 0.0);
- * result max + tie * (sum - max). */
-typedef struct {
+/* ScoreExpr (query/planner.rs:113-153), restated as the recursive enum it is:
+ *   Leaf(idx)                     -> leaves.get(idx).copied().unwrap_or(0.0)            (:124)
+ *   Sum(children)                 -> children.iter().map(evaluate).sum::<f32>()          (:125-126);
+ *                                    since Rust 1.83 the f32 Sum identity is -0.0 (toolchain pin
+ *                                    1.92, rust-toolchain.toml:2)
+ *   DisMax{children, tie_breaker} -> empty => 0.0; max starts at -inf, sum at 0.0; every child
+ *                                    counts (a leaf without contributions evaluates to 0.0);
+ *                                    max + tie * (sum - max)                             (:127-151)
+ * A plan (ScorePlan, :156-165) = root expression + leaf_count. */
+enum { EXPR_LEAF = 0, EXPR_SUM = 1, EXPR_DISMAX = 2 };
+typedef struct expr {
   int kind;
-  float tie;
+  float tie;                   /* DisMax */
+  uint32_t leaf;               /* Leaf */
+  uint32_t n_children;         /* Sum / DisMax */
+  const struct expr *children;
+} expr;
+typedef struct {
+  const expr *root;
   uint32_t leaf_count;
 } plan_t;
 
-static inline float plan_evaluate(const plan_t *p, const float *leaves) {
-  if (p->kind == SLO_PLAN_DISMAX) {
-    if (p->leaf_count == 0) return 0.0f;
-    float mx = -INFINITY, sum = 0.0f;
-    for (uint32_t i = 0; i < p->leaf_count; i++) {
-      float sc = leaves[i];
-      mx = fmaxf(mx, sc);
-      sum += sc;
+static float expr_evaluate(const expr *e, const float *leaves, uint32_t n_leaves) {
+  switch (e->kind) {
+    case EXPR_LEAF:
+      return e->leaf < n_leaves ? leaves[e->leaf] : 0.0f;
+    case EXPR_SUM: {
+      float s = -0.0f;
+      for (uint32_t i = 0; i < e->n_children; i++) s += expr_evaluate(&e->children[i], leaves, n_leaves);
+      return s;
     }
-    return mx + p->tie * (sum - mx);
+    default: {
+      if (e->n_children == 0) return 0.0f;
+      float mx = -INFINITY, sum = 0.0f;
+      for (uint32_t i = 0; i < e->n_children; i++) {
+        float sc = expr_evaluate(&e->children[i], leaves, n_leaves);
+        mx = fmaxf(mx, sc); /* f32::max: a NaN operand yields the other one, as fmaxf */
+        sum += sc;
+      }
+      return mx + e->tie * (sum - mx);
+    }
   }
-  float s = -0.0f;
-  for (uint32_t i = 0; i < p->leaf_count; i++) s += leaves[i];
-  return s;
+}
+
+static inline float plan_evaluate(const plan_t *p, const float *leaves) {
+  return expr_evaluate(p->root, leaves, p->leaf_count);
+}
+
+/* Root over the leaves 0..leaf_count-1 (what a query string builds, planner.rs:354-360; DisMax of
+ * leaves: dis_max of term queries).  nodes: caller storage for 1 + leaf_count expressions. */
+static void plan_flat(plan_t *p, expr *nodes, int kind, float tie, uint32_t leaf_count) {
+  for (uint32_t i = 0; i < leaf_count; i++) {
+    expr lf = {EXPR_LEAF, 0.0f, i, 0, NULL};
+    nodes[1 + i] = lf;
+  }
+  expr root = {kind == SLO_PLAN_DISMAX ? EXPR_DISMAX : EXPR_SUM, tie, 0, leaf_count, nodes + 1};
+  nodes[0] = root;
+  p->root = &nodes[0];
+  p->leaf_count = leaf_count;
+}
+
+/* Two-level tree: the root combines groups, a group combines its (consecutive) leaves — the shapes
+ * dis_max{queries} (planner.rs:470-487) and bool{should: [multi_match ...]} (:670-690) build.  A
+ * Sum group of ONE leaf is the bare Leaf child the reference has there.
+ * nodes: caller storage for 1 + n_groups + leaf_count expressions. */
+static void plan_tree(plan_t *p, expr *nodes, int kind, float tie, uint32_t leaf_count, uint32_t n_groups,
+                      const uint32_t *leaf_group, const int32_t *group_plan, const float *group_tie) {
+  expr *groups = nodes + 1, *leafs = nodes + 1 + n_groups;
+  for (uint32_t i = 0; i < leaf_count; i++) {
+    expr lf = {EXPR_LEAF, 0.0f, i, 0, NULL};
+    leafs[i] = lf;
+  }
+  uint32_t l = 0;
+  for (uint32_t g = 0; g < n_groups; g++) {
+    uint32_t first = l;
+    while (l < leaf_count && leaf_group[l] == g) l++;
+    if (l - first == 1 && group_plan[g] != SLO_PLAN_DISMAX) {
+      groups[g] = leafs[first];
+    } else {
+      expr ge = {group_plan[g] == SLO_PLAN_DISMAX ? EXPR_DISMAX : EXPR_SUM, group_tie[g], 0, l - first, leafs + first};
+      groups[g] = ge;
+    }
+  }
+  expr root = {kind == SLO_PLAN_DISMAX ? EXPR_DISMAX : EXPR_SUM, tie, 0, n_groups, groups};
+  nodes[0] = root;
+  p->root = &nodes[0];
+  p->leaf_count = leaf_count;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -636,22 +697,45 @@ int slo_execute_top_k(const slo_term *terms, uint32_t n_terms, uint32_t k, int s
                       uint32_t block_size, int use_plan, const uint8_t *deleted,
                       const float *min_len_cache, uint32_t *out_doc, float *out_score,
                       slo_stats *stats) {
-  plan_t plan = {SLO_PLAN_SUM, 0.0f, 0};
+  uint32_t leaf_count = 0;
   for (uint32_t t = 0; t < n_terms; t++)
-    if (terms[t].leaf + 1 > plan.leaf_count) plan.leaf_count = terms[t].leaf + 1;
-  return execute_with_plan(terms, n_terms, k, strategy, block_size, use_plan ? &plan : NULL, deleted,
-                           min_len_cache, out_doc, out_score, stats);
+    if (terms[t].leaf + 1 > leaf_count) leaf_count = terms[t].leaf + 1;
+  expr *nodes = (expr *)malloc(((size_t)leaf_count + 1) * sizeof(expr));
+  plan_t plan;
+  plan_flat(&plan, nodes, SLO_PLAN_SUM, 0.0f, leaf_count);
+  int n = execute_with_plan(terms, n_terms, k, strategy, block_size, use_plan ? &plan : NULL, deleted,
+                            min_len_cache, out_doc, out_score, stats);
+  free(nodes);
+  return n;
 }
 
 int slo_execute_top_k_plan(const slo_term *terms, uint32_t n_terms, uint32_t k, int strategy,
                            uint32_t block_size, int plan_kind, float tie_breaker,
                            uint32_t leaf_count, const uint8_t *deleted, const float *min_len_cache,
                            uint32_t *out_doc, float *out_score, slo_stats *stats) {
-  plan_t plan = {plan_kind, tie_breaker, leaf_count};
   for (uint32_t t = 0; t < n_terms; t++)
-    if (terms[t].leaf + 1 > plan.leaf_count) plan.leaf_count = terms[t].leaf + 1;
-  return execute_with_plan(terms, n_terms, k, strategy, block_size, &plan, deleted, min_len_cache,
-                           out_doc, out_score, stats);
+    if (terms[t].leaf + 1 > leaf_count) leaf_count = terms[t].leaf + 1;
+  expr *nodes = (expr *)malloc(((size_t)leaf_count + 1) * sizeof(expr));
+  plan_t plan;
+  plan_flat(&plan, nodes, plan_kind, tie_breaker, leaf_count);
+  int n = execute_with_plan(terms, n_terms, k, strategy, block_size, &plan, deleted, min_len_cache,
+                            out_doc, out_score, stats);
+  free(nodes);
+  return n;
+}
+
+int slo_execute_top_k_tree(const slo_term *terms, uint32_t n_terms, uint32_t k, int strategy,
+                           uint32_t block_size, int plan_kind, float tie_breaker, uint32_t leaf_count,
+                           uint32_t n_groups, const uint32_t *leaf_group, const int32_t *group_plan,
+                           const float *group_tie, const uint8_t *deleted, const float *min_len_cache,
+                           uint32_t *out_doc, float *out_score, slo_stats *stats) {
+  expr *nodes = (expr *)malloc(((size_t)leaf_count + n_groups + 1) * sizeof(expr));
+  plan_t plan;
+  plan_tree(&plan, nodes, plan_kind, tie_breaker, leaf_count, n_groups, leaf_group, group_plan, group_tie);
+  int n = execute_with_plan(terms, n_terms, k, strategy, block_size, &plan, deleted, min_len_cache,
+                            out_doc, out_score, stats);
+  free(nodes);
+  return n;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -690,6 +774,10 @@ typedef struct {
   const int32_t *q_plan;     /* per query SLO_PLAN_*, or NULL: SUM */
   const float *q_tie;        /* per query, or NULL */
   const uint32_t *q_nleaves; /* per query (leaves of the plan), or NULL: max leaf + 1 */
+  /* two-level plans (NULL leaf_group: flat): CSR of per-leaf groups and per-group kind / tie */
+  const uint32_t *q_leaf_offsets, *leaf_group, *q_group_offsets;
+  const int32_t *group_plan;
+  const float *group_tie;
 } batch_ctx;
 
 static void run_query(const batch_ctx *c, uint32_t q, slo_term *terms, float *mins, uint32_t *tmp_doc,
@@ -727,11 +815,21 @@ static void run_query(const batch_ctx *c, uint32_t q, slo_term *terms, float *mi
       n++;
     }
     if (n == 0) continue; /* api/reader.rs:3003-3005 */
-    int got = slo_execute_top_k_plan(terms, n, c->k, c->strategy, c->block_size,
-                                     c->q_plan ? c->q_plan[q] : SLO_PLAN_SUM,
-                                     c->q_tie ? c->q_tie[q] : 0.0f, n_leaves, seg->deleted,
-                                     c->min_len ? mins : NULL, tmp_doc, tmp_score,
-                                     c->stats ? &c->stats[q] : NULL);
+    int got;
+    if (c->leaf_group) {
+      uint32_t lo = c->q_leaf_offsets[q], go = c->q_group_offsets[q];
+      got = slo_execute_top_k_tree(terms, n, c->k, c->strategy, c->block_size,
+                                   c->q_plan ? c->q_plan[q] : SLO_PLAN_SUM, c->q_tie ? c->q_tie[q] : 0.0f,
+                                   c->q_leaf_offsets[q + 1] - lo, c->q_group_offsets[q + 1] - go,
+                                   c->leaf_group + lo, c->group_plan + go, c->group_tie + go, seg->deleted,
+                                   c->min_len ? mins : NULL, tmp_doc, tmp_score, c->stats ? &c->stats[q] : NULL);
+    } else {
+      got = slo_execute_top_k_plan(terms, n, c->k, c->strategy, c->block_size,
+                                   c->q_plan ? c->q_plan[q] : SLO_PLAN_SUM,
+                                   c->q_tie ? c->q_tie[q] : 0.0f, n_leaves, seg->deleted,
+                                   c->min_len ? mins : NULL, tmp_doc, tmp_score,
+                                   c->stats ? &c->stats[q] : NULL);
+    }
     for (int i = 0; i < got; i++) {
       hits[n_hits].score = tmp_score[i];
       hits[n_hits].seg = s;
@@ -787,6 +885,20 @@ int slo_search_batch_plan(const slo_segment *segs, uint32_t n_segs, uint32_t nq,
                           const uint32_t *q_nleaves, uint32_t k, int strategy, uint32_t block_size,
                           int n_threads, int cache_min_len, uint32_t *out_doc, uint32_t *out_seg,
                           float *out_score, uint32_t *out_count, slo_stats *stats_or_null) {
+  return slo_search_batch_tree(segs, n_segs, nq, q_offsets, q_terms, q_weights, q_leaf, q_plan, q_tie, q_nleaves,
+                               NULL, NULL, NULL, NULL, NULL, k, strategy, block_size, n_threads, cache_min_len,
+                               out_doc, out_seg, out_score, out_count, stats_or_null);
+}
+
+int slo_search_batch_tree(const slo_segment *segs, uint32_t n_segs, uint32_t nq,
+                          const uint32_t *q_offsets, const uint32_t *q_terms, const float *q_weights,
+                          const uint32_t *q_leaf, const int32_t *q_plan, const float *q_tie,
+                          const uint32_t *q_nleaves, const uint32_t *q_leaf_offsets,
+                          const uint32_t *leaf_group, const uint32_t *q_group_offsets,
+                          const int32_t *group_plan, const float *group_tie, uint32_t k, int strategy,
+                          uint32_t block_size, int n_threads, int cache_min_len, uint32_t *out_doc,
+                          uint32_t *out_seg, float *out_score, uint32_t *out_count,
+                          slo_stats *stats_or_null) {
   if (!segs || !q_offsets || !out_doc || !out_seg || !out_score || !out_count) return -1;
   if (n_threads < 1) n_threads = 1;
   if (nq == 0) return 0;
@@ -813,7 +925,8 @@ int slo_search_batch_plan(const slo_segment *segs, uint32_t n_segs, uint32_t nq,
   for (int t = 0; t < n_threads; t++) {
     batch_ctx c = {segs,      n_segs,   nq,        q_offsets, q_terms,   q_weights, k,
                    strategy,  block_size, min_len, max_fields, out_doc,  out_seg,   out_score,
-                   out_count, stats_or_null, t,    n_threads, q_leaf, q_plan, q_tie, q_nleaves};
+                   out_count, stats_or_null, t,    n_threads, q_leaf, q_plan, q_tie, q_nleaves,
+                   q_leaf_offsets, leaf_group, q_group_offsets, group_plan, group_tie};
     ctxs[t] = c;
   }
   if (n_threads == 1) {

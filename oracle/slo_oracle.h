@@ -132,6 +132,26 @@ int slo_search_batch_plan(const slo_segment *segs, uint32_t n_segs, uint32_t nq,
                           int n_threads, int cache_min_len, uint32_t *out_doc, uint32_t *out_seg,
                           float *out_score, uint32_t *out_count, slo_stats *stats_or_null);
 
+/* Two-level score plans (ScoreExpr::evaluate is recursive, query/planner.rs:122-153): the root
+ * (q_plan / q_tie) combines GROUPS, a group (group_plan / group_tie) combines its consecutive
+ * LEAVES: leaf_group[q_leaf_offsets[q] + l] = group of leaf l of query q (non-decreasing),
+ * group g of query q = group_plan / group_tie [q_group_offsets[q] + g].  A Sum group of one leaf is
+ * a bare Leaf child.  leaf_group == NULL: slo_search_batch_plan. */
+int slo_search_batch_tree(const slo_segment *segs, uint32_t n_segs, uint32_t nq,
+                          const uint32_t *q_offsets, const uint32_t *q_terms, const float *q_weights,
+                          const uint32_t *q_leaf, const int32_t *q_plan, const float *q_tie,
+                          const uint32_t *q_nleaves, const uint32_t *q_leaf_offsets,
+                          const uint32_t *leaf_group, const uint32_t *q_group_offsets,
+                          const int32_t *group_plan, const float *group_tie, uint32_t k, int strategy,
+                          uint32_t block_size, int n_threads, int cache_min_len, uint32_t *out_doc,
+                          uint32_t *out_seg, float *out_score, uint32_t *out_count,
+                          slo_stats *stats_or_null);
+int slo_execute_top_k_tree(const slo_term *terms, uint32_t n_terms, uint32_t k, int strategy,
+                           uint32_t block_size, int plan_kind, float tie_breaker, uint32_t leaf_count,
+                           uint32_t n_groups, const uint32_t *leaf_group, const int32_t *group_plan,
+                           const float *group_tie, const uint8_t *deleted, const float *min_len_cache,
+                           uint32_t *out_doc, float *out_score, slo_stats *stats);
+
 /* vectors/mod.rs:74-81 */
 void slo_normalize_in_place(float *v, uint32_t dim);
 /* vectors/mod.rs:107-120 */

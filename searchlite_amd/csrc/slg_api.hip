@@ -1090,7 +1090,7 @@ int slg_batch_run(slg_batch *b) {
       sp.slice_desc = b->d_slice_desc.as<slg::SliceDesc>();
       sp.reject_table = ix->d_reject_table.as<const uint32_t *>();
       sp.n_segs = (uint32_t)ix->segs.size();
-      sp.plan_batch = b->plan_batch ? 1u : 0u;
+      sp.plan_batch = b->plan_batch ? (b->nested ? 2u : 1u) : 0u;
       sp.cand = b->d_cand.as<uint2>();
       sp.slice_cbeg = b->d_slice_cbeg.as<uint64_t>();
       sp.slice_ccnt = b->d_slice_ccnt.as<uint32_t>();

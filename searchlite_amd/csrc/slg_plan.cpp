@@ -17,6 +17,7 @@ namespace {
   } while (0)
 
 inline uint32_t full_mask(uint32_t n) { return n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u); }
+constexpr uint32_t kMaxPlanNodes = 255;  // leaves / groups of a two-level plan (8-bit fields of TermRef::gmeta)
 
 // ---- validation of the caller's arrays (cheap, before anything indexes through them) ------------
 struct BatchFacts {
@@ -65,9 +66,11 @@ BatchFacts validate_batch(const BatchIn &in, uint32_t n_segs) {
       const uint32_t nl = pl.q_leaf_offsets[q + 1] - pl.q_leaf_offsets[q];
       const uint32_t ng = pl.q_group_offsets[q + 1] - pl.q_group_offsets[q];
       PLAN_REQUIRE(nl == pl.q_nleaves[q], "q_leaf_offsets disagrees with q_nleaves in query " + std::to_string(q));
-      if (nl > SLG_MAX_QUERY_TERMS || ng > SLG_MAX_QUERY_TERMS)
+      // (the descriptors keep a group's id and its leaf count in 8 bits each; leaves without a
+      //  term are legal — a DisMax counts them as 0.0 — so the limits are not the term limit)
+      if (nl > kMaxPlanNodes || ng > kMaxPlanNodes)
         throw SlgError(SLG_ERR_UNSUPPORTED, "query " + std::to_string(q) + " has more than " +
-                                                std::to_string(SLG_MAX_QUERY_TERMS) + " leaves or groups");
+                                                std::to_string(kMaxPlanNodes) + " leaves or groups");
       uint32_t prev = 0;
       bool is_flat = ng == nl;  // every leaf its own Sum group == the flat plan
       for (uint32_t l = 0; l < nl; l++) {
@@ -186,7 +189,7 @@ void plan_queries(const Pass1Ctx &c, const uint32_t q_lo, const uint32_t q_hi, P
     const bool groups = pl.leaf_group != nullptr;
     const uint32_t *lgroup = groups ? pl.leaf_group + pl.q_leaf_offsets[q] : nullptr;
     const uint32_t n_groups = groups ? pl.q_group_offsets[q + 1] - pl.q_group_offsets[q] : 0u;
-    uint32_t leaves_in_group[SLG_MAX_QUERY_TERMS] = {0};
+    uint32_t leaves_in_group[kMaxPlanNodes + 1] = {0};
     bool nested = false;
     if (groups) {
       PLAN_REQUIRE(n_leaves == pl.q_nleaves[q], "a term names a leaf beyond q_nleaves in query " + std::to_string(q));

@@ -50,15 +50,16 @@ constexpr int multi_wave_lds(int kregs) {
   return kSpanWords * 4 + kSpanWords * 4 + (kMultiCap + 64) * 4 + kMultiCap * 4 +
          (uni_buffered(kregs) ? buftopk_lds(kregs) : 0);
 }
-constexpr int kMultiPlanLds = 2 * kMultiCap * 4;  // acc[] and max[] of the leaf close
+constexpr int kMultiPlanLds = 2 * kMultiCap * 4;  // acc[] and max[] of the leaf close (x2 for two-level plans)
 
 // MODE 0: flat sums; 1: the batch has MaxScore-classified sub-queries (non-essential lists are
-// only probed); 2: the batch has score plans (leaf close).  Separate instantiations: the extra
-// code of one mode costs the others registers.
+// only probed); 2: the batch has score plans (leaf close); 3: some of them two-level (group close).
+// Separate instantiations: the extra code of one mode costs the others registers.
 template <int KREGS, int MODE>
 __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) {
   constexpr bool MS = MODE == 1;
-  constexpr bool PL = MODE == 2;
+  constexpr bool PL = MODE >= 2;
+  constexpr bool NE = MODE == 3;  // two-level plans (its own instantiation: the group close costs registers)
   constexpr int NS = kUniSlots;
   constexpr bool BUF = uni_buffered(KREGS);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -92,12 +93,15 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
   // lane t < T: list t's posting offset, weight, term id
   uint64_t my_off = 0;
   float my_w = 0.0f;
-  uint32_t my_leaf = 0;
+  uint32_t my_leaf = 0, my_gmeta = 0;
+  float my_gtie = 0.0f;
   if (lane < T) {
     const TermRef tr = p.terms[s.term_begin + lane];
     my_off = tr.off;
     my_w = tr.weight;
     my_leaf = tr.leaf;
+    my_gmeta = tr.gmeta;
+    my_gtie = tr.gtie;
   }
   const uint32_t my_off_lo = (uint32_t)my_off, my_off_hi = (uint32_t)(my_off >> 32);
   const uint32_t ess_mask = MS ? rfl(s.ess_mask) : 0xFFFFFFFFu;  // bit t: list t is essential
@@ -109,6 +113,12 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
   const uint32_t n_leaves = rfl(s.n_leaves);
   float *acc = reinterpret_cast<float *>(smem + multi_wave_lds(KREGS));  // only if plan_batch
   float *mxv = acc + kMultiCap;
+  // two-level plans (plan_batch == 2): acc / mxv accumulate the CURRENT GROUP's leaves, racc / rmx
+  // the root over the closed groups
+  const uint32_t n_groups = NE ? rfl(s.n_groups) : 0u;
+  const bool nested = n_groups != 0u;
+  float *racc = mxv + kMultiCap;
+  float *rmx = racc + kMultiCap;
   const gu32_t gbounds = (gu32_t)p.bounds + s.bounds_begin + (size_t)r0 * T;
   const gu32_t grdoc = (gu32_t)p.rdoc + s.rdoc_begin + r0;
 
@@ -277,6 +287,13 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
         acc4[lane + 64] = make_uint4(a0, a0, a0, a0);
         mx4[lane] = make_uint4(max_init, max_init, max_init, max_init);
         mx4[lane + 64] = make_uint4(max_init, max_init, max_init, max_init);
+        if (nested) {  // the root: a DisMax sum starts at 0.0, a Sum at -0.0; its max at -inf
+          uint4 *ra4 = reinterpret_cast<uint4 *>(racc), *rm4 = reinterpret_cast<uint4 *>(rmx);
+          ra4[lane] = make_uint4(a0, a0, a0, a0);
+          ra4[lane + 64] = make_uint4(a0, a0, a0, a0);
+          rm4[lane] = make_uint4(0xFF800000u, 0xFF800000u, 0xFF800000u, 0xFF800000u);
+          rm4[lane + 64] = make_uint4(0xFF800000u, 0xFF800000u, 0xFF800000u, 0xFF800000u);
+        }
       }
       wave_fence();
       SLG_STAMP(1);
@@ -348,6 +365,53 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
             acc[r] = a;
             mxv[r] = m;
             vals[r] = 0u;
+          }
+        }
+        wave_fence();
+      };
+      // Two-level plans (ScoreExpr::evaluate recursion, planner.rs:122-153): the lists arrive sorted
+      // by leaf and a group's leaves are consecutive.  A leaf change folds vals into the GROUP's
+      // (acc, mxv); a group change folds the group's value — Sum: acc; DisMax: max + tie * (sum -
+      // max), a leaf of the group without a posting in this chunk counting as 0.0 — into the root's
+      // (racc, rmx) and resets the group accumulators for the next group's kind.
+      uint32_t g_closed = 0, groups_closed = 0, cur_group = 0xFFFFFFFFu, cur_gmeta = 0;
+      float cur_gtie = 0.0f;
+      auto open_group = [&](const uint32_t gmeta) {  // bulk init of the group accumulators
+        const float a0 = (gmeta >> 16) & 1u ? 0.0f : -0.0f;
+        for (uint32_t r = lane; r < ndocs; r += 64) {
+          acc[r] = a0;
+          mxv[r] = -INFINITY;
+        }
+        wave_fence();
+      };
+      auto close_group_leaf = [&]() {  // the current leaf's sums -> the group
+        g_closed++;
+        for (uint32_t r = lane; r < ndocs; r += 64) {
+          const float c = __uint_as_float(vals[r]);
+          acc[r] = acc[r] + c;
+          mxv[r] = fmaxf(mxv[r], c);
+          vals[r] = 0u;
+        }
+        wave_fence();
+      };
+      auto close_group = [&](const bool final) {  // the group's value -> the root (-> vals when final)
+        groups_closed++;
+        const bool g_dismax = (cur_gmeta >> 16) & 1u;
+        const bool leaf_idle = g_closed < ((cur_gmeta >> 8) & 0xFFu);
+        const bool group_idle = final && groups_closed < n_groups;
+        for (uint32_t r = lane; r < ndocs; r += 64) {
+          const float a = acc[r];
+          float m = mxv[r];
+          if (leaf_idle) m = fmaxf(m, 0.0f);
+          const float gv = g_dismax ? m + cur_gtie * (a - m) : a;
+          const float ra = racc[r] + gv;
+          float rm = fmaxf(rmx[r], gv);
+          if (final) {
+            if (group_idle) rm = fmaxf(rm, 0.0f);
+            vals[r] = __float_as_uint(plan == 2u ? rm + tie * (ra - rm) : ra);
+          } else {
+            racc[r] = ra;
+            rmx[r] = rm;
           }
         }
         wave_fence();
@@ -434,7 +498,20 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
           if (plan) {
             const uint32_t lf = rl(my_leaf, lst);
             if (lf != cur_leaf) {
-              if (cur_leaf != 0xFFFFFFFFu) close_leaf(false);
+              if (nested) {
+                const uint32_t gm = rl(my_gmeta, lst);
+                if (cur_leaf != 0xFFFFFFFFu) close_group_leaf();
+                if ((gm & 0xFFu) != cur_group) {
+                  if (cur_group != 0xFFFFFFFFu) close_group(false);
+                  open_group(gm);
+                  cur_group = gm & 0xFFu;
+                  cur_gmeta = gm;
+                  cur_gtie = __uint_as_float(rl(__float_as_uint(my_gtie), lst));
+                  g_closed = 0;
+                }
+              } else if (cur_leaf != 0xFFFFFFFFu) {
+                close_leaf(false);
+              }
               cur_leaf = lf;
             }
           }
@@ -451,7 +528,14 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
       }
       wave_fence();
       SLG_STAMP(4);
-      if (plan) close_leaf(true);
+      if (plan) {
+        if (nested) {
+          close_group_leaf();
+          close_group(true);
+        } else {
+          close_leaf(true);
+        }
+      }
       // ---- P4: the docs of the chunk in rank order -> top-k ----
       for (uint32_t base = 0; base < ndocs; base += 64) {
         const uint32_t r = base + lane;

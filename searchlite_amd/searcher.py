@@ -151,16 +151,21 @@ class GpuIndex:
 
     # -- search ----------------------------------------------------------------------
     def prepare(self, q_offsets, q_terms, q_weights, k: int, strategy: int = Wand,
-                q_filter=None, q_leaf=None, q_plan=None, q_tie=None, q_nleaves=None) -> "PreparedBatch":
-        """q_leaf / q_plan / q_tie / q_nleaves: score plans (slg_batch_prepare_plan)."""
+                q_filter=None, q_leaf=None, q_plan=None, q_tie=None, q_nleaves=None,
+                q_leaf_offsets=None, leaf_group=None, q_group_offsets=None, group_plan=None,
+                group_tie=None) -> "PreparedBatch":
+        """q_leaf / q_plan / q_tie / q_nleaves: score plans; leaf_group / group_plan / group_tie with
+        their per-query offsets: two-level plans (slg_batch_prepare_plans, slg_score_plans)."""
         return PreparedBatch(self, q_offsets, q_terms, q_weights, k, strategy, q_filter,
-                             q_leaf, q_plan, q_tie, q_nleaves)
+                             q_leaf, q_plan, q_tie, q_nleaves, q_leaf_offsets, leaf_group,
+                             q_group_offsets, group_plan, group_tie)
 
     def search_plan(self, q_offsets, q_terms, q_weights, k: int, q_leaf=None, q_plan=None,
-                    q_tie=None, q_nleaves=None, strategy: int = Wand, q_filter=None):
-        """Batch search with score plans (multi-field leaves / DisMax) -> (doc, seg, score, count)."""
+                    q_tie=None, q_nleaves=None, strategy: int = Wand, q_filter=None, **tree):
+        """Batch search with score plans (multi-field leaves / DisMax; **tree: the two-level plan
+        arrays of prepare()) -> (doc, seg, score, count)."""
         b = self.prepare(q_offsets, q_terms, q_weights, k, strategy, q_filter, q_leaf, q_plan,
-                         q_tie, q_nleaves)
+                         q_tie, q_nleaves, **tree)
         try:
             b.run()
             return b.fetch()
@@ -400,7 +405,9 @@ class PreparedBatch:
     """A planned query batch with device-resident descriptors and work buffers."""
 
     def __init__(self, index: GpuIndex, q_offsets, q_terms, q_weights, k: int, strategy: int,
-                 q_filter=None, q_leaf=None, q_plan=None, q_tie=None, q_nleaves=None):
+                 q_filter=None, q_leaf=None, q_plan=None, q_tie=None, q_nleaves=None,
+                 q_leaf_offsets=None, leaf_group=None, q_group_offsets=None, group_plan=None,
+                 group_tie=None):
         self.index = index
         self._lib = index._lib
         q_offsets = np.ascontiguousarray(q_offsets, dtype=np.uint32)
@@ -417,9 +424,14 @@ class PreparedBatch:
         assert ql is None or len(ql) == len(q_weights)
         assert all(x is None or len(x) == self.nq for x in (qp, qt, qn))
         opt = lambda a: None if a is None else _ptr(a)
-        self._h = self._lib.slg_batch_prepare_plan(
-            index._h, self.nq, _ptr(q_offsets), _ptr(q_terms), _ptr(q_weights), opt(ql), opt(qp),
-            opt(qt), opt(qn), opt(qf), k, strategy)
+        u32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.uint32)
+        qlo, lg, qgo = u32(q_leaf_offsets), u32(leaf_group), u32(q_group_offsets)
+        gp = None if group_plan is None else np.ascontiguousarray(group_plan, dtype=np.int32)
+        gt = None if group_tie is None else np.ascontiguousarray(group_tie, dtype=np.float32)
+        plans = N.ScorePlans(opt(ql), opt(qp), opt(qt), opt(qn), opt(qlo), opt(lg), opt(qgo), opt(gp), opt(gt))
+        self._h = self._lib.slg_batch_prepare_plans(
+            index._h, self.nq, _ptr(q_offsets), _ptr(q_terms), _ptr(q_weights), C.addressof(plans),
+            opt(qf), k, strategy)
         if not self._h:
             raise N.SlgError(N.last_error_code() or N.ERR_INVALID, N.last_error())
         index._batches.add(self)

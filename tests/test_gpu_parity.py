@@ -268,6 +268,92 @@ def test_score_plans_multi_field_and_dismax(gpu, oracle, k):
     assert_same_hits(got, want_f, 0.0, "plans + filter")
 
 
+@pytest.mark.parametrize("k", [11, 400])
+def test_two_level_score_plans(gpu, oracle, k):
+    """ScoreExpr::evaluate is recursive (query/planner.rs:122-153); the two-level trees real requests
+    build, mixed in one batch with flat plans, two segments, tombstones, ragged leaves:
+      * `dis_max{queries: [query_string, query_string, ...]}` (planner.rs:470-487): root DisMax +
+        tie over sub-scorers, each a Sum over its words' leaves (a leaf = the word's fields);
+      * `bool{should: [multi_match best_fields, term]}` (planner.rs:670-690): root Sum over
+        [DisMax group over the fields' leaves, a bare leaf];
+      * a root DisMax over DisMax groups, one of them with a leaf that has no term at all.
+    Bit-exact against the oracle's recursive restatement."""
+    from tests.util import random_multifield_segment
+    rng = np.random.default_rng(900 + k)
+    vocab, F = 14, 3
+    segs = [random_multifield_segment(rng, 2600 + 500 * i, vocab, F, 12) for i in range(2)]
+    segs[0].set_deleted(list(range(3, segs[0].n_docs, 13)))
+    offs, terms, w, leaf, plan, tie, nl = [0], [], [], [], [], [], []
+    qlo, lg, qgo, gp, gt = [0], [], [0], [], []
+    for q in range(30):
+        kind = q % 4
+        words = [int(x) for x in rng.choice(vocab, size=4, replace=False)]
+        ql, qg, qgp, qgt = [], [], [], []   # this query's term leaves, leaf groups, group plans / ties
+        if kind == 0:    # dis_max over two query strings of two words each; leaf = word (its fields add up)
+            for wi, wd in enumerate(words):
+                for f in range(F):
+                    terms.append([f * vocab + wd] * 2)
+                    w.append(np.float32(1.0 + 0.25 * f))
+                    ql.append(wi)
+            qg, qgp, qgt = [0, 0, 1, 1], [gpu.PLAN_SUM, gpu.PLAN_SUM], [0.0, 0.0]
+            plan.append(gpu.PLAN_DISMAX), tie.append(0.3), nl.append(4)
+        elif kind == 1:  # bool.should: [multi_match best_fields over F fields of word 0, term word 1 in field 0]
+            for f in range(F):
+                terms.append([f * vocab + words[0]] * 2)
+                w.append(np.float32(1.0 + 0.5 * f))
+                ql.append(f)
+            terms.append([words[1]] * 2)
+            w.append(np.float32(2.0))
+            ql.append(F)
+            qg, qgp, qgt = [0] * F + [1], [gpu.PLAN_DISMAX, gpu.PLAN_SUM], [0.4, 0.0]
+            plan.append(gpu.PLAN_SUM), tie.append(0.0), nl.append(F + 1)
+        elif kind == 2:  # DisMax of DisMax groups; group 1 has a leaf (index 4) no term names
+            for wi, wd in enumerate(words[:2]):
+                for f in range(2):
+                    terms.append([f * vocab + wd] * 2)
+                    w.append(np.float32(0.5 + wi))
+                    ql.append(wi * 2 + f)
+            qg, qgp, qgt = [0, 0, 1, 1, 1], [gpu.PLAN_DISMAX, gpu.PLAN_DISMAX], [1.0, 0.25]
+            plan.append(gpu.PLAN_DISMAX), tie.append(0.5), nl.append(5)
+        else:            # a flat plan inside the same batch: every leaf its own Sum group
+            for wi, wd in enumerate(words[:3]):
+                terms.append([wd] * 2)
+                w.append(np.float32(1.0))
+                ql.append(wi)
+            qg, qgp, qgt = [0, 1, 2], [gpu.PLAN_SUM] * 3, [0.0] * 3
+            plan.append(gpu.PLAN_SUM), tie.append(0.0), nl.append(3)
+        leaf += ql
+        offs.append(len(terms))
+        lg += qg
+        qlo.append(len(lg))
+        gp += qgp
+        gt += qgt
+        qgo.append(len(gp))
+    offs = np.array(offs, dtype=np.uint32)
+    terms = np.array(terms, dtype=np.uint32)
+    w = np.array(w, dtype=np.float32)
+    kw = dict(q_leaf=np.array(leaf, dtype=np.uint32), q_plan=np.array(plan, dtype=np.int32),
+              q_tie=np.array(tie, dtype=np.float32), q_nleaves=np.array(nl, dtype=np.uint32),
+              q_leaf_offsets=np.array(qlo, dtype=np.uint32), leaf_group=np.array(lg, dtype=np.uint32),
+              q_group_offsets=np.array(qgo, dtype=np.uint32), group_plan=np.array(gp, dtype=np.int32),
+              group_tie=np.array(gt, dtype=np.float32))
+    want = oracle.search_batch(segs, offs, terms, w, k, strategy=oracle.BM25, **kw)
+    flat_kw = {n: kw[n] for n in ("q_leaf", "q_plan", "q_tie", "q_nleaves")}
+    flat = oracle.search_batch(segs, offs, terms, w, k, strategy=oracle.BM25, **flat_kw)
+    assert not np.array_equal(want[2].view(np.uint32), flat[2].view(np.uint32))  # the groups matter
+    with gpu.GpuIndex(segs) as ix:
+        for strat in (gpu.Bm25, gpu.Wand):
+            assert_same_hits(ix.search_plan(offs, terms, w, k, strategy=strat, **kw), want, 0.0,
+                             f"two-level plans k={k} strategy={strat}")
+        # all-flat groups through the two-level entry = the flat entry, bit for bit
+        n_l = sum(nl)
+        flat_tree = dict(flat_kw, q_leaf_offsets=np.concatenate([[0], np.cumsum(nl)]).astype(np.uint32),
+                         leaf_group=np.concatenate([np.arange(n) for n in nl]).astype(np.uint32),
+                         q_group_offsets=np.concatenate([[0], np.cumsum(nl)]).astype(np.uint32),
+                         group_plan=np.zeros(n_l, np.int32), group_tie=np.zeros(n_l, np.float32))
+        assert_same_hits(ix.search_plan(offs, terms, w, k, **flat_tree), flat, 0.0, "flat plan as one-leaf groups")
+
+
 @pytest.mark.parametrize("k", [1025, 2049, 5000, 20001])
 def test_very_large_k_rank_ranges(gpu, oracle, k):
     """k up to the reference's 20 001 (api/reader.rs:2615-2619): the select kernel emits the result

@@ -419,6 +419,86 @@ def test_score_plan_arithmetic_against_numpy(oracle):
             assert np.float32(got[2][0, i]).view(np.uint32) == np.float32(want[int(got[0][0, i])]).view(np.uint32)
 
 
+def _eval_tree_numpy(leaves, root_plan, root_tie, leaf_group, group_plan, group_tie):
+    """ScoreExpr::evaluate (planner.rs:122-153) on one doc's leaf values, numpy f32, written
+    independently of the oracle: Sum folds from -0.0, DisMax keeps (max from -inf, sum from 0.0),
+    a Sum group of one leaf is the bare Leaf."""
+    f32 = np.float32
+
+    def node(kind, tie, vals):
+        if kind == 0:
+            s_ = f32(-0.0)
+            for v in vals:
+                s_ = f32(s_ + v)
+            return s_
+        mx, sm = f32(-np.inf), f32(0.0)
+        for v in vals:
+            mx = f32(max(mx, v))
+            sm = f32(sm + v)
+        return f32(mx + f32(f32(tie) * f32(sm - mx)))
+
+    groups = []
+    for g in range(len(group_plan)):
+        vals = [leaves[l] for l in range(len(leaves)) if leaf_group[l] == g]
+        groups.append(vals[0] if (len(vals) == 1 and group_plan[g] == 0) else node(group_plan[g], group_tie[g], vals))
+    return node(root_plan, root_tie, groups)
+
+
+def test_two_level_score_plans_against_numpy(oracle):
+    """The recursive ScoreExpr restatement on the two shapes real requests build: `dis_max{queries}`
+    = DisMax of sub-scorers (planner.rs:470-487: each sub-query a Sum over its fields' leaves) and
+    `bool{should: [multi_match, term]}` = Sum of [DisMax group, bare leaf] (planner.rs:670-690),
+    checked per doc against an independent numpy f32 evaluation."""
+    from tests.util import random_multifield_segment
+    rng = np.random.default_rng(23)
+    vocab, F = 10, 3
+    seg = random_multifield_segment(rng, 300, vocab, F, 9)
+    words = [1, 4, 6]
+    # 3 words x 3 fields = 9 terms; leaf = word*?: 5 leaves: word0 -> leaves 0,1 (fields 0|1,2), word1 -> leaf 2, word2 -> 3,4
+    terms = np.array([[f * vocab + w_] for w_ in words for f in range(F)], dtype=np.uint32)
+    leaf = np.array([0, 1, 1, 2, 2, 2, 3, 3, 4], dtype=np.uint32)
+    w = (rng.random(len(terms)).astype(np.float32) + np.float32(0.5))
+    offs = np.array([0, len(terms)], dtype=np.uint32)
+    shapes = [  # (root plan, root tie, leaf_group, group_plan, group_tie)
+        (oracle.PLAN_DISMAX, 0.3, [0, 0, 1, 2, 2], [oracle.PLAN_SUM, oracle.PLAN_SUM, oracle.PLAN_SUM], [0, 0, 0]),
+        (oracle.PLAN_SUM, 0.0, [0, 0, 1, 2, 2], [oracle.PLAN_DISMAX, oracle.PLAN_SUM, oracle.PLAN_DISMAX], [0.5, 0, 1.0]),
+        (oracle.PLAN_DISMAX, 1.0, [0, 0, 0, 1, 1], [oracle.PLAN_DISMAX, oracle.PLAN_DISMAX], [0.0, 0.25]),
+    ]
+    for rp, rt, lg, gp, gt in shapes:
+        got = oracle.search_batch([seg], offs, terms, w, 300, strategy=oracle.BM25, q_leaf=leaf, q_plan=[rp],
+                                  q_tie=[rt], q_nleaves=[5], q_leaf_offsets=[0, 5], leaf_group=lg,
+                                  q_group_offsets=[0, len(gp)], group_plan=gp, group_tie=gt)
+        leaves = np.zeros((300, 5), dtype=np.float32)
+        seen = np.zeros(300, dtype=bool)
+        for i, t in enumerate(terms[:, 0]):
+            a, b_ = int(seg.term_offsets[t]), int(seg.term_offsets[t + 1])
+            f = int(seg.term_field[t])
+            for d, tf in zip(seg.doc_ids[a:b_], seg.tfs[a:b_]):
+                x = oracle.score_tf(float(tf), float(b_ - a), float(seg.field_doc_len[f][d]),
+                                    float(seg.field_avgdl[f]), seg.docs, seg.k1, seg.b, float(w[i]))
+                leaves[d, leaf[i]] = np.float32(leaves[d, leaf[i]] + np.float32(x))
+                seen[d] = True
+        n = int(got[3][0])
+        assert n == int(seen.sum())
+        for i in range(n):
+            d = int(got[0][0, i])
+            want = _eval_tree_numpy(leaves[d], rp, rt, lg, gp, gt)
+            assert np.float32(got[2][0, i]).view(np.uint32) == np.float32(want).view(np.uint32), (rp, d)
+        # pruned strategies agree with the exhaustive one on the head (tests/pruning.rs standard)
+        head = oracle.search_batch([seg], offs, terms, w, 10, strategy=oracle.WAND, q_leaf=leaf, q_plan=[rp],
+                                   q_tie=[rt], q_nleaves=[5], q_leaf_offsets=[0, 5], leaf_group=lg,
+                                   q_group_offsets=[0, len(gp)], group_plan=gp, group_tie=gt)
+        assert np.array_equal(head[0][0], got[0][0, :10])
+    # every leaf its own Sum group == the flat plan, bit for bit
+    flat = oracle.search_batch([seg], offs, terms, w, 300, strategy=oracle.BM25, q_leaf=leaf,
+                               q_plan=[oracle.PLAN_DISMAX], q_tie=[0.4], q_nleaves=[5])
+    tree = oracle.search_batch([seg], offs, terms, w, 300, strategy=oracle.BM25, q_leaf=leaf,
+                               q_plan=[oracle.PLAN_DISMAX], q_tie=[0.4], q_nleaves=[5], q_leaf_offsets=[0, 5],
+                               leaf_group=[0, 1, 2, 3, 4], q_group_offsets=[0, 5], group_plan=[0] * 5,
+                               group_tie=[0.0] * 5)
+    assert np.array_equal(flat[0], tree[0]) and np.array_equal(flat[2].view(np.uint32), tree[2].view(np.uint32))
+
+
 def test_baseline_a_model_returns_the_scorer_results(oracle):
     """BASELINE.md "Baseline A" (scorer + per-query posting decode x2 + doc-length rebuild): the
     decode / rebuild round trip must not change a single hit."""

@@ -2,7 +2,8 @@
 tombstones, doc filters, score plans and strategies, each batch compared bit for bit with the CPU
 oracle.  usage: python tools/fuzz_parity.py [iterations] [seed]
 (SLG_MAXSCORE=1 / SLG_UNIFORM_MAX_TERMS=0 in the environment force pruning / the many-term kernel;
-FUZZ_MANY_LISTS=1 draws MaxScore-classified queries of 14..32 lists instead.)"""
+FUZZ_MANY_LISTS=1 draws MaxScore-classified queries of 14..32 lists instead; FUZZ_TREES=1 turns the
+score plans of the standard cases into random two-level trees.)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -65,6 +66,27 @@ def run_case(seed0, it, tuning=None):
       use_plan = rng.random() < 0.6
       kw = dict(q_leaf=np.array(leaf, dtype=np.uint32), q_plan=np.array(plan, dtype=np.int32),
                 q_tie=np.array(tie, dtype=np.float32), q_nleaves=np.array(nl, dtype=np.uint32)) if use_plan else {}
+      if use_plan and os.environ.get("FUZZ_TREES", "0") != "0":
+          # two-level plans: the leaves of every query cut into consecutive groups, each Sum or DisMax
+          # (drawn from a generator of its own, so the keyed flat cases stay what they were)
+          trng = np.random.default_rng(seed0 * 1000003 + it + 77)
+          qlo, lg, qgo, gp, gt = [0], [], [0], [], []
+          for q in range(nq):
+              g = 0
+              for l in range(nl[q]):
+                  if l and trng.random() < 0.5:
+                      g += 1
+                  lg.append(g)
+              ng = g + 1 if nl[q] else 0
+              for _ in range(ng):
+                  dm = trng.random() < 0.5
+                  gp.append(sa.PLAN_DISMAX if dm else sa.PLAN_SUM)
+                  gt.append(float(trng.choice([0.0, 0.5, 1.0])) if dm else 0.0)
+              qlo.append(len(lg))
+              qgo.append(len(gp))
+          kw.update(q_leaf_offsets=np.array(qlo, dtype=np.uint32), leaf_group=np.array(lg, dtype=np.uint32),
+                    q_group_offsets=np.array(qgo, dtype=np.uint32), group_plan=np.array(gp, dtype=np.int32),
+                    group_tie=np.array(gt, dtype=np.float32))
       use_filter = rng.random() < 0.4
       masks = [rng.random(sg.n_docs) < rng.choice([0.05, 0.5, 0.95]) for sg in segs]
       with sa.GpuIndex(segs, tuning=tuning) as ix:
