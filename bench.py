@@ -315,73 +315,52 @@ def main():
 
     # ---- leg 1 (`value`): host arrays in -> prepare -> run -> fetch -> host arrays out ----
     n_thr = max(1, args.host_threads)
-    thr_streams = [torch.cuda.Stream() for _ in range(2 * n_thr)]
     first_results = {}
 
-    import queue
-
     class HostPool:
-        """Persistent caller threads (a server's request threads): created and warmed before the
-        timed region, fed step numbers round-robin; run(n) returns when n steps are done.  A thread
-        keeps TWO batches going, each on a stream of its own: it plans and launches step i + n_thr
-        before it collects step i, so the host round trip of one batch (D2H, Python, planning the
-        next one) never leaves the GPU without queued work."""
+        """The caller threads (a server's request threads): lib/libslg_harness.so — the same loop a
+        Rust / C++ host of the C ABI runs (searchlite serves one request per OS thread,
+        searchlite-http/src/lib.rs:640-643), without Python's interpreter lock in the measurement.
+        Persistent threads, created and warmed before the timed region, fed step numbers round-robin;
+        a thread keeps TWO batches going on two HIP streams of its own (prepare + run of the next
+        batch, then fetch + destroy of the previous one), so one batch's host round trip never
+        leaves the GPU without queued work.  run(n) returns when n steps have been fetched."""
 
         def __init__(self):
-            self.todo = [queue.Queue() for _ in range(n_thr)]
-            self.done, self.errors = queue.Queue(), []
-            self.threads = [threading.Thread(target=self._worker, args=(t,), daemon=True) for t in range(n_thr)]
-            for t in self.threads:
-                t.start()
-
-        def _collect(self, prev):
-            b, i = prev
-            res = b.fetch()
-            b.close()
-            if (i % n_sets) not in first_results:
-                first_results[i % n_sets] = res
-            self.done.put(i)
-
-        def _worker(self, tid):
-            torch.cuda.set_device(local_rank)
-            prev, lap = None, 0
-            while True:
-                i = self.todo[tid].get()
-                if i is None:
-                    return
-                try:
-                    if i == "flush":
-                        if prev is not None:
-                            self._collect(prev)
-                            prev = None
-                        continue
-                    offs, terms, w = qs[i % n_sets]
-                    b = index.prepare(offs, terms, w, k, strategy)
-                    b.set_stream(thr_streams[2 * tid + (lap & 1)].cuda_stream)
-                    lap += 1
-                    b.run()
-                    if prev is not None:
-                        self._collect(prev)
-                    prev = (b, i)
-                except Exception as e:  # noqa: BLE001
-                    self.errors.append(e)
-                    self.done.put(-1)
+            import ctypes as C
+            from searchlite_amd import build as sbuild
+            L = C.CDLL(sbuild.build_harness())
+            L.slh_create.restype = C.c_void_p
+            L.slh_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_uint32, C.c_uint32, C.c_int]
+            L.slh_run.restype = C.c_int
+            L.slh_run.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+            L.slh_error.restype = C.c_char_p
+            L.slh_error.argtypes = [C.c_void_p]
+            L.slh_first_result.restype = C.c_int
+            L.slh_first_result.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+            L.slh_destroy.argtypes = [C.c_void_p]
+            self.L, self.C = L, C
+            self.keep = [(np.ascontiguousarray(o, np.uint32), np.ascontiguousarray(t, np.uint32),
+                          np.ascontiguousarray(w_, np.float32)) for o, t, w_ in qs]
+            ptrs = lambda j: (C.c_void_p * n_sets)(*[x[j].ctypes.data for x in self.keep])
+            self.h = L.slh_create(index._h, local_rank, n_thr, n_sets, ptrs(0), ptrs(1), ptrs(2), nq, k, strategy)
 
         def run(self, n_steps, first):
-            for i in range(first, first + n_steps):
-                self.todo[i % n_thr].put(i)
-            for q_ in self.todo:
-                q_.put("flush")
-            for _ in range(n_steps):
-                self.done.get()
-            if self.errors:
-                raise self.errors[0]
+            if self.L.slh_run(self.h, first, n_steps) != 0:
+                raise RuntimeError("host harness: " + self.L.slh_error(self.h).decode())
+
+        def first_result(self, j):
+            d = np.zeros((nq, k), np.uint32)
+            s_ = np.zeros((nq, k), np.uint32)
+            sc = np.zeros((nq, k), np.float32)
+            c = np.zeros(nq, np.uint32)
+            ok = self.L.slh_first_result(self.h, j, d.ctypes.data, s_.ctypes.data, sc.ctypes.data, c.ctypes.data)
+            return (d, s_, sc, c) if ok else None
 
         def close(self):
-            for q_ in self.todo:
-                q_.put(None)
-            for t in self.threads:
-                t.join()
+            self.L.slh_destroy(self.h)
+            self.h = None
 
     value = ms_per_step = value_spread = None
     if not rerank and not args.kernel_leg_only:
@@ -400,6 +379,9 @@ def main():
             pool.run(args.steps, host_warm + r * args.steps)
             fence()
             region_s.append(max_over_ranks(time.perf_counter() - t1))
+        hp0 = pool.first_result(0)
+        if hp0 is not None:
+            first_results[0] = hp0
         pool.close()
         elapsed = float(np.median(region_s))
         ms_per_step = elapsed / args.steps * 1e3

@@ -4,6 +4,7 @@
 * lib/libslg_corpus.so     — harness tool: synthetic Zipf corpus generator (g++, host only).
 * lib/libslg_segfile.so    — host-only decoder of searchlite's segment files (g++).
 * lib/libslg_plan.so       — the host planner behind a test C ABI (g++; CPU unit tests).
+* lib/libslg_harness.so    — bench harness: native caller threads over the C ABI (bench.py).
 
 hipcc cross-compiles gfx950 without a GPU, so this runs in the build container; the built
 .so files travel to the GPU box with the repo snapshot.
@@ -124,8 +125,25 @@ def build_plan_lib(force: bool = False, extra_flags=(), out: str | None = None) 
     return out
 
 
+HARNESS_LIB = os.path.join(LIBDIR, "libslg_harness.so")
+
+
+def build_harness(force: bool = False) -> str:
+    """bench harness: native caller threads over the C ABI (csrc/tools/host_harness.cpp); links
+    libsearchlite_gpu.so.  Not part of the product library."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    src = os.path.join(CSRC, "tools", "host_harness.cpp")
+    hdr = os.path.join(_HERE, "..", "include", "searchlite_gpu.h")
+    if force or _newer(HARNESS_LIB, [src, hdr, GPU_LIB]):
+        subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread",
+                               "-x", "hip", src, "-L" + LIBDIR, "-lsearchlite_gpu", "-Wl,-rpath,$ORIGIN",
+                               "-o", HARNESS_LIB])
+    return HARNESS_LIB
+
+
 def build_all(force: bool = False, verbose: bool = False) -> None:
     build_gpu(force, verbose)
+    build_harness(force)
     build_corpus_tool(force)
     build_segfile(force)
     build_plan_lib(force)

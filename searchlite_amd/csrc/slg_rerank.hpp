@@ -256,6 +256,103 @@ __device__ __forceinline__ void rerank_scan_rows(const RerankParams &p, const ui
   }
 }
 
+// The same whole-row scan for SEVERAL clause vectors over one vector field (multi-clause hybrid
+// requests, api/reader.rs:225-254): a wave takes 4 candidates at a time, has their 4 whole rows in
+// flight (dim <= 256 * CH, dim % 4 == 0), resolves the next 4 row pointers under them, and runs
+// every clause against the rows it holds — each row is read ONCE whatever the clause count.  Clause
+// cc's vector lies in LDS at s_qc + cc * q_stride.  Writes the similarity (cosine: dot, NaN -> 0;
+// L2: -sqrt sum (x - y)^2, vectors/mod.rs:107-120) of clause cc and candidate c to
+// s_vs[cc * vs_stride + c]; with s_has != nullptr, candidates that have a vector get has_bits OR-ed
+// into s_has[c] (the caller zeroes it).
+template <int CH>
+__device__ __forceinline__ void rerank_scan_clauses(const VecSegDev *vsegs, const uint32_t n_segs, const uint32_t dim,
+                                                    const int32_t metric, const float *s_qc, const uint32_t q_stride,
+                                                    const uint32_t n_cl, const uint32_t *cdoc, const uint32_t *cseg,
+                                                    const uint32_t n, const float *readable, float *s_vs,
+                                                    const uint32_t vs_stride, uint32_t *s_has, const uint32_t has_bits,
+                                                    const uint32_t lane, const uint32_t wave) {
+  constexpr int U = 4;
+  if (n == 0) return;
+  typedef float fvec4 __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(1))) fvec4 *grow_t;
+  typedef const __attribute__((address_space(1))) uint32_t *gword_t;
+  uint32_t idx[CH];
+  bool valid[CH];
+#pragma unroll
+  for (int ch = 0; ch < CH; ch++) {
+    const uint32_t i = ch * 256 + lane * 4;
+    valid[ch] = i < dim;
+    idx[ch] = valid[ch] ? i : 0u;
+  }
+  grow_t rowN[U];
+  bool haveN[U];
+  auto resolve = [&](const uint32_t c0) {  // branch-free on the scalar unit (clamped indices)
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const uint32_t c = c0 + u;
+      const bool c_ok = c < n;
+      const uint32_t cc = c_ok ? c : 0u;
+      const uint32_t doc = cdoc[cc], seg = cseg[cc];
+      const bool seg_ok = seg < n_segs;
+      const VecSegDev vd = vsegs[seg_ok ? seg : 0u];
+      const bool doc_ok = c_ok && seg_ok && vd.dim == dim && doc < vd.n_docs;
+      const gword_t optr = doc_ok ? (gword_t)(vd.offsets + doc) : (gword_t)cdoc;  // (any readable word)
+      const uint32_t off = *optr;
+      haveN[u] = doc_ok && off != 0xFFFFFFFFu;
+      rowN[u] = (grow_t)(haveN[u] ? vd.values + (size_t)off * dim : readable);
+    }
+  };
+  resolve(wave * U);
+  for (uint32_t c0 = wave * U; c0 < n; c0 += 4 * U) {
+    bool have[U];
+    fvec4 b[U][CH];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      have[u] = haveN[u];
+#pragma unroll
+      for (int ch = 0; ch < CH; ch++) b[u][ch] = rowN[u][idx[ch] >> 2];
+    }
+    if (c0 + 4 * U < n) resolve(c0 + 4 * U);  // the next group's pointers, under this group's rows
+    for (uint32_t cc = 0; cc < n_cl; cc++) {
+      fvec4 a[CH];
+#pragma unroll
+      for (int ch = 0; ch < CH; ch++) {
+        const fvec4 v = *reinterpret_cast<const fvec4 *>(s_qc + cc * q_stride + idx[ch]);
+        a[ch] = valid[ch] ? v : (fvec4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int ch = 0; ch < CH; ch++) {
+          const fvec4 bb = valid[ch] ? b[u][ch] : a[ch];  // masked lanes: a = 0 and a - a = 0
+          if (metric == 0) {
+            acc += a[ch].x * bb.x;
+            acc += a[ch].y * bb.y;
+            acc += a[ch].z * bb.z;
+            acc += a[ch].w * bb.w;
+          } else {
+            const float d0 = a[ch].x - bb.x, d1 = a[ch].y - bb.y, d2 = a[ch].z - bb.z, d3 = a[ch].w - bb.w;
+            acc += d0 * d0;
+            acc += d1 * d1;
+            acc += d2 * d2;
+            acc += d3 * d3;
+          }
+        }
+        const float sum = wave_sum_f(acc);
+        const uint32_t c = c0 + u;
+        if (lane == 0 && c < n && have[u])
+          s_vs[cc * vs_stride + c] = metric == 0 ? (sum != sum ? 0.0f : sum) : -sqrtf(sum);
+      }
+    }
+    if (s_has && lane == 0) {
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (c0 + u < n && have[u]) s_has[c0 + u] |= has_bits;
+    }
+  }
+}
+
 // One workgroup (4 waves) per query.  dim <= 768 and a multiple of 4: rerank_scan_rows (whole
 // rows, 4 candidates per wave and step).  Other dims: 8 candidates per wave and step, 256 floats
 // of each row at a time.
@@ -485,8 +582,22 @@ __global__ void __launch_bounds__(256) rerank_multi_kernel(RerankMultiParams mp)
         }
       }
     }
+  } else if ((dim & 3u) == 0 && dim <= 768u) {
+    // ---- VALU path (L2, or cosine at dimensions the MFMA tiling does not take): four candidates
+    //      per wave and step with their whole rows in flight, every clause against the rows held ----
+    const float *readable = p.qvecs + (size_t)q * NC * dim;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+    if (dim <= 256u)
+      rerank_scan_clauses<1>(p.vsegs, p.n_segs, dim, metric, s_q, qs, NC, cdoc, cseg, n, readable, s_vs, p.max_cand,
+                             nullptr, 0u, lane, wv);
+    else if (dim <= 512u)
+      rerank_scan_clauses<2>(p.vsegs, p.n_segs, dim, metric, s_q, qs, NC, cdoc, cseg, n, readable, s_vs, p.max_cand,
+                             nullptr, 0u, lane, wv);
+    else
+      rerank_scan_clauses<3>(p.vsegs, p.n_segs, dim, metric, s_q, qs, NC, cdoc, cseg, n, readable, s_vs, p.max_cand,
+                             nullptr, 0u, lane, wv);
   } else {
-    // ---- VALU path: one candidate per wave at a time; its row is read ONCE into registers
+    // ---- other dimensions: one candidate per wave at a time; its row is read ONCE into registers
     //      (dim <= 1024) and every clause runs against it ----
     typedef const __attribute__((address_space(1))) float *gf_t;
     constexpr int RV = 16;
@@ -604,10 +715,34 @@ __global__ void __launch_bounds__(256) rerank_fields_kernel(RerankFieldsParams f
   for (uint32_t i = threadIdx.x; i < fp.q_floats; i += 256) s_q[i] = p.qvecs[(size_t)q * fp.q_floats + i];
   __syncthreads();
 
-  for (uint32_t c = wave; c < n; c += 4) {
+  for (uint32_t c = threadIdx.x; c < n; c += 256) s_has[c] = 0u;
+  __syncthreads();
+  // clause after clause: every clause is a row gather from ITS field's store; where the dimension
+  // allows, with the four-rows-in-flight scan of the single-field kernels
+  uint32_t slow_clauses = 0;
+  for (uint32_t cc = 0; cc < NC; cc++) {
+    const uint32_t dim = fp.cdim[cc];
+    if ((dim & 3u) != 0 || dim > 768u || (fp.coff[cc] & 3u) != 0) {
+      slow_clauses |= 1u << cc;
+      continue;
+    }
+    const float *readable = p.qvecs + (size_t)q * fp.q_floats + fp.coff[cc];
+    if (dim <= 256u)
+      rerank_scan_clauses<1>(fp.cvsegs[cc], p.n_segs, dim, fp.cmetric[cc], s_q + fp.coff[cc], 0u, 1u, cdoc, cseg, n,
+                             readable, s_vs + cc * p.max_cand, p.max_cand, s_has, 1u << cc, lane, wave);
+    else if (dim <= 512u)
+      rerank_scan_clauses<2>(fp.cvsegs[cc], p.n_segs, dim, fp.cmetric[cc], s_q + fp.coff[cc], 0u, 1u, cdoc, cseg, n,
+                             readable, s_vs + cc * p.max_cand, p.max_cand, s_has, 1u << cc, lane, wave);
+    else
+      rerank_scan_clauses<3>(fp.cvsegs[cc], p.n_segs, dim, fp.cmetric[cc], s_q + fp.coff[cc], 0u, 1u, cdoc, cseg, n,
+                             readable, s_vs + cc * p.max_cand, p.max_cand, s_has, 1u << cc, lane, wave);
+  }
+  __syncthreads();  // (the two loops spread the candidates over the waves differently: s_has is shared)
+  for (uint32_t c = wave; slow_clauses != 0u && c < n; c += 4) {
     const uint32_t doc = cdoc[c], seg = cseg[c];
     uint32_t has = 0;
     for (uint32_t cc = 0; cc < NC; cc++) {
+      if (!((slow_clauses >> cc) & 1u)) continue;
       const uint32_t dim = fp.cdim[cc];
       const int32_t metric = fp.cmetric[cc];
       const float *row = nullptr;
@@ -634,7 +769,7 @@ __global__ void __launch_bounds__(256) rerank_fields_kernel(RerankFieldsParams f
       if (lane == 0) s_vs[cc * p.max_cand + c] = metric == 0 ? (sum != sum ? 0.0f : sum) : -sqrtf(sum);
       has |= 1u << cc;
     }
-    if (lane == 0) s_has[c] = has;
+    if (lane == 0) s_has[c] |= has;
   }
   __syncthreads();
   // ---- compute_hybrid_score (api/reader.rs:225-254) per candidate, clauses in order ----

@@ -1,0 +1,223 @@
+// host_harness.cpp — bench harness: the caller threads of bench.py's host-inclusive leg, native.
+//
+// searchlite serves one request per OS thread (searchlite-http/src/lib.rs:640-643, spawn_blocking);
+// its host language is Rust, i.e. threads without an interpreter lock.  bench.py's Python threads
+// share the GIL, which made the host-inclusive rate a measurement of Python's thread hand-offs
+// (a 20-step region is 2.5 steps per thread).  This file is the same loop as a C++ caller of the
+// C ABI: persistent threads, each keeping TWO batches going on two HIP streams of its own —
+// slg_batch_prepare (plan + H2D) -> slg_batch_set_stream -> slg_batch_run, then slg_batch_fetch
+// (D2H into host arrays) + slg_batch_destroy of the batch launched before.  Harness only: built as
+// lib/libslg_harness.so, linked against libsearchlite_gpu.so, never part of the product library.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/searchlite_gpu.h"
+
+namespace {
+
+struct QuerySet {
+  const uint32_t *offs, *terms;
+  const float *w;
+};
+
+struct Worker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<int64_t> todo;  // step numbers; -1 = flush, -2 = quit
+  hipStream_t streams[2] = {nullptr, nullptr};
+};
+
+struct Harness {
+  slg_index *ix = nullptr;
+  int device = 0;
+  uint32_t nq = 0, k = 0;
+  int strategy = 0;
+  std::vector<QuerySet> sets;
+  std::vector<Worker *> workers;
+  std::mutex done_mu;
+  std::condition_variable done_cv;
+  int64_t done = 0;
+  std::string error;
+  // results of the first batch of every query set (bench.py compares them with the other legs)
+  std::vector<std::vector<uint32_t>> first_doc, first_seg, first_count;
+  std::vector<std::vector<float>> first_score;
+  std::vector<char> have_first;
+};
+
+struct Pending {
+  slg_batch *b = nullptr;
+  int64_t step = -1;
+};
+
+void collect(Harness *h, Pending &p, std::vector<uint32_t> &doc, std::vector<uint32_t> &seg,
+             std::vector<float> &score, std::vector<uint32_t> &count) {
+  if (!p.b) return;
+  const int rc = slg_batch_fetch(p.b, doc.data(), seg.data(), score.data(), count.data(), nullptr);
+  slg_batch_destroy(p.b);
+  const size_t set = (size_t)(p.step % (int64_t)h->sets.size());
+  {
+    std::lock_guard<std::mutex> lk(h->done_mu);
+    if (rc != SLG_OK && h->error.empty()) h->error = std::string("slg_batch_fetch: ") + slg_last_error();
+    if (rc == SLG_OK && !h->have_first[set]) {
+      h->first_doc[set] = doc;
+      h->first_seg[set] = seg;
+      h->first_score[set] = score;
+      h->first_count[set] = count;
+      h->have_first[set] = 1;
+    }
+    h->done++;
+  }
+  h->done_cv.notify_all();
+  p.b = nullptr;
+}
+
+void worker_main(Harness *h, Worker *w) {
+  (void)hipSetDevice(h->device);
+  const size_t n = (size_t)h->nq * h->k;
+  std::vector<uint32_t> doc(n ? n : 1), seg(n ? n : 1), count(h->nq ? h->nq : 1);
+  std::vector<float> score(n ? n : 1);
+  Pending prev;
+  uint64_t lap = 0;
+  for (;;) {
+    int64_t step;
+    {
+      std::unique_lock<std::mutex> lk(w->mu);
+      w->cv.wait(lk, [&] { return !w->todo.empty(); });
+      step = w->todo.front();
+      w->todo.pop_front();
+    }
+    if (step == -2) {
+      collect(h, prev, doc, seg, score, count);
+      return;
+    }
+    if (step == -1) {
+      collect(h, prev, doc, seg, score, count);
+      continue;
+    }
+    const QuerySet &qs = h->sets[(size_t)(step % (int64_t)h->sets.size())];
+    slg_batch *b = slg_batch_prepare(h->ix, h->nq, qs.offs, qs.terms, qs.w, h->k, h->strategy);
+    int rc = b ? SLG_OK : slg_last_error_code();
+    if (b) rc = slg_batch_set_stream(b, (void *)w->streams[lap++ & 1u]);
+    if (b && rc == SLG_OK) rc = slg_batch_run(b);
+    if (rc != SLG_OK) {
+      std::lock_guard<std::mutex> lk(h->done_mu);
+      if (h->error.empty()) h->error = std::string("prepare/run: ") + slg_last_error();
+    }
+    collect(h, prev, doc, seg, score, count);  // the batch launched one lap ago
+    if (b && rc == SLG_OK) {
+      prev.b = b;
+      prev.step = step;
+    } else {
+      if (b) slg_batch_destroy(b);
+      std::lock_guard<std::mutex> lk(h->done_mu);
+      h->done++;
+      h->done_cv.notify_all();
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// q_offsets / q_terms / q_weights: n_sets pointers to query arrays that stay valid for the harness' life
+void *slh_create(slg_index *ix, int device, int n_threads, int n_sets, const uint32_t *const *q_offsets,
+                 const uint32_t *const *q_terms, const float *const *q_weights, uint32_t nq, uint32_t k,
+                 int strategy) {
+  auto *h = new Harness();
+  h->ix = ix;
+  h->device = device;
+  h->nq = nq;
+  h->k = k;
+  h->strategy = strategy;
+  for (int s = 0; s < n_sets; s++) h->sets.push_back(QuerySet{q_offsets[s], q_terms[s], q_weights[s]});
+  h->first_doc.resize(n_sets);
+  h->first_seg.resize(n_sets);
+  h->first_score.resize(n_sets);
+  h->first_count.resize(n_sets);
+  h->have_first.assign(n_sets, 0);
+  (void)hipSetDevice(device);
+  for (int t = 0; t < n_threads; t++) {
+    auto *w = new Worker();
+    for (auto &st : w->streams) (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    h->workers.push_back(w);
+  }
+  for (auto *w : h->workers) w->th = std::thread(worker_main, h, w);
+  return h;
+}
+
+// Runs steps [first, first + n_steps), round-robin over the threads, and returns when every one of
+// them has been fetched.  0 on success, -1 on error (slh_error).
+int slh_run(void *hp, int64_t first, int64_t n_steps) {
+  auto *h = static_cast<Harness *>(hp);
+  int64_t target;
+  {
+    std::lock_guard<std::mutex> lk(h->done_mu);
+    target = h->done + n_steps;
+  }
+  const size_t nt = h->workers.size();
+  for (int64_t i = first; i < first + n_steps; i++) {
+    Worker *w = h->workers[(size_t)(i % (int64_t)nt)];
+    {
+      std::lock_guard<std::mutex> lk(w->mu);
+      w->todo.push_back(i);
+    }
+    w->cv.notify_one();
+  }
+  for (auto *w : h->workers) {
+    {
+      std::lock_guard<std::mutex> lk(w->mu);
+      w->todo.push_back(-1);
+    }
+    w->cv.notify_one();
+  }
+  std::unique_lock<std::mutex> lk(h->done_mu);
+  h->done_cv.wait(lk, [&] { return h->done >= target; });
+  return h->error.empty() ? 0 : -1;
+}
+
+const char *slh_error(void *hp) { return static_cast<Harness *>(hp)->error.c_str(); }
+
+// the results of the first batch of query set `set`; returns 1 if one was run
+int slh_first_result(void *hp, int set, uint32_t *doc, uint32_t *seg, float *score, uint32_t *count) {
+  auto *h = static_cast<Harness *>(hp);
+  std::lock_guard<std::mutex> lk(h->done_mu);
+  if (set < 0 || (size_t)set >= h->sets.size() || !h->have_first[set]) return 0;
+  const size_t n = (size_t)h->nq * h->k;
+  std::memcpy(doc, h->first_doc[set].data(), n * 4);
+  std::memcpy(seg, h->first_seg[set].data(), n * 4);
+  std::memcpy(score, h->first_score[set].data(), n * 4);
+  std::memcpy(count, h->first_count[set].data(), (size_t)h->nq * 4);
+  return 1;
+}
+
+void slh_destroy(void *hp) {
+  auto *h = static_cast<Harness *>(hp);
+  for (auto *w : h->workers) {
+    {
+      std::lock_guard<std::mutex> lk(w->mu);
+      w->todo.push_back(-2);
+    }
+    w->cv.notify_one();
+  }
+  for (auto *w : h->workers) {
+    w->th.join();
+    (void)hipSetDevice(h->device);
+    for (auto st : w->streams)
+      if (st) (void)hipStreamDestroy(st);
+    delete w;
+  }
+  delete h;
+}
+
+}  // extern "C"

@@ -48,4 +48,32 @@ for metric in ((0, 1) if len(sys.argv) <= 2 else (metric,)):
         ms = a.elapsed_time(b) / 5
         gb = nq * ncand * dim * 4 / 1e9
         print(f"clauses {nc}: {ms:.3f} ms, row bytes {gb:.2f} GB -> {gb / ms:.2f} TB/s", flush=True)
+    # clauses over DIFFERENT vector fields (rerank_fields_kernel): field 0 = the segment's own store,
+    # field 1 = a second 384-d store of the other metric; 2 and 4 clauses alternating between them
+    d2 = 384
+    vals2 = corpus.unit_vectors(n_docs, d2, seed=31)
+    f1 = ix.add_vector_field([(1 - metric, np.arange(n_docs, dtype=np.uint32), vals2)])
+    for nc in (2, 4):
+        fields = np.array([0, f1] * (nc // 2), dtype=np.uint32)
+        dims = [dim if f == 0 else d2 for f in fields]
+        qv = torch.from_numpy(np.concatenate([corpus.unit_vectors(nq, d, seed=40 + i) for i, d in enumerate(dims)],
+                                             axis=1)).cuda()
+        al = torch.full((nq, nc), 0.5, dtype=torch.float32, device="cuda")
+        def run_f():
+            N.check(L.slg_rerank_fields_batch_device(ix._h, nq, nc, fields.ctypes.data, qv.data_ptr(), al.data_ptr(), None,
+                                                     cd.data_ptr(), cs.data_ptr(), cb.data_ptr(), cc.data_ptr(), ncand, k_out,
+                                                     od.data_ptr(), os_.data_ptr(), osc.data_ptr(), ov.data_ptr(), oc.data_ptr()))
+        for _ in range(2):
+            run_f()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(5):
+            run_f()
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 5
+        gb = nq * ncand * sum(dims) * 4 / 1e9
+        print(f"fields kernel, {nc} clauses over 2 fields ({dim}-d + {d2}-d): {ms:.3f} ms, row bytes {gb:.2f} GB -> {gb / ms:.2f} TB/s", flush=True)
+    del vals2
     ix.close()
