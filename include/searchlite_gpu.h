@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SLG_ABI_VERSION 1u
+#define SLG_ABI_VERSION 2u  /* 2: slg_tuning grew (pool_cap_mb, uniform_kernel, uniform_sigma_x100); shard groups; slg_batch_prepare_plans */
 #define SLG_NO_TERM 0xFFFFFFFFu      /* term absent from a segment (api/reader.rs:2989) */
 #define SLG_NO_VECTOR 0xFFFFFFFFu    /* vectors/mod.rs:65-67 (u32::MAX offset) */
 #define SLG_MAX_QUERY_TERMS 32u      /* scored terms per query per segment */
@@ -178,6 +178,8 @@ typedef struct {
                                     device allocation of the library fails (slg_index_trim_pool) */
   uint32_t uniform_kernel;       /* SLG_UNIFORM_KERNEL (3): form of the few-term scoring kernel; 2 = the
                                     round-2 kernel (kept for A/B timing on one device) */
+  uint32_t uniform_sigma_x100;   /* SLG_UNIFORM_SIGMA (0 = 160): the few-term planner keeps a round's
+                                    expected slots + this many hundredths of a sigma under 8.3 */
 } slg_tuning;
 void slg_tuning_default(slg_tuning *out);
 slg_index *slg_index_create_tuned(const slg_segment_desc *segs, uint32_t n_segs, int device,

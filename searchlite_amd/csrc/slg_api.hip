@@ -628,6 +628,7 @@ void slg_tuning_default(slg_tuning *t) {
   t->block_max = env_i32("SLG_NO_BLOCK_MAX", 0) == 0;
   t->pool_cap_mb = env_u32("SLG_POOL_CAP_MB", 0);
   t->uniform_kernel = env_u32("SLG_UNIFORM_KERNEL", 3);
+  t->uniform_sigma_x100 = env_u32("SLG_UNIFORM_SIGMA", 0);
 }
 
 slg_index *slg_index_create(const slg_segment_desc *segs, uint32_t n_segs, int device) {

@@ -311,6 +311,7 @@ uint32_t uniform_round_target(const slg::RoundQuery &sq, const slg::TermRef *t, 
   uint32_t dflt = 64u * (slg::kUniSlots > (int)n ? slg::kUniSlots - n : 0u) + 64u;
   if (!tn.uniform_round_target && n > 1) {
     const double Pd = (double)P;
+    const double sigmas = tn.uniform_sigma_x100 ? tn.uniform_sigma_x100 / 100.0 : 1.6;
     uint32_t best = 64;
     for (uint32_t R = 96; R <= (uint32_t)slg::kUniCap; R += 16) {
       double mu = 0.0, var = 0.0;
@@ -323,8 +324,9 @@ uint32_t uniform_round_target(const slg::RoundQuery &sq, const slg::TermRef *t, 
           var += c / 4096.0 + 1.0 / 12.0;
         }
       }
-      if (mu + 1.6 * std::sqrt(var) > 8.3) break;  // (1.0 / 1.3 / 1.6 / 2.0 / 2.5 sigma: 0.1024 / 0.1011 /
-                                                   //  0.1006 / 0.1019 / 0.1039 ms on config 2; fixed 384: 0.1042)
+      // (round-2 kernel, 1.0 / 1.3 / 1.6 / 2.0 / 2.5 sigma: 0.1024 / 0.1011 / 0.1006 / 0.1019 / 0.1039 ms on
+      //  config 2; fixed 384: 0.1042)
+      if (mu + sigmas * std::sqrt(var) > 8.3) break;
       best = R;
     }
     dflt = best;

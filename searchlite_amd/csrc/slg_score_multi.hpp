@@ -86,6 +86,7 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
   const SegDev sd = p.segs[s.seg];
   const gu32_t gdocs = (gu32_t)sd.docs;
   const gf32_t gimps = (gf32_t)sd.imps;
+  const uint64_t null_idx = sd.null_idx;
   const uint32_t fid = rfl(s.filter);
   const gu32_t gdel = (gu32_t)(fid ? p.reject_table[(size_t)(fid - 1) * p.n_segs + s.seg] : sd.deleted);
   const uint32_t k = p.k;
@@ -159,10 +160,12 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
       nimp[jj] = gimps[base + lane];
     }
   };
-  auto take_batch = [&](const uint32_t b, const uint32_t cnt, const uint32_t dhi) {
+  auto take_batch = [&](const uint32_t b, const uint32_t dhi) {
 #pragma unroll
     for (int jj = 0; jj < NS; jj++) {  // lanes past the slot's count / docs past the cut: idle
-      const bool live = lane < rl(cnt, b * 8u + jj) && ndoc[jj] < dhi;
+      // (no lane count: the arrays are padded per list, so lanes past the slot's postings hold
+      //  later postings of the same list — doc >= the cut — or sentinels; unused slots load sentinels)
+      const bool live = ndoc[jj] < dhi;
       doc[jj] = live ? ndoc[jj] : kDocEnd;
       imp[jj] = nimp[jj];
     }
@@ -186,7 +189,7 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
     const uint32_t kin = (lane - l_gs) * 64u;
     const bool used = lane < S;
     const uint32_t left = used && l_c > kin ? l_c - kin : 0u;
-    const uint64_t base = used ? l_abs + kin : 0ull;
+    const uint64_t base = used ? l_abs + kin : null_idx;  // unused slot: a run of sentinels
     st = tG;
     cnt = left < 64u ? left : 64u;
     lo = (uint32_t)base;
@@ -312,7 +315,7 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
         auto set_bits = [&](const uint32_t (&src)[NS], const uint32_t bb) {
 #pragma unroll
           for (int jj = 0; jj < NS; jj++) {
-            const bool live = lane < rl(a_cnt, bb * 8u + jj) && src[jj] < dhi;
+            const bool live = src[jj] < dhi;
             const uint32_t rel = src[jj] - wbase;
             if (live && rel < wspan) atomicOr(&bm[rel >> 5], 1u << (rel & 31u));
           }
@@ -454,7 +457,11 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
           d_st = (uint32_t)__builtin_amdgcn_ds_permute((int)(pos * 4u), (int)d_st);
           d_lo = (uint32_t)__builtin_amdgcn_ds_permute((int)(pos * 4u), (int)d_lo);
           d_hi = (uint32_t)__builtin_amdgcn_ds_permute((int)(pos * 4u), (int)d_hi);
-          if (kept < 64u && lane >= kept) d_cnt = 0u;  // (lane 63 may hold a dropped slot's leftovers)
+          if (kept < 64u && lane >= kept) {  // (lane 63 may hold a dropped slot's leftovers)
+            d_cnt = 0u;
+            d_lo = (uint32_t)null_idx;
+            d_hi = (uint32_t)(null_idx >> 32);
+          }
           nb = (kept + 7u) >> 3;
           if (!first8_same && nb != 0u) issue_batch(0, d_lo, d_hi);  // batch 0 changed: load it again
         }
@@ -462,7 +469,7 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
       SLG_STAMP(3);
       // ---- sweep C: rank every posting, accumulate slot by slot (= in list order) ----
       for (uint32_t b = 0; b < nb; b++) {
-        take_batch(b, d_cnt, dhi);
+        take_batch(b, dhi);
         if (b + 1 < nb) issue_batch(b + 1, d_lo, d_hi);
         uint32_t rank[NS];
         bool in[NS];

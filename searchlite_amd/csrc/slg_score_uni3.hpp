@@ -251,8 +251,10 @@ score_uniform3_kernel(RoundScoreParams p) {
       wave_fence();
       // P1: one bit per posting: word = doc mod 1024, field = (doc / 1024) mod 8, bit = list
 #pragma unroll
-      for (int jj = 0; jj < NS; jj++)
-        atomicOr(&flt[e.doc[jj] & (kJoinWords - 1)], ((lbits >> (4 * jj)) & 0xFu) << ((e.doc[jj] >> 8) & 0x1Cu));
+      for (int jj = 0; jj < NS; jj++) {
+        const uint32_t lb = (lbits >> (4 * jj)) & 0xFu;
+        atomicOr(&flt[e.doc[jj] & (kJoinWords - 1)], lb << ((e.doc[jj] >> 8) & 0x1Cu));
+      }
       wave_fence();
       SLG_STAMP(2);
       // P2: the lists that hold my doc (or an alias of it)

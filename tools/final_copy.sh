@@ -1,7 +1,7 @@
 #!/bin/bash
 # Files what tools/final_run.sh produced (merged back into gpurun_out/) under profiles/.
 # usage: bash tools/final_copy.sh <round tag>
-TAG=${1:-r02}
+TAG=${1:-r03}
 G=gpurun_out
 for c in c2 c3 c4 c5; do tail -1 $G/final/bench_$c.json > profiles/${TAG}_bench_$c.json; done
 tail -1 $G/final/bench_c2_steps20.json > profiles/${TAG}_bench_c2_steps20.json

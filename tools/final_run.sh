@@ -3,12 +3,12 @@
 # every config and the rocprofv3 passes of configs 2 and 3.  Everything lands under gpurun_out/final/;
 # tools/final_copy.sh files it under profiles/.   usage: bash tools/final_run.sh <round tag, e.g. r02>
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/final
 rm -rf $OUT && mkdir -p $OUT
 cd $REPO
-timeout -k 10 900 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1 || { tail -20 $OUT/pytest_gpu.log; exit 1; }
+timeout -k 10 1000 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1 || { tail -20 $OUT/pytest_gpu.log; exit 1; }
 tail -2 $OUT/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1 || { tail -20 $OUT/smoke.log; exit 1; }
 tail -1 $OUT/smoke.log
