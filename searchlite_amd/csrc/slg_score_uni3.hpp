@@ -239,6 +239,15 @@ score_uniform3_kernel(RoundScoreParams p) {
   //      the others (later postings of the same lists, sentinels) only ever add filter bits.
   //      lbits: the list bit of every slot, 4 bits each (uniform) ----
   auto accumulate = [&](const URound &e, const uint32_t end, const uint32_t lbits) {
+#ifdef SLG_U3_LOADS_ONLY  // diagnostic build: what the load stream alone costs (results are wrong)
+    {
+      uint32_t chk = 0;
+#pragma unroll
+      for (int jj = 0; jj < NS; jj++) chk ^= e.doc[jj] ^ __float_as_uint(e.sc[jj]);
+      if (chk == 0x12345678u && end == 7u && lbits == 9u) n_scored++;
+      return;
+    }
+#endif
     SLG_STAMP(1);
     uint32_t x[NS];
     uint32_t accx = hot_all ? 1u : 0u;
