@@ -509,7 +509,7 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_measured_in_run": False,
                          "kernel": ("score_uniform3_kernel" if os.environ.get("SLG_UNIFORM_KERNEL", "3") != "2"
-                                    else "score_uniform_kernel") if T <= 4 else "score_multi_kernel",
+                                    else "score_uniform_kernel") if T <= int(os.environ.get("SLG_UNIFORM_MAX_TERMS", "4")) else "score_multi_kernel",
                          "kernel_ms": round(kern_avg_ms, 4), "launches": n_launch,
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "exhaustive_bytes_per_launch": int(exhaustive_bytes),

@@ -54,7 +54,7 @@ def build_gpu(force: bool = False, verbose: bool = False, stamps: bool = False, 
     objdir = os.path.join(LIBDIR, f"obj_{tag}" if tag else "obj")
     out_lib = os.path.join(LIBDIR, f"libsearchlite_gpu_{tag}.so") if tag else GPU_LIB
     os.makedirs(objdir, exist_ok=True)
-    hdrs = [os.path.join(CSRC, h) for h in ("slg_desc.hpp", "slg_kernels.hpp", "slg_rerank.hpp", "slg_score.hpp", "slg_score_uni.hpp", "slg_score_uni3.hpp",
+    hdrs = [os.path.join(CSRC, h) for h in ("slg_desc.hpp", "slg_kernels.hpp", "slg_rerank.hpp", "slg_score.hpp", "slg_score_uni.hpp", "slg_score_uni3.hpp", "slg_score_uni4.hpp",
                                            "slg_score_multi.hpp", "slg_plan.hpp")]
     hdrs.append(os.path.join(_HERE, "..", "include", "searchlite_gpu.h"))
     compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"] + (["-DSLG_STAMPS"] if stamps else []) \

@@ -372,8 +372,15 @@ template <> void launch_score_kregs<16>(const RoundScoreParams &, int, hipStream
 }  // namespace slg
 namespace {
 
-// kind: 1 few-term kernel (slg_score_uni3.hpp), 2 many-term kernel (slg_score_multi.hpp),
+// kind: 1 few-term kernel (slg_score_uni3.hpp; 5: its 5..8-list form), 2 many-term kernel (slg_score_multi.hpp),
 // 3 many-term kernel with pruning-classified lists, 4 the round-2 few-term kernel (slg_score_uni.hpp)
+// 6 / 7: the few-term kernel in its blocked form (slg_score_uni4.hpp), <= 4 / 5..8 lists
+int uniform_kind(uint32_t form, uint32_t max_terms) {
+  const bool few = max_terms <= (uint32_t)slg::kUniMaxLists;
+  if (form == 2) return 4;
+  if (form == 3) return few ? 1 : 5;
+  return few ? 6 : 7;
+}
 void launch_score(const slg::RoundScoreParams &sp, int kind, hipStream_t st) {
 #ifdef SLG_STAMPS  // diagnostic build: only the k <= 64 variant is compiled
   if (kregs_for(sp.k) != 1) throw SlgError(SLG_ERR_UNSUPPORTED, "stamps build supports k <= 64 only");
@@ -478,9 +485,9 @@ void stage_segment(slg_index *ix, SegHost &sh, const slg_segment_desc &d) {
   const uint64_t P = sh.term_offsets[d.n_terms];
   sh.n_postings = P;
 
-  // padded layout (SegDev): every list is followed by kListPad sentinel entries, + one more run at
-  // the end (null_idx): the scoring kernels load whole 64-lane slots starting at any posting
-  const uint64_t P_pad = P + (uint64_t)slg::kListPad * ((uint64_t)d.n_terms + 1);
+  // padded layout (SegDev): every list is followed by kListPad sentinel entries, + a run of kNullRun
+  // at the end (null_idx): the scoring kernels load whole 64-lane slots starting at any posting
+  const uint64_t P_pad = P + (uint64_t)slg::kListPad * (uint64_t)d.n_terms + (uint64_t)slg::kNullRun;
   sh.null_idx = P + (uint64_t)slg::kListPad * d.n_terms;
   sh.d_docs.alloc(P_pad * 4, &ix->pool);
   sh.d_imps.alloc(P_pad * 4, &ix->pool);
@@ -627,7 +634,7 @@ void slg_tuning_default(slg_tuning *t) {
   t->slice_order = env_i32("SLG_NO_SLICE_ORDER", 0) == 0;
   t->block_max = env_i32("SLG_NO_BLOCK_MAX", 0) == 0;
   t->pool_cap_mb = env_u32("SLG_POOL_CAP_MB", 0);
-  t->uniform_kernel = env_u32("SLG_UNIFORM_KERNEL", 3);
+  t->uniform_kernel = env_u32("SLG_UNIFORM_KERNEL", 4);
   t->uniform_sigma_x100 = env_u32("SLG_UNIFORM_SIGMA", 0);
 }
 
@@ -647,7 +654,8 @@ slg_index *slg_index_create_tuned(const slg_segment_desc *segs, uint32_t n_segs,
     } else {
       slg_tuning_default(&tune);
     }
-    tune.uniform_max_terms = std::min<uint32_t>(tune.uniform_max_terms, slg::kUniMaxLists);
+    tune.uniform_max_terms = std::min<uint32_t>(
+        tune.uniform_max_terms, tune.uniform_kernel == 2 ? slg::kUniMaxLists : slg::kU3MaxLists);
     tune.max_rounds_per_slice = std::min<uint32_t>(tune.max_rounds_per_slice, slg::kMaxRoundsPerSlice);
     tune.slices_per_subquery = std::max<uint32_t>(1, tune.slices_per_subquery);
     for (uint32_t s = 0; s < n_segs; s++) validate_segment(segs[s], s, tune.validate != 0);
@@ -1121,7 +1129,10 @@ int slg_batch_run(slg_batch *b) {
         ev = &ix->prof_events[ix->prof_used++];
         SLG_HIP(hipEventRecord(ev->first, st));
       }
-      launch_score(sp, b->uniform ? (ix->tune.uniform_kernel == 2 ? 4 : 1) : (b->pruned ? 3 : 2), st);
+      launch_score(sp,
+                   b->uniform ? uniform_kind(ix->tune.uniform_kernel, b->max_terms)
+                              : (b->pruned ? 3 : 2),
+                   st);
       if (ev) SLG_HIP(hipEventRecord(ev->second, st));
     }
     if (b->k > 0 && b->cand_mode && b->n_slices > 0) {

@@ -37,14 +37,15 @@ SLG_HD inline int champ_index(uint32_t k) {
 // end).  The scoring kernels therefore need no per-slot lane count to tell real postings from
 // foreign ones.  null_idx = a 64-entry run of sentinels (the slot unused descriptor lanes load).
 constexpr uint32_t kListPad = 64;
+constexpr uint32_t kNullRun = 576;  // sentinels at null_idx: a whole round of idle lanes (64 x 8) + a slot
 struct SegDev {
-  const uint32_t *docs;     // [P + kListPad * (V + 1)] doc ids
+  const uint32_t *docs;     // [P + kListPad * V + kNullRun] doc ids
   const float *imps;        // same layout: precomputed bm25 (weight == 1) per posting
   const uint32_t *deleted;  // bitmap words or nullptr
   const float *champ;       // [V * kChampions] per-term descending impact lower bounds
   uint32_t n_docs;
   uint32_t pad;
-  uint64_t null_idx;        // index of kListPad sentinel entries
+  uint64_t null_idx;        // index of kNullRun sentinel entries
 };
 
 struct TermRef {  // one scored term of one sub-query
@@ -115,7 +116,9 @@ constexpr int kSpanWords = 512;           // bitmap words per window (many-term 
 constexpr uint32_t kSpan = kSpanWords * 32;  // docs per window
 constexpr int kUniSlots = 8;                 // 64-posting slots per round
 constexpr int kUniCap = kUniSlots * 64;      // postings per round
-constexpr int kUniMaxLists = 4;              // lists per sub-query on the few-term kernel
+constexpr int kUniMaxLists = 4;              // lists per sub-query on the round-2 few-term kernel and
+                                             // on the 4-bit-field form of the current one
+constexpr int kU3MaxLists = 8;               // lists per sub-query on the few-term kernel (8-bit fields)
 constexpr int kMultiCap = 512;       // accumulators (= distinct docs) per chunk
 constexpr int kMultiTarget = 448;    // planned postings per round (host; measured optimum 448-480)
 

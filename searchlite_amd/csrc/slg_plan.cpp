@@ -300,36 +300,61 @@ void plan_queries(const Pass1Ctx &c, const uint32_t q_lo, const uint32_t q_hi, P
 }
 
 // ---- pass 2: rounds of about one register set of postings, slices of consecutive rounds ----------
-// postings per round of a few-term sub-query.  Every list is padded to a 64-lane slot (half a slot
-// wasted per list on average).  A round that needs more than 8 slots is streamed in chunks at 2-3x
+// postings per round of a few-term sub-query.  Slot forms of the kernel (slg_score_uni.hpp, _uni3):
+// every list is padded to a 64-lane slot (half a slot wasted per list on average).  A round that needs more than 8 slots is streamed in chunks at 2-3x
 // the cost, so the target follows the sub-query's own mix of list lengths: the largest R (steps of
 // 16) whose expected slots stay under 8 with 1.6 sigma to spare.  The longest list is cut at exact
 // strides (its count is R * f); every other list's count c is roughly Poisson around R * f:
 // ceil(c / 64) has mean c/64 + 1/2 and variance c/4096 + 1/12.
 uint32_t uniform_round_target(const slg::RoundQuery &sq, const slg::TermRef *t, uint64_t P, const slg_tuning &tn) {
   const uint32_t n = sq.n_terms;
-  uint32_t dflt = 64u * (slg::kUniSlots > (int)n ? slg::kUniSlots - n : 0u) + 64u;
-  if (!tn.uniform_round_target && n > 1) {
-    const double Pd = (double)P;
-    const double sigmas = tn.uniform_sigma_x100 ? tn.uniform_sigma_x100 / 100.0 : 1.6;
-    uint32_t best = 64;
-    for (uint32_t R = 96; R <= (uint32_t)slg::kUniCap; R += 16) {
-      double mu = 0.0, var = 0.0;
-      for (uint32_t j = 0; j < n; j++) {
-        const double c = (double)R * (double)t[j].df / Pd;
-        if (j == sq.longest) {
-          mu += std::ceil(c / 64.0);
-        } else {
-          mu += c / 64.0 + 0.5;
-          var += c / 4096.0 + 1.0 / 12.0;
+  const double Pd = (double)P;
+  const double sigmas = tn.uniform_sigma_x100 ? tn.uniform_sigma_x100 / 100.0 : 1.6;
+  uint32_t dflt;
+  if (tn.uniform_kernel >= 4) {
+    // blocked layout (slg_score_uni4.hpp): a list is padded to whole lanes of 8 postings, a round
+    // has 64 lanes.  ceil(c / 8) has mean c/8 + 7/16 and variance c/64 + 1/12 (c roughly Poisson)
+    dflt = (uint32_t)slg::kUniCap;
+    if (!tn.uniform_round_target && n > 1) {
+      uint32_t best = 64;
+      for (uint32_t R = 96; R <= (uint32_t)slg::kUniCap; R += 8) {
+        double mu = 0.0, var = 0.0;
+        for (uint32_t j = 0; j < n; j++) {
+          const double c = (double)R * (double)t[j].df / Pd;
+          if (j == sq.longest) {
+            mu += std::ceil(c / 8.0);
+          } else {
+            mu += c / 8.0 + 7.0 / 16.0;
+            var += c / 64.0 + 1.0 / 12.0;
+          }
         }
+        if (mu + sigmas * std::sqrt(var) > 64.3) break;
+        best = R;
       }
-      // (round-2 kernel, 1.0 / 1.3 / 1.6 / 2.0 / 2.5 sigma: 0.1024 / 0.1011 / 0.1006 / 0.1019 / 0.1039 ms on
-      //  config 2; fixed 384: 0.1042)
-      if (mu + sigmas * std::sqrt(var) > 8.3) break;
-      best = R;
+      dflt = best;
     }
-    dflt = best;
+  } else {
+    dflt = 64u * (slg::kUniSlots > (int)n ? slg::kUniSlots - n : 0u) + 64u;
+    if (!tn.uniform_round_target && n > 1) {
+      uint32_t best = 64;
+      for (uint32_t R = 96; R <= (uint32_t)slg::kUniCap; R += 16) {
+        double mu = 0.0, var = 0.0;
+        for (uint32_t j = 0; j < n; j++) {
+          const double c = (double)R * (double)t[j].df / Pd;
+          if (j == sq.longest) {
+            mu += std::ceil(c / 64.0);
+          } else {
+            mu += c / 64.0 + 0.5;
+            var += c / 4096.0 + 1.0 / 12.0;
+          }
+        }
+        // (round-2 kernel, 1.0 / 1.3 / 1.6 / 2.0 / 2.5 sigma: 0.1024 / 0.1011 / 0.1006 / 0.1019 / 0.1039 ms on
+        //  config 2; fixed 384: 0.1042)
+        if (mu + sigmas * std::sqrt(var) > 8.3) break;
+        best = R;
+      }
+      dflt = best;
+    }
   }
   return std::max<uint32_t>(48, std::min<uint32_t>(tn.uniform_round_target ? tn.uniform_round_target : dflt,
                                                    (uint32_t)slg::kUniCap));

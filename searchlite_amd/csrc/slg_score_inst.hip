@@ -6,6 +6,7 @@
 #include "slg_score.hpp"
 #include "slg_score_uni.hpp"
 #include "slg_score_uni3.hpp"
+#include "slg_score_uni4.hpp"
 #include "slg_score_multi.hpp"
 
 #ifndef SLG_INST_KREGS
@@ -22,8 +23,22 @@ void launch_score_kregs(const RoundScoreParams &sp, int kind, hipStream_t st);
 template <>
 void launch_score_kregs<SLG_INST_KREGS>(const RoundScoreParams &sp, int kind, hipStream_t st) {
   if (kind == 1) {  // <= 4 lists (slg_score_uni3.hpp)
-    hipLaunchKernelGGL((score_uniform3_kernel<SLG_INST_KREGS>), dim3(sp.n_slices), dim3(64),
-                       u3_wave_lds(SLG_INST_KREGS), st, sp);
+    hipLaunchKernelGGL((score_uniform3_kernel<SLG_INST_KREGS, 4>), dim3(sp.n_slices), dim3(64),
+                       u3_wave_lds(SLG_INST_KREGS, 4), st, sp);
+    return;
+  }
+  if (kind == 5) {  // 5..8 lists: the same kernel with 8 list bits per filter field
+    hipLaunchKernelGGL((score_uniform3_kernel<SLG_INST_KREGS, 8>), dim3(sp.n_slices), dim3(64),
+                       u3_wave_lds(SLG_INST_KREGS, 8), st, sp);
+    return;
+  }
+  if (kind == 6 || kind == 7) {  // <= 4 / 5..8 lists, blocked layout (slg_score_uni4.hpp)
+    if (kind == 6)
+      hipLaunchKernelGGL((score_uniform4_kernel<SLG_INST_KREGS, 4>), dim3(sp.n_slices), dim3(64),
+                         u4_wave_lds(SLG_INST_KREGS, 4, u4_filter_words(4)), st, sp);
+    else
+      hipLaunchKernelGGL((score_uniform4_kernel<SLG_INST_KREGS, 8>), dim3(sp.n_slices), dim3(64),
+                         u4_wave_lds(SLG_INST_KREGS, 8, u4_filter_words(8)), st, sp);
     return;
   }
   if (kind == 4) {  // the round-2 form of the same kernel (slg_tuning.uniform_kernel = 2: A/B timing)

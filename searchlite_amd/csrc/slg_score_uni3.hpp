@@ -39,18 +39,37 @@ namespace slg {
 constexpr int kU3Rows = 9;  // descriptor rows of 8 slots: 8 planned rounds + the chunk row
 constexpr int kU3DescBytes = kU3Rows * 8 * 16;
 constexpr int kU3EndBytes = (kMaxRoundsPerSlice + 1) * 4;
-constexpr int u3_desc_off(int kregs) { return uni_plan_off(kregs) + kUniPlanLds; }
-constexpr int u3_wave_lds(int kregs) { return u3_desc_off(kregs) + kU3DescBytes + ((kU3EndBytes + 15) & ~15); }
+// ML = lists a sub-query may have: 4 (a filter field is 4 list bits) or 8 (8 list bits per field:
+// half as many fields per word, so the filter gets twice the words)
+constexpr int u3_filter_words(int ml) { return ml <= 4 ? kJoinWords : 2 * kJoinWords; }
+constexpr int u3_plan_off(int kregs, int ml) { return u3_filter_words(ml) * 4 + (uni_buffered(kregs) ? buftopk_lds(kregs) : 0); }
+constexpr int u3_plan_lds(int ml) { return 64 * 4 + 2 * ml * 4; }
+constexpr int u3_desc_off(int kregs, int ml) { return u3_plan_off(kregs, ml) + u3_plan_lds(ml); }
+constexpr int u3_wave_lds(int kregs, int ml) {
+  return u3_desc_off(kregs, ml) + kU3DescBytes + ((kU3EndBytes + 15) & ~15);
+}
 
 #ifndef SLG_U3_WAVES
 #define SLG_U3_WAVES 6  // 80 VGPRs, no spill; 24 waves x 6.6 KB of LDS per CU
 #endif
 
-template <int KREGS>
+#ifndef SLG_U3_WAVES8
+#define SLG_U3_WAVES8 4  // ML = 8: 10.7 KB of LDS per wave = 15 waves per CU
+#endif
+constexpr int u3_waves(int kregs, int ml) { return ml > 4 ? SLG_U3_WAVES8 : (kregs >= 4 ? 5 : SLG_U3_WAVES); }
+
+template <int KREGS, int ML>
 __global__ void __launch_bounds__(64)
-    __attribute__((amdgpu_waves_per_eu(KREGS >= 4 ? 5 : SLG_U3_WAVES, KREGS >= 4 ? 5 : SLG_U3_WAVES)))
+    __attribute__((amdgpu_waves_per_eu(u3_waves(KREGS, ML), u3_waves(KREGS, ML))))
 score_uniform3_kernel(RoundScoreParams p) {
   constexpr int NS = kUniSlots;
+  constexpr int FW = u3_filter_words(ML);       // filter words
+  constexpr uint32_t LB = ML <= 4 ? 4u : 8u;    // list bits per filter field
+  constexpr uint32_t LBM = (1u << LB) - 1u;
+  // field of a doc: word = doc mod FW, shift = LB * ((doc / FW) mod (32 / LB))
+  constexpr uint32_t FSH = (FW == 1024 ? 10u : 11u) - (LB == 4u ? 2u : 3u);
+  constexpr uint32_t FSM = LB == 4u ? 0x1Cu : 0x18u;
+  static_assert(FW == 1024 || FW == 2048, "filter size");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t widx = blockIdx.x;
@@ -62,8 +81,8 @@ score_uniform3_kernel(RoundScoreParams p) {
   uint32_t *flt = reinterpret_cast<uint32_t *>(smem);
   uint4 *flt4 = reinterpret_cast<uint4 *>(smem);
   uint2 *queue = reinterpret_cast<uint2 *>(smem);  // {doc, score} of queued postings; overlays flt
-  uint4 *const sdesc = reinterpret_cast<uint4 *>(smem + u3_desc_off(KREGS));  // {idx lo, idx hi, weight, meta}
-  uint32_t *const rend = reinterpret_cast<uint32_t *>(smem + u3_desc_off(KREGS) + kU3DescBytes);
+  uint4 *const sdesc = reinterpret_cast<uint4 *>(smem + u3_desc_off(KREGS, ML));  // {idx lo, idx hi, weight, meta}
+  uint32_t *const rend = reinterpret_cast<uint32_t *>(smem + u3_desc_off(KREGS, ML) + kU3DescBytes);
 
   const uint32_t T = rfl(sl.n_terms);
   const uint32_t n_r = rfl(sl.n_rounds);
@@ -80,8 +99,8 @@ score_uniform3_kernel(RoundScoreParams p) {
 
   // lane t < T: list t's weight and posting offset; all cut points of the slice (entry r*T + t:
   // where round r starts in list t); the end doc of every round
-  uint32_t *const bflat = reinterpret_cast<uint32_t *>(smem + uni_plan_off(KREGS));
-  uint32_t *const off_lo = bflat + 64, *const off_hi = off_lo + kUniMaxLists;
+  uint32_t *const bflat = reinterpret_cast<uint32_t *>(smem + u3_plan_off(KREGS, ML));
+  uint32_t *const off_lo = bflat + 64, *const off_hi = off_lo + ML;
   float my_w = 0.0f;
   if (lane < T) {
     const TermRef tr = p.terms[sl.term_begin + lane];
@@ -95,7 +114,7 @@ score_uniform3_kernel(RoundScoreParams p) {
   auto list_off = [&](const uint32_t t) { return ((uint64_t)off_hi[t] << 32) | off_lo[t]; };
 
   BufTopK<BUF ? KREGS : 1> btop;  // k <= 256; for larger k only its threshold is used
-  btop.init(reinterpret_cast<uint64_t *>(smem + kJoinWords * 4));
+  btop.init(reinterpret_cast<uint64_t *>(smem + FW * 4));
   uint32_t ccur = 0;
   uint64_t cbeg = 0;
   if (!BUF) {
@@ -122,6 +141,24 @@ score_uniform3_kernel(RoundScoreParams p) {
     float sc[NS];  // in flight: impact; settled: weight * impact (score_tf, wand.rs:285)
   };
 
+  // a round's 8 list bits packed LB bits per slot (0: unused slot): an OR over the round's 8 lanes
+  // (j = the lane's slot).  ML = 8: slots 0..3 in `lo`, 4..7 in `hi`
+  auto pack_list_bits = [&](const uint32_t lbit, const uint32_t j, uint32_t &lo, uint32_t &hi) {
+    if constexpr (ML <= 4) {
+      lo = lbit << (4u * j);
+      hi = 0u;
+    } else {
+      lo = j < 4u ? lbit << (8u * j) : 0u;
+      hi = j >= 4u ? lbit << (8u * (j - 4u)) : 0u;
+      hi |= (uint32_t)__shfl_xor((int)hi, 1, 64);
+      hi |= (uint32_t)__shfl_xor((int)hi, 2, 64);
+      hi |= (uint32_t)__shfl_xor((int)hi, 4, 64);
+    }
+    lo |= (uint32_t)__shfl_xor((int)lo, 1, 64);
+    lo |= (uint32_t)__shfl_xor((int)lo, 2, 64);
+    lo |= (uint32_t)__shfl_xor((int)lo, 4, 64);
+  };
+  auto slot_bit = [&](const uint64_t lbits, const int jj) { return (uint32_t)(lbits >> (LB * jj)) & LBM; };
   // ---- descriptors of 8 consecutive planned rounds: lane 8*i + j = slot j of round g0 + i.
   //      Written to LDS row i; meta = list bit | slots the round needs (saturated) << 8 ----
   auto describe_group = [&](const uint32_t g0) {
@@ -144,14 +181,11 @@ score_uniform3_kernel(RoundScoreParams p) {
       w = mine ? wt : w;
       run += m;
     }
-    // the round's 8 list bits packed 4 bits per slot (0: unused slot): a reduction over its 8 lanes
-    uint32_t lbpack = lbit << (4u * j);
-    lbpack |= (uint32_t)__shfl_xor((int)lbpack, 1, 64);
-    lbpack |= (uint32_t)__shfl_xor((int)lbpack, 2, 64);
-    lbpack |= (uint32_t)__shfl_xor((int)lbpack, 4, 64);
+    uint32_t lbpack, lbpack_hi;
+    pack_list_bits(lbit, j, lbpack, lbpack_hi);
     // meta: slot 0 = slots the round needs (saturated), slot 1 = the packed list bits
     sdesc[lane] = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), __float_as_uint(w),
-                             j == 1u ? lbpack : (run < 255u ? run : 255u));
+                             j == 1u ? lbpack : (ML > 4 && j == 2u ? lbpack_hi : (run < 255u ? run : 255u)));
   };
   // ---- chunk of an over-full round: per-list ranges [lo, lo + cnt) held in lane t -> row 8;
   //      returns the slots in use.  lane j also keeps its slot's list (consumed counts) ----
@@ -169,13 +203,11 @@ score_uniform3_kernel(RoundScoreParams p) {
     const bool used = lane < run && lane < (uint32_t)NS;
     const uint64_t idx = used ? l_abs + (lane - l_ss) * 64u : null_idx;
     const float wt = __int_as_float((int)__shfl((int)__float_as_int(my_w), (int)tj, 64));
-    uint32_t lbpack = lane < (uint32_t)NS && used ? (1u << tj) << (4u * lane) : 0u;
-    lbpack |= (uint32_t)__shfl_xor((int)lbpack, 1, 64);
-    lbpack |= (uint32_t)__shfl_xor((int)lbpack, 2, 64);
-    lbpack |= (uint32_t)__shfl_xor((int)lbpack, 4, 64);
+    uint32_t lbpack, lbpack_hi;
+    pack_list_bits(lane < (uint32_t)NS && used ? 1u << tj : 0u, lane & 7u, lbpack, lbpack_hi);
     if (lane < (uint32_t)NS)
       sdesc[64 + lane] = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), used ? __float_as_uint(wt) : 0u,
-                                    lane == 1u ? lbpack : (run < 255u ? run : 255u));
+                                    lane == 1u ? lbpack : (ML > 4 && lane == 2u ? lbpack_hi : (run < 255u ? run : 255u)));
     slot_list_of_lane = used ? tj : 0xFFu;
     return run;
   };
@@ -201,7 +233,10 @@ score_uniform3_kernel(RoundScoreParams p) {
     }
   };
   auto row_slots = [&](const uint32_t row) { return rfl(sdesc[row * 8u].w); };
-  auto row_lbits = [&](const uint32_t row) { return rfl(sdesc[row * 8u + 1u].w); };  // 4 bits per slot
+  auto row_lbits = [&](const uint32_t row) {  // LB bits per slot
+    const uint64_t hi = ML > 4 ? rfl(sdesc[row * 8u + 2u].w) : 0u;
+    return (hi << 32) | rfl(sdesc[row * 8u + 1u].w);
+  };
 
   // ---- candidates -> top-k (one take_checked site per source; BufTopK::compact is large) ----
   auto threshold_score = [&]() {  // score part of the current threshold as a float (-inf: none)
@@ -237,14 +272,14 @@ score_uniform3_kernel(RoundScoreParams p) {
 
   // ---- score the postings of `e`: all postings with doc < end are this round's (or chunk's);
   //      the others (later postings of the same lists, sentinels) only ever add filter bits.
-  //      lbits: the list bit of every slot, 4 bits each (uniform) ----
-  auto accumulate = [&](const URound &e, const uint32_t end, const uint32_t lbits) {
+  //      lbits: the list bit of every slot, LB bits each (uniform) ----
+  auto accumulate = [&](const URound &e, const uint32_t end, const uint64_t lbits) {
 #ifdef SLG_U3_LOADS_ONLY  // diagnostic build: what the load stream alone costs (results are wrong)
     {
       uint32_t chk = 0;
 #pragma unroll
       for (int jj = 0; jj < NS; jj++) chk ^= e.doc[jj] ^ __float_as_uint(e.sc[jj]);
-      if (chk == 0x12345678u && end == 7u && lbits == 9u) n_scored++;
+      if (chk == 0x12345678u && end == 7u && lbits == 9ull) n_scored++;
       return;
     }
 #endif
@@ -253,27 +288,24 @@ score_uniform3_kernel(RoundScoreParams p) {
     uint32_t accx = hot_all ? 1u : 0u;
     if (T > 1) {
       // P0: clear the filter
-      flt4[lane] = make_uint4(0u, 0u, 0u, 0u);
-      flt4[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
-      flt4[lane + 128] = make_uint4(0u, 0u, 0u, 0u);
-      flt4[lane + 192] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+      for (int c = 0; c < FW / 256; c++) flt4[lane + 64 * c] = make_uint4(0u, 0u, 0u, 0u);
       wave_fence();
-      // P1: one bit per posting: word = doc mod 1024, field = (doc / 1024) mod 8, bit = list
+      // P1: one bit per posting: word = doc mod FW, field = (doc / FW) mod (32 / LB), bit = list
 #pragma unroll
       for (int jj = 0; jj < NS; jj++) {
-        const uint32_t lb = (lbits >> (4 * jj)) & 0xFu;
-        atomicOr(&flt[e.doc[jj] & (kJoinWords - 1)], lb << ((e.doc[jj] >> 8) & 0x1Cu));
+        atomicOr(&flt[e.doc[jj] & (FW - 1)], slot_bit(lbits, jj) << ((e.doc[jj] >> FSH) & FSM));
       }
       wave_fence();
       SLG_STAMP(2);
       // P2: the lists that hold my doc (or an alias of it)
 #pragma unroll
-      for (int jj = 0; jj < NS; jj++) x[jj] = flt[e.doc[jj] & (kJoinWords - 1)];
+      for (int jj = 0; jj < NS; jj++) x[jj] = flt[e.doc[jj] & (FW - 1)];
       wave_fence();  // the queue overlays the filter: all reads are issued before its writes
       // P3: x != 0: another list's bit is set in my field (my own always is)
 #pragma unroll
       for (int jj = 0; jj < NS; jj++)
-        x[jj] = ((x[jj] >> ((e.doc[jj] >> 8) & 0x1Cu)) & 0xFu) ^ ((lbits >> (4 * jj)) & 0xFu);
+        x[jj] = ((x[jj] >> ((e.doc[jj] >> FSH) & FSM)) & LBM) ^ slot_bit(lbits, jj);
     } else {
 #pragma unroll
       for (int jj = 0; jj < NS; jj++) x[jj] = 0u;
@@ -374,56 +406,61 @@ score_uniform3_kernel(RoundScoreParams p) {
     } else if (n != 0u) {
       // many entries (dense lists): binary search of my doc in the queue segment of every list,
       // in list order.  qe[u] = entries of the lists <= u (segment u = [qe[u-1], qe[u])).
-      uint32_t qe0 = 0, qe1 = 0, qe2 = 0, qe3 = 0;
+      uint32_t qe[ML + 1];
+      qe[0] = 0u;
 #pragma unroll
-      for (int jj = 0; jj < NS; jj++) {
-        const uint32_t lbj = (lbits >> (4 * jj)) & 0xFu;  // list bit of the slot (1, 2, 4, 8)
-        qe0 += lbj <= 1u ? cnt[jj] : 0u;
-        qe1 += lbj <= 2u ? cnt[jj] : 0u;
-        qe2 += lbj <= 4u ? cnt[jj] : 0u;
-        qe3 += cnt[jj];
+      for (int u = 0; u < ML; u++) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int jj = 0; jj < NS; jj++) c += slot_bit(lbits, jj) <= (1u << u) ? cnt[jj] : 0u;  // (0: unused slot, cnt 0)
+        qe[u + 1] = c;
       }
-      const uint32_t qe[5] = {0u, qe0, qe1, qe2, qe3};
       uint32_t maxlen = 0;
 #pragma unroll
-      for (int u = 0; u < kUniMaxLists; u++) maxlen = qe[u + 1] - qe[u] > maxlen ? qe[u + 1] - qe[u] : maxlen;
+      for (int u = 0; u < ML; u++) maxlen = qe[u + 1] - qe[u] > maxlen ? qe[u + 1] - qe[u] : maxlen;
       const uint32_t steps = maxlen ? 32u - (uint32_t)__builtin_clz(maxlen) : 0u;  // halvings that empty the longest
       for (uint32_t rb = 0; rb < n; rb += 64) {  // receivers in blocks of 64 lanes
         const uint32_t idx = rb + lane;
         const bool have = idx < n;
         const uint2 me = have ? queue[idx] : make_uint2(kDocEnd, 0u);
-        const uint32_t ml = (idx >= qe0 ? 1u : 0u) + (idx >= qe1 ? 1u : 0u) + (idx >= qe2 ? 1u : 0u);
-        // the searches in the lists' segments are independent: one LDS read of each per step
-        uint32_t lo[kUniMaxLists], hi[kUniMaxLists];
+        uint32_t ml = 0;  // my list
 #pragma unroll
-        for (int u = 0; u < kUniMaxLists; u++) {
-          lo[u] = qe[u];
-          hi[u] = qe[u + 1];
-        }
-        for (uint32_t st = 0; st < steps; st++) {
-          uint32_t mid[kUniMaxLists], dk[kUniMaxLists];
-#pragma unroll
-          for (int u = 0; u < kUniMaxLists; u++) mid[u] = (lo[u] + hi[u]) >> 1;  // < qe[u + 1] while lo < hi
-#pragma unroll
-          for (int u = 0; u < kUniMaxLists; u++) dk[u] = queue[mid[u] < qe[u + 1] ? mid[u] : 0u].x;
-          wave_fence();  // (all four reads are in flight before the first compare)
-#pragma unroll
-          for (int u = 0; u < kUniMaxLists; u++) {
-            const bool less = dk[u] < me.x;
-            const bool open = lo[u] < hi[u];
-            lo[u] = open && less ? mid[u] + 1u : lo[u];
-            hi[u] = open && !less ? mid[u] : hi[u];
-          }
-        }
+        for (int u = 1; u < ML; u++) ml += idx >= qe[u] ? 1u : 0u;
         float acc = 0.0f;
         bool lower = false;
+        // the searches in the lists' segments are independent: one LDS read of each per step, four
+        // lists at a time (the sum stays in list order)
 #pragma unroll
-        for (int u = 0; u < kUniMaxLists; u++) {  // the sum, in list order
-          const uint2 kk = queue[lo[u] < qe[u + 1] ? lo[u] : 0u];  // (an empty segment reads entry 0: ignored)
-          const bool mine = ml == (uint32_t)u;
-          const bool hit = have && (mine || (lo[u] < qe[u + 1] && kk.x == me.x));
-          acc = hit ? acc + (mine ? __uint_as_float(me.y) : __uint_as_float(kk.y)) : acc;
-          lower = lower || (hit && (uint32_t)u < ml);
+        for (int h = 0; h < ML; h += 4) {
+          uint32_t lo[4], hi[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            lo[u] = qe[h + u];
+            hi[u] = qe[h + u + 1];
+          }
+          for (uint32_t st = 0; st < steps; st++) {
+            uint32_t mid[4], dk[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) mid[u] = (lo[u] + hi[u]) >> 1;  // < qe[h + u + 1] while lo < hi
+#pragma unroll
+            for (int u = 0; u < 4; u++) dk[u] = queue[mid[u] < qe[h + u + 1] ? mid[u] : 0u].x;
+            wave_fence();  // (all four reads are in flight before the first compare)
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const bool less = dk[u] < me.x;
+              const bool open = lo[u] < hi[u];
+              lo[u] = open && less ? mid[u] + 1u : lo[u];
+              hi[u] = open && !less ? mid[u] : hi[u];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {  // the sum, in list order
+            const uint2 kk = queue[lo[u] < qe[h + u + 1] ? lo[u] : 0u];  // (an empty segment reads entry 0: ignored)
+            const bool mine = ml == (uint32_t)(h + u);
+            const bool hit = have && (mine || (lo[u] < qe[h + u + 1] && kk.x == me.x));
+            acc = hit ? acc + (mine ? __uint_as_float(me.y) : __uint_as_float(kk.y)) : acc;
+            lower = lower || (hit && (uint32_t)(h + u) < ml);
+          }
         }
         const uint64_t ownerm = __ballot(have && !lower);
         n_scored += (uint32_t)__popcll(ownerm);
@@ -462,7 +499,7 @@ score_uniform3_kernel(RoundScoreParams p) {
     const bool big = !first && en_slots > (uint32_t)NS;
     const uint32_t row = rr & 7u;
     const uint32_t rend_r = first ? 0u : rfl(rend[rr]);
-    uint32_t lbits = first ? 0u : row_lbits(row);
+    uint64_t lbits = first ? 0ull : row_lbits(row);
     if (!first && !big) settle(ew, en, row);
 #ifdef SLG_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -1,0 +1,597 @@
+// slg_score_uni4.hpp — the few-term scoring kernel (<= 8 lists per sub-query; BASELINE configs 2, 3
+// and 5), fourth form: slg_score_uni3.hpp with the round's postings laid out BLOCKED over the wave.
+//
+// Same algorithm — exact pre-planned rounds, FILTER + JOIN accumulate, buffered top-k; restates
+// query/wand.rs:459-566 (every posting scored, per-doc sums in ScorePlan leaf order,
+// planner.rs:122-135) and push_top_k (wand.rs:905-916).  What changed is which posting a lane holds.
+// The earlier forms gave every list whole 64-lane slots (register j of all lanes = 64 consecutive
+// postings of ONE list): a list with 10 postings in the round still cost a slot, so a 5-list round
+// of config 3 carried ~300 postings in its 512 lanes x registers, and the slot's list (posting
+// index, weight, list bit) was a wave-uniform value that had to be fetched per slot.  Here lane l
+// holds 8 CONSECUTIVE postings of one list in its 8 registers: the round's lists are laid end to
+// end, each padded to a multiple of 8 postings, and lane l takes positions 8l .. 8l+7.  So
+//   * a list wastes at most 7 lane-registers per round (mean 3.5) instead of half a slot (32): the
+//     planner fills rounds to ~470 postings whatever the number of lists;
+//   * list, weight, list bit and posting index are PER-LANE values, found once per round (8 byte
+//     boundaries compared in two SIMD-in-register subtractions + one LDS table read), not per slot;
+//   * a lane's postings are contiguous in memory: four 16-byte loads per round (doc ids, impacts)
+//     instead of sixteen 4-byte ones — the wave still reads contiguous runs of 2 KB per list;
+//   * the join queue must be in (list, doc) order = position order = lane-major: the queued entries
+//     are placed by a wave prefix sum over the lanes' counts (no per-slot ballots).
+// Posting arrays are padded per list (SegDev, kListPad) and end in kNullRun sentinels (idle lanes).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "slg_score_uni.hpp"
+
+namespace slg {
+
+// per-wave LDS: [filter / join queue][top-k buffer][cut points (64 words), list offsets, weights]
+//               [list table: 9 rows (8 planned rounds + the chunk row) x (ML + 1) entries of 16 B]
+//               [row headers: 9 x 16 B][round end docs]
+constexpr int kU4Rows = 9;
+constexpr int u4_plan_off(int kregs, int fw) { return fw * 4 + (uni_buffered(kregs) ? buftopk_lds(kregs) : 0); }
+constexpr int u4_plan_lds(int ml) { return 64 * 4 + 3 * ml * 4; }
+constexpr int u4_tbl_off(int kregs, int ml, int fw) { return u4_plan_off(kregs, fw) + ((u4_plan_lds(ml) + 15) & ~15); }
+constexpr int u4_tbl_bytes(int ml) { return kU4Rows * (ml + 1) * 16 + kU4Rows * 16; }
+constexpr int u4_end_bytes() { return ((kMaxRoundsPerSlice + 1) * 4 + 15) & ~15; }
+constexpr int u4_wave_lds(int kregs, int ml, int fw) { return u4_tbl_off(kregs, ml, fw) + u4_tbl_bytes(ml) + u4_end_bytes(); }
+
+#ifndef SLG_U4_WAVES
+#define SLG_U4_WAVES 5
+#endif
+#ifndef SLG_U4_WAVES8
+#define SLG_U4_WAVES8 4
+#endif
+#ifndef SLG_U4_FW8
+#define SLG_U4_FW8 2048  // filter words of the 5..8-list form
+#endif
+constexpr int u4_filter_words(int ml) { return ml <= 4 ? kJoinWords : SLG_U4_FW8; }
+constexpr int u4_waves(int kregs, int ml) { return ml > 4 ? SLG_U4_WAVES8 : (kregs >= 4 ? 5 : SLG_U4_WAVES); }
+
+// 16-byte loads at 4-byte alignment (a lane's 8 postings start at any posting)
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef u32x4_t U4x4 __attribute__((aligned(4)));
+
+template <int KREGS, int ML>
+__global__ void __launch_bounds__(64)
+    __attribute__((amdgpu_waves_per_eu(u4_waves(KREGS, ML), u4_waves(KREGS, ML))))
+score_uniform4_kernel(RoundScoreParams p) {
+  constexpr int NS = kUniSlots;            // postings per lane and round
+  constexpr int FW = u4_filter_words(ML);  // filter words
+  constexpr int TE = ML + 1;               // table entries per row: the lists + the idle-lane entry
+  constexpr uint32_t LB = ML <= 4 ? 4u : 8u;  // list bits per filter field
+  constexpr uint32_t LBM = (1u << LB) - 1u;
+  // field of a doc: word = doc mod FW, shift = LB * ((doc / FW) mod (32 / LB))
+  constexpr uint32_t FSH = (FW == 1024 ? 10u : 11u) - (LB == 4u ? 2u : 3u);
+  constexpr uint32_t FSM = LB == 4u ? 0x1Cu : 0x18u;
+  static_assert(FW == 1024 || FW == 2048, "filter size");
+  static_assert(FW * 4 >= kUniCap * 8, "the join queue ({doc, score} per posting) overlays the filter");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t widx = blockIdx.x;
+  if (widx >= p.n_slices) return;  // waves are independent: no workgroup barrier anywhere
+  const SliceDesc sl = p.slice_desc[widx];
+  const uint32_t slice = rfl(sl.slice);
+
+  constexpr bool BUF = uni_buffered(KREGS);
+  uint32_t *flt = reinterpret_cast<uint32_t *>(smem);
+  uint4 *flt4 = reinterpret_cast<uint4 *>(smem);
+  uint2 *queue = reinterpret_cast<uint2 *>(smem);  // {doc, score} of queued postings; overlays flt
+  uint4 *const tbl = reinterpret_cast<uint4 *>(smem + u4_tbl_off(KREGS, ML, FW));  // {idx lo, idx hi, weight, list bit}
+  uint4 *const hdr = tbl + kU4Rows * TE;  // {first lanes of lists 1..4, of lists 5..8 (bytes), lanes in use, -}
+  uint32_t *const rend = reinterpret_cast<uint32_t *>(smem + u4_tbl_off(KREGS, ML, FW) + u4_tbl_bytes(ML));
+
+  const uint32_t T = rfl(sl.n_terms);
+  const uint32_t n_r = rfl(sl.n_rounds);
+  const SegDev sd = p.segs[sl.seg];
+  const gu32_t gdocs = (gu32_t)sd.docs;
+  const gf32_t gimps = (gf32_t)sd.imps;
+  // per-lane bases: lane l's postings are lanebase[idx .. idx + 7]
+  const gu32_t ldocs = gdocs + 8u * lane;
+  const gf32_t limps = gimps + 8u * lane;
+  const uint64_t null_idx = sd.null_idx;
+  const uint32_t fid = rfl(sl.filter);
+  const gu32_t gdel = (gu32_t)(fid ? p.reject_table[(size_t)(fid - 1) * p.n_segs + sl.seg] : sd.deleted);
+  const uint32_t k = p.k;
+
+  // lane t < T: list t's weight and posting offset; all cut points of the slice (entry r*T + t:
+  // where round r starts in list t); the end doc of every round
+  uint32_t *const bflat = reinterpret_cast<uint32_t *>(smem + u4_plan_off(KREGS, FW));
+  uint32_t *const off_lo = bflat + 64, *const off_hi = off_lo + ML, *const wts = off_hi + ML;
+  if (lane < T) {
+    const TermRef tr = p.terms[sl.term_begin + lane];
+    wts[lane] = __float_as_uint(tr.weight);
+    off_lo[lane] = (uint32_t)tr.off;
+    off_hi[lane] = (uint32_t)(tr.off >> 32);
+  }
+  bflat[lane] = lane < (n_r + 1) * T ? p.bounds[sl.bounds_off + lane] : 0u;
+  if (lane < n_r) rend[lane] = p.rdoc[sl.rdoc_off + lane + 1];
+  wave_fence();
+  auto list_off = [&](const uint32_t t) { return ((uint64_t)off_hi[t] << 32) | off_lo[t]; };
+
+  BufTopK<BUF ? KREGS : 1> btop;  // k <= 256; for larger k only its threshold is used
+  btop.init(reinterpret_cast<uint64_t *>(smem + FW * 4));
+  uint32_t ccur = 0;
+  uint64_t cbeg = 0;
+  if (!BUF) {
+    uint32_t before = 0;
+    for (uint32_t t = 0; t < T; t++) before += rfl(bflat[t]);
+    cbeg = (((uint64_t)rfl(sl.cand_hi) << 32) | rfl(sl.cand_lo)) + before;
+  }
+  uint2 *const creg = BUF ? nullptr : p.cand + cbeg;
+  {  // threshold seed (RoundQuery::theta0)
+    const float th0 = __uint_as_float(rfl(__float_as_uint(sl.theta0)));
+    if (th0 > 0.0f) btop.set_floor(th0);
+  }
+  uint32_t n_scored = 0;
+  for (uint32_t t = 0; t < T; t++) n_scored += rfl(bflat[n_r * T + t]) - rfl(bflat[t]);
+
+#ifdef SLG_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_ins = 0, st_queued = 0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+  const unsigned long long st_begin = wall_clock64();  // 100 MHz, device-wide
+#endif
+
+  struct BRound {
+    uint32_t doc[NS];  // lane l: 8 consecutive postings of ONE list
+    float sc[NS];      // in flight: impact; settled: weight * impact (score_tf, wand.rs:285)
+    uint32_t w, lb;    // the lane's list: weight bits, list bit (0: idle lane)
+  };
+
+  // ---- list table of one round.  A list with c postings in the round takes m = ceil(c / 8) lanes
+  //      right after the lists before it; entry t = {A, weight, list bit} with A = the posting index
+  //      lane 0 WOULD read (list offset + cut point - 8 * first lane), so lane l reads A + 8 l.
+  //      Entry T serves the idle lanes behind the last list: sentinels at null_idx.  The header holds
+  //      the first lane of lists 1..8 as bytes (127: no such list) and the lanes in use. ----
+  auto boundary_byte = [&](const uint32_t u, const uint32_t first, const uint32_t used) {
+    // the byte list u >= 1 contributes: its first lane; the idle entry (u == T) starts at `used`
+    return u < T ? (first < 127u ? first : 127u) : (u == T ? used : 127u);
+  };
+  // ---- 8 consecutive planned rounds at once: lane 8 i + t = list t of round g0 + i -> row i ----
+  // (rare paths take their own copy of the lane id through an empty asm: values derived from it are
+  //  then computed where they are used instead of being hoisted into registers held over the loop)
+  auto fresh_lane = [&]() {
+    uint32_t l = lane;
+    asm volatile("" : "+v"(l));
+    return l;
+  };
+  // (__shfl* derive the lane id again and the compiler keeps that copy in a register over the loop)
+  auto from_lane = [&](const uint32_t v, const uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v);
+  };
+  auto describe_group = [&](const uint32_t g0) {
+    const uint32_t lane = fresh_lane();
+    const uint32_t i = lane >> 3, t = lane & 7u, ri = g0 + i;
+    const bool rv = ri < n_r && t < T;
+    const uint32_t src = (ri * T + t) & 63u;
+    const uint32_t lo_t = bflat[src];
+    const uint32_t c = rv ? bflat[(src + T) & 63u] - lo_t : 0u;  // postings of list t in the round
+    const uint32_t m = (c + 7u) >> 3;
+    uint32_t incl = m;  // prefix sum over the round's 8 lanes
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+      const uint32_t v = from_lane(incl, (lane - (uint32_t)d) & 63u);
+      incl += t >= (uint32_t)d ? v : 0u;
+    }
+    const uint32_t first = incl - m;
+    const uint32_t total = from_lane(incl, lane | 7u);
+    const uint32_t used = total < 64u ? total : 64u;
+    if (t < T) {
+      const uint64_t a = list_off(t) + lo_t - 8ull * first;
+      tbl[i * TE + t] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), wts[t], 1u << t);
+    }
+    if (t == 0u) {
+      const uint64_t a = null_idx - 8ull * used;
+      tbl[i * TE + T] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), 0u, 0u);
+    }
+    const uint32_t u = t == 0u ? 8u : t;  // lane t speaks for list t; lane 0 for list 8
+    const uint32_t val = boundary_byte(u, first, used);
+    uint32_t bl = u <= 4u ? val << (8u * (u - 1u)) : 0u;
+    uint32_t bh = u > 4u ? val << (8u * (u - 5u)) : 0u;
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+      bl |= from_lane(bl, lane ^ (uint32_t)d);
+      bh |= from_lane(bh, lane ^ (uint32_t)d);
+    }
+    if (t == 0u) hdr[i] = make_uint4(bl, bh, total < 255u ? total : 255u, 0u);
+  };
+  // ---- chunk of an over-full round: per-list ranges [lo, lo + cnt) held in lane t -> row 8;
+  //      lane t gets its list's lanes [first, first + m) ----
+  auto describe_chunk = [&](const uint32_t lo, const uint32_t cnt, uint32_t &first, uint32_t &m) {
+    const uint32_t lane = fresh_lane();
+    m = lane < T ? (cnt + 7u) >> 3 : 0u;
+    const uint32_t incl = wave_incl_scan(m);
+    first = incl - m;
+    const uint32_t total = rl(incl, 63);  // <= 64 (the chunk was sized for it)
+    if (lane < T) {
+      const uint64_t a = list_off(lane) + lo - 8ull * first;
+      tbl[8 * TE + lane] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), wts[lane], 1u << lane);
+    }
+    if (lane == 0u) {
+      const uint64_t a = null_idx - 8ull * total;
+      tbl[8 * TE + T] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), 0u, 0u);
+    }
+    const uint32_t val = lane >= 1u && lane <= 8u ? boundary_byte(lane, first, total) : 0u;
+    uint32_t bl = lane >= 1u && lane <= 4u ? val << (8u * (lane - 1u)) : 0u;
+    uint32_t bh = lane >= 5u && lane <= 8u ? val << (8u * (lane - 5u)) : 0u;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      bl |= from_lane(bl, lane ^ (uint32_t)d);
+      bh |= from_lane(bh, lane ^ (uint32_t)d);
+    }
+    if (lane == 0u) hdr[8] = make_uint4(bl, bh, total, 0u);
+  };
+
+  // ---- issue the loads of row `row`: my list = the number of boundary bytes <= my lane (two
+  //      SIMD-in-register subtractions: byte = 0x80 + lane - boundary keeps its top bit iff
+  //      boundary <= lane; boundaries are <= 127, so no byte borrows), then its table entry ----
+  const uint32_t lanev = 0x80808080u | (lane * 0x01010101u);
+  auto issue = [&](BRound &r, const uint32_t row) {
+    const uint4 h = hdr[row];  // (uniform address: a broadcast read)
+    uint32_t t = (uint32_t)__popc((lanev - h.x) & 0x80808080u);
+    if constexpr (ML > 4) t += (uint32_t)__popc((lanev - h.y) & 0x80808080u);
+    const uint4 en = tbl[row * TE + t];
+    const uint64_t idx = ((uint64_t)en.y << 32) | en.x;
+    typedef const __attribute__((address_space(1))) U4x4 *gq_t;
+    const gq_t pd = (gq_t)(ldocs + idx);
+    const gq_t pi = (gq_t)(limps + idx);
+    const U4x4 d0 = pd[0], d1 = pd[1], i0 = pi[0], i1 = pi[1];
+    r.doc[0] = d0.x, r.doc[1] = d0.y, r.doc[2] = d0.z, r.doc[3] = d0.w;
+    r.doc[4] = d1.x, r.doc[5] = d1.y, r.doc[6] = d1.z, r.doc[7] = d1.w;
+    r.sc[0] = __uint_as_float(i0.x), r.sc[1] = __uint_as_float(i0.y), r.sc[2] = __uint_as_float(i0.z),
+    r.sc[3] = __uint_as_float(i0.w), r.sc[4] = __uint_as_float(i1.x), r.sc[5] = __uint_as_float(i1.y),
+    r.sc[6] = __uint_as_float(i1.z), r.sc[7] = __uint_as_float(i1.w);
+    r.w = en.z;
+    r.lb = en.w;
+  };
+  // ---- dst = the loaded round src with the lane's list weight applied ----
+  auto settle = [&](BRound &dst, const BRound &src) {
+    const float w = __uint_as_float(src.w);
+#pragma unroll
+    for (int jj = 0; jj < NS; jj++) {
+      dst.doc[jj] = src.doc[jj];
+      dst.sc[jj] = src.sc[jj] * w;
+    }
+    dst.lb = src.lb;
+  };
+  auto row_lanes = [&](const uint32_t row) { return rfl(hdr[row].z); };
+
+  // ---- candidates -> top-k (one take_checked site per source; BufTopK::compact is large) ----
+  auto threshold_score = [&]() {  // score part of the current threshold as a float (-inf: none)
+    const uint32_t hi = (uint32_t)(btop.th >> 32);
+    return hi < 0x00800000u ? -INFINITY : key_to_float((int32_t)(hi ^ 0x80000000u));
+  };
+  auto take_checked = [&](const bool cand, const float score, const uint32_t doc) {
+    const uint32_t ok = ordered_score(score);
+    const bool ps = cand && btop.passes(ok, ~doc);
+    if constexpr (BUF) {
+      btop.append_checked(ps, ok, ~doc, k, lane, (const uint32_t *)gdel);
+    } else {  // the candidate region holds one entry per posting
+      const uint64_t m = __ballot(ps);
+      const uint32_t at = ccur + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      if (ps) creg[at] = make_uint2(ok, doc);
+      ccur += (uint32_t)__popcll(m);
+    }
+  };
+  // the per-posting threshold test works on score BITS (slg_score_uni3.hpp): thr_m1 = bits(threshold)
+  // - 1; a threshold that is not positive sends every round through the exact candidate code (hot_all)
+  uint32_t thr_m1 = 0;
+  bool hot_all = true;
+  auto refresh_threshold = [&]() {
+    const float thf = threshold_score();
+    hot_all = !(thf > 0.0f);
+    thr_m1 = rfl(hot_all ? 0u : __float_as_uint(thf) - 1u);
+  };
+  refresh_threshold();
+
+  // ---- score the postings of `e`: all postings with doc < end are this round's (or chunk's);
+  //      the others (later postings of the same lists, sentinels) only ever add filter bits.
+  //      bnd_*_v: the round's list boundaries (header words, uniform; for the dense join) ----
+  auto accumulate = [&](const BRound &e, const uint32_t end, const uint32_t bnd_lo_v, const uint32_t bnd_hi_v) {
+    SLG_STAMP(1);
+    uint32_t x[NS];
+    uint32_t accx = hot_all ? 1u : 0u;
+    if (T > 1) {
+      // P0: clear the filter
+#pragma unroll
+      for (int c = 0; c < FW / 256; c++) flt4[lane + 64 * c] = make_uint4(0u, 0u, 0u, 0u);
+      wave_fence();
+      // P1: one bit per posting: word = doc mod FW, field = (doc / FW) mod (32 / LB), bit = list
+#pragma unroll
+      for (int jj = 0; jj < NS; jj++)
+        atomicOr(&flt[e.doc[jj] & (FW - 1)], e.lb << ((e.doc[jj] >> FSH) & FSM));
+      wave_fence();
+      SLG_STAMP(2);
+      // P2: the lists that hold my doc (or an alias of it)
+#pragma unroll
+      for (int jj = 0; jj < NS; jj++) x[jj] = flt[e.doc[jj] & (FW - 1)];
+      wave_fence();  // the queue overlays the filter: all reads are issued before its writes
+      // P3: x != 0: another list's bit is set in my field (my own always is)
+#pragma unroll
+      for (int jj = 0; jj < NS; jj++) x[jj] = ((x[jj] >> ((e.doc[jj] >> FSH) & FSM)) & LBM) ^ e.lb;
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < NS; jj++) x[jj] = 0u;
+    }
+    // postings whose score may reach the threshold are queued too: a single is a doc without a
+    // partner (the exact compare happens once, at the join's candidate site)
+    if (!hot_all) {
+#pragma unroll
+      for (int jj = 0; jj < NS; jj++) x[jj] |= __builtin_elementwise_sub_sat(__float_as_uint(e.sc[jj]), thr_m1);
+    }
+#pragma unroll
+    for (int jj = 0; jj < NS; jj++) accx |= x[jj];
+
+    SLG_STAMP(3);
+    uint32_t n = 0;  // queued postings
+    uint32_t qincl = 0;  // inclusive prefix sum of the lanes' queued postings
+    bool touched = false;
+    if (__ballot(accx != 0u) != 0ull) {
+      if (hot_all) {
+        // no positive threshold yet (no seed; filtered query; candidates mode without a seed): every
+        // single of the round is a candidate: score = 0.0 + w*impact (wand.rs:539).  One site; the
+        // register is selected at run time
+        touched = true;
+#pragma unroll 1
+        for (uint32_t it = 0; it < (uint32_t)NS; it++) {
+          float xs = e.sc[0];
+          uint32_t dc = e.doc[0], xf = x[0];
+#pragma unroll
+          for (int j = 1; j < NS; j++) {
+            xs = it == (uint32_t)j ? e.sc[j] : xs;
+            dc = it == (uint32_t)j ? e.doc[j] : dc;
+            xf = it == (uint32_t)j ? x[j] : xf;
+          }
+          const bool single = xf == 0u && dc < end;
+          if (__ballot(single) == 0ull) continue;
+          take_checked(single, 0.0f + xs, dc);
+        }
+      }
+      // shared docs (and aliases), and hot singles, of THIS round are queued in position order =
+      // (list, doc) order: lane-major.  qf = 1 for a queued posting (plain VALU: x != 0 and
+      // doc < end as saturating subtracts), the lanes' counts are prefix-summed over the wave
+      uint32_t qf[NS], cnt = 0;
+#pragma unroll
+      for (int jj = 0; jj < NS; jj++) {
+        const uint32_t below = __builtin_elementwise_sub_sat(end, e.doc[jj]);  // != 0: doc < end
+        const uint32_t both = x[jj] < below ? x[jj] : below;                    // != 0: both
+        qf[jj] = both < 1u ? both : 1u;
+        cnt += qf[jj];
+      }
+      qincl = wave_incl_scan(cnt);
+      n = rl(qincl, 63);
+      uint32_t at = qincl - cnt;
+#pragma unroll
+      for (int jj = 0; jj < NS; jj++) {
+        if (qf[jj] != 0u) queue[at] = make_uint2(e.doc[jj], __float_as_uint(e.sc[jj]));
+        at += qf[jj];
+      }
+      // the all-pairs join reads the queue in groups of 8 entries: pad the last group with entries
+      // no doc matches (what lies behind the queue is filter words, i.e. arbitrary bit patterns)
+      if (lane >= n && lane < ((n + 7u) & ~7u) && n <= (uint32_t)kJoinPairs) queue[lane] = make_uint2(kDocEnd, 0u);
+      wave_fence();
+      n_scored -= n;
+    }
+    SLG_STAMP(4);
+#ifdef SLG_STAMPS
+    st_queued += n;
+#endif
+    // P4: join.  The queue is sorted by (list, doc).  A doc's sum is ((0.0 + x_a) + x_b) + ... over
+    // the lists that hold it, in list order (= the reference's term order); its entry in the lowest
+    // list owns the result.
+    if (n != 0u && n <= (uint32_t)kJoinPairs) {
+      // few entries (the usual case): all pairs.  Sender l is read by a BROADCAST ds_read (uniform
+      // address); same = (doc_l == my doc) as an all-ones mask; acc += same ? x_l : +0.0 (adding
+      // +0.0 is exact: a sum that starts at +0.0 is never -0.0); first = the lowest l holding my doc
+      const bool have = lane < n;
+      const uint2 me = have ? queue[lane] : make_uint2(kDocEnd, 0u);
+      float acc = 0.0f;
+      uint32_t first = 64u;
+#pragma unroll
+      for (int g = 0; g < kJoinPairs; g += 8) {
+        if ((uint32_t)g < n) {
+#pragma unroll
+          for (int l = g; l < g + 8; l++) {
+            const uint2 sq = queue[l];
+            const uint32_t diff = sq.x ^ me.x;
+            const uint32_t nm = 0u - (diff < 1u ? diff : 1u);  // 0: same doc, ~0: another doc
+            acc += __uint_as_float(sq.y & ~nm);
+            const uint32_t cand = (uint32_t)l | nm;
+            first = cand < first ? cand : first;
+          }
+        }
+      }
+      const bool own = have && first == lane;
+      n_scored += (uint32_t)__popcll(__ballot(own));
+      if (__ballot(own && acc >= threshold_score()) != 0ull) {
+        touched = true;
+        take_checked(own, acc, me.x);
+      }
+    } else if (n != 0u) {
+      // many entries (dense lists): binary search of my doc in the queue segment of every list,
+      // in list order.  qe[u] = entries of the lists < u = the prefix sum at the last lane before
+      // list u's first lane (segment u = [qe[u], qe[u + 1])).
+      const uint32_t bnd_lo = rfl(bnd_lo_v), bnd_hi = rfl(bnd_hi_v);
+      uint32_t qe[ML + 1];
+      qe[0] = 0u;
+#pragma unroll
+      for (int u = 1; u <= ML; u++) {
+        const uint32_t f = ((u <= 4 ? bnd_lo >> (8 * (u - 1)) : bnd_hi >> (8 * (u - 5))) & 0xFFu);
+        qe[u] = f == 0u ? 0u : rl(qincl, (f < 64u ? f : 64u) - 1u);
+      }
+      uint32_t maxlen = 0;
+#pragma unroll
+      for (int u = 0; u < ML; u++) maxlen = qe[u + 1] - qe[u] > maxlen ? qe[u + 1] - qe[u] : maxlen;
+      const uint32_t steps = maxlen ? 32u - (uint32_t)__builtin_clz(maxlen) : 0u;  // halvings that empty the longest
+      for (uint32_t rb = 0; rb < n; rb += 64) {  // receivers in blocks of 64 lanes
+        const uint32_t idx = rb + lane;
+        const bool have = idx < n;
+        const uint2 me = have ? queue[idx] : make_uint2(kDocEnd, 0u);
+        uint32_t ml = 0;  // my list
+#pragma unroll
+        for (int u = 1; u < ML; u++) ml += idx >= qe[u] ? 1u : 0u;
+        float acc = 0.0f;
+        bool lower = false;
+        // the searches in the lists' segments are independent: one LDS read of each per step, four
+        // lists at a time (the sum stays in list order)
+#pragma unroll
+        for (int h = 0; h < ML; h += 4) {
+          uint32_t lo[4], hi[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            lo[u] = qe[h + u];
+            hi[u] = qe[h + u + 1];
+          }
+          for (uint32_t st = 0; st < steps; st++) {
+            uint32_t mid[4], dk[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) mid[u] = (lo[u] + hi[u]) >> 1;  // < qe[h + u + 1] while lo < hi
+#pragma unroll
+            for (int u = 0; u < 4; u++) dk[u] = queue[mid[u] < qe[h + u + 1] ? mid[u] : 0u].x;
+            wave_fence();  // (all four reads are in flight before the first compare)
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const bool less = dk[u] < me.x;
+              const bool open = lo[u] < hi[u];
+              lo[u] = open && less ? mid[u] + 1u : lo[u];
+              hi[u] = open && !less ? mid[u] : hi[u];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {  // the sum, in list order
+            const uint2 kk = queue[lo[u] < qe[h + u + 1] ? lo[u] : 0u];  // (an empty segment reads entry 0: ignored)
+            const bool mine = ml == (uint32_t)(h + u);
+            const bool hit = have && (mine || (lo[u] < qe[h + u + 1] && kk.x == me.x));
+            acc = hit ? acc + (mine ? __uint_as_float(me.y) : __uint_as_float(kk.y)) : acc;
+            lower = lower || (hit && (uint32_t)(h + u) < ml);
+          }
+        }
+        const bool own = have && !lower;
+        n_scored += (uint32_t)__popcll(__ballot(own));
+        if (__ballot(own && acc >= threshold_score()) != 0ull) {
+          touched = true;
+          take_checked(own, acc, me.x);
+        }
+      }
+    }
+    wave_fence();
+    if (touched) refresh_threshold();
+    SLG_STAMP(6);
+  };
+
+  // lane t < T: cut points of round rr and rr + 1 of this slice
+  auto cuts = [&](const uint32_t rr, uint32_t &lo, uint32_t &hi) {
+    const uint32_t src = rr * T + lane;
+    const uint32_t a = bflat[src & 63], b = bflat[(src + T) & 63];
+    lo = lane < T ? a : 0u;
+    hi = lane < T ? b : 0u;
+  };
+  auto lane_sum_T = [&](const uint32_t v) {
+    uint32_t R = 0;
+    for (uint32_t t = 0; t < T; t++) R += rl(v, t);
+    return R;
+  };
+
+  // ---- driver: planned rounds are prefetched one ahead (`en` loads while `ew` is processed);
+  //      a round that needs more than 64 lanes is streamed in chunks cut at a common doc id.
+  //      ONE accumulate site and ONE planned-issue site (code size / I-cache): iteration rr = -1
+  //      only issues round 0 ----
+  BRound ew, en;
+  uint32_t en_lanes = 0;
+  for (uint32_t rr = 0xFFFFFFFFu; rr == 0xFFFFFFFFu || rr < n_r; rr++) {
+    const bool first = rr == 0xFFFFFFFFu;
+    const bool big = !first && en_lanes > 64u;
+    const uint32_t rend_r = first ? 0u : rfl(rend[rr]);
+    uint4 hcur = hdr[rr & 7u];  // (read before the next group's descriptors replace the row)
+    if (!first && !big) settle(ew, en);
+#ifdef SLG_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    SLG_STAMP(7);
+    if (first || rr + 1 < n_r) {  // prefetch the next round
+      const uint32_t nx = rr + 1u, nrow = nx & 7u;
+      if (nrow == 0) {
+        wave_fence();  // (the read of row 7's header precedes the rewrite)
+        describe_group(nx);
+        wave_fence();
+      }
+      en_lanes = row_lanes(nrow);
+      if (en_lanes <= 64u) issue(en, nrow);
+    }
+    SLG_STAMP(0);
+    if (first) continue;
+    uint32_t ocur = 0, oend = 0, end = rend_r;
+    if (big) cuts(rr, ocur, oend);
+    uint32_t guard = 0;
+    do {
+      if (big) {
+        // next chunk of an over-full round: every list with postings left gets >= 1 lane, the rest
+        // in proportion to what it has left; the chunk ends at the smallest "last loaded doc" of
+        // the lists that did not finish, so all postings of a doc are scored in the same chunk
+        const uint32_t lane = fresh_lane();
+        const uint32_t rem = oend - ocur;
+        const uint32_t nne = (uint32_t)__popcll(__ballot(rem != 0u));
+        const uint32_t R = lane_sum_T(rem);
+        if (R == 0 || ++guard > (1u << 22)) break;
+        const uint32_t need = lane_sum_T((rem + 7u) >> 3);
+        uint32_t chunk = rem;
+        if (need > 64u) {
+          const float share = (float)(64u - nne) * ((float)rem / (float)R);
+          const uint32_t mlanes = rem == 0u ? 0u : 1u + (uint32_t)share;
+          chunk = rem < mlanes * 8u ? rem : mlanes * 8u;
+        }
+        uint32_t lastdoc = kDocEnd;
+        if (chunk < rem) lastdoc = gdocs[list_off(lane < T ? lane : 0u) + ocur + chunk - 1];
+        uint32_t my_first, my_m;
+        wave_fence();
+        describe_chunk(ocur, chunk, my_first, my_m);
+        wave_fence();
+        hcur = hdr[8];
+        issue(ew, 8);
+        settle(ew, ew);
+        uint32_t bound = kDocEnd;
+        for (uint32_t t = 0; t < T; t++) {
+          const uint32_t ld = rl(lastdoc, t);
+          bound = ld < bound ? ld : bound;
+        }
+        // (kDocEnd: nothing was cut, the chunk is the rest of the round)
+        end = bound == kDocEnd ? rend_r : (bound + 1u < rend_r ? bound + 1u : rend_r);
+        // what each list consumed: its postings with doc < end (a prefix of its lanes' postings)
+        uint32_t below = 0;
+#pragma unroll
+        for (int jj = 0; jj < NS; jj++) below += ew.doc[jj] < end ? 1u : 0u;
+        const uint32_t bincl = wave_incl_scan(below);
+        const uint32_t hi_v = from_lane(bincl, (my_first + my_m - 1u) & 63u);
+        const uint32_t lo_v = from_lane(bincl, (my_first - 1u) & 63u);
+        ocur += my_m == 0u ? 0u : hi_v - (my_first == 0u ? 0u : lo_v);
+      }
+      accumulate(ew, end, hcur.x, hcur.y);
+    } while (big);
+  }
+
+  // ---- write this slice's candidates ----
+  if constexpr (BUF) {  // k entries, sentinel-padded, for merge_topk_kernel
+    btop.write_out(p.slice_tk + (size_t)slice * k, p.slice_doc + (size_t)slice * k, k, lane,
+                   (const uint32_t *)gdel);
+  } else if (lane == 0) {  // region already written; deleted docs are dropped by the select
+    p.slice_cbeg[slice] = cbeg;
+    p.slice_ccnt[slice] = ccur;
+  }
+  if (p.q_scored && lane == 0 && n_scored) atomicAdd(&p.q_scored[sl.q], n_scored);
+#ifdef SLG_STAMPS
+  const unsigned long long st_extra = st_ins | (st_queued << 32);
+  if (p.stamps && lane == 0) {
+    for (int i = 0; i < 8; i++) p.stamps[(size_t)slice * 12 + i] = st_acc[i];
+    p.stamps[(size_t)slice * 12 + 8] = st_extra;
+    p.stamps[(size_t)slice * 12 + 9] = st_begin;
+    p.stamps[(size_t)slice * 12 + 10] = wall_clock64();
+    p.stamps[(size_t)slice * 12 + 11] = ((unsigned long long)n_r << 32) | (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+  }
+#endif
+}
+
+}  // namespace slg

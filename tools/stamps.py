@@ -8,8 +8,10 @@ build.GPU_LIB = build.build_gpu(stamps=True)  # (re)built when a source is newer
 from searchlite_amd import searcher, _native as N
 if len(sys.argv) > 1:
     os.environ["SLG_ROUNDS_PER_SLICE"] = sys.argv[1]
-seg = corpus.zipf_segment(1_000_000, 1 << 18, seed=42)
-offs, terms, w = corpus.zipf_queries(1024, int(os.environ.get("TERMS", "3")), seed=7, vocab=1 << 18)
+# (DOCS=10000000 VOCAB=1048576 SEED=43 TERMS=5: config 3's corpus)
+n_docs, vocab = int(os.environ.get("DOCS", "1000000")), int(os.environ.get("VOCAB", str(1 << 18)))
+seg = corpus.zipf_segment(n_docs, vocab, seed=int(os.environ.get("SEED", "42")))
+offs, terms, w = corpus.zipf_queries(1024, int(os.environ.get("TERMS", "3")), seed=7, vocab=vocab)
 ix = searcher.GpuIndex([seg])
 b = ix.prepare(offs, terms, w, int(os.environ.get("K", "11")), int(os.environ.get("STRATEGY", "1")))
 for _ in range(3):
@@ -26,7 +28,7 @@ T_ = int(os.environ.get("TERMS", "3"))
 names = (["0 describe + issue next", "1 chunk setup / loop", "2 P0+P1 clear+or", "3 P2+P3 read back + flags", "4 queue build",
           "5 -", "6 join + candidates", "7 wait loads + settle"] if os.environ.get("SLG_UNIFORM_KERNEL", "3") != "2" else
          ["0 plan/issue next", "1 chunk setup", "2 P0+P1 clear+or", "3 P2 read back", "4 P3 queue",
-          "5 singles", "6 P4 join", "7 wait loads+copy"]) if T_ <= 4 else \
+          "5 singles", "6 P4 join", "7 wait loads+copy"]) if T_ <= int(os.environ.get("SLG_UNIFORM_MAX_TERMS", "4")) else \
         ["0 round setup (bounds, describe)", "1 P0 clear", "2 sweep A (bits)", "3 P2 prefix", "4 sweep C (accumulate)",
          "5 P4 top-k", "6 advance / tail", "7 -"]
 ins = out[:, 8] & np.uint64(0xFFFFFFFF); queued = out[:, 8] >> np.uint64(32)
