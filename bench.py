@@ -508,8 +508,9 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_measured_in_run": False,
-                         "kernel": ("score_uniform3_kernel" if os.environ.get("SLG_UNIFORM_KERNEL", "3") != "2"
-                                    else "score_uniform_kernel") if T <= int(os.environ.get("SLG_UNIFORM_MAX_TERMS", "4")) else "score_multi_kernel",
+                         "kernel": {"2": "score_uniform_kernel", "3": "score_uniform3_kernel"}.get(
+                             os.environ.get("SLG_UNIFORM_KERNEL", "4"), "score_uniform4_kernel")
+                         if T <= int(os.environ.get("SLG_UNIFORM_MAX_TERMS", "8")) else "score_multi_kernel",
                          "kernel_ms": round(kern_avg_ms, 4), "launches": n_launch,
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "exhaustive_bytes_per_launch": int(exhaustive_bytes),

@@ -158,9 +158,11 @@ typedef struct {
                                     last doc id of each list (ids < n_docs is always enforced) */
   int32_t champions;             /* !SLG_NO_CHAMPIONS (1): per-term champion table = threshold seed */
   int32_t allow_any_arch;        /* SLG_ALLOW_ANY_ARCH (0) */
-  int32_t pruning;               /* SLG_MAXSCORE (-1): -1 auto = on for batches with a query of more
-                                    terms than uniform_max_terms, strategies Wand/Bmw; 0 off; 1 on */
-  uint32_t uniform_max_terms;    /* SLG_UNIFORM_MAX_TERMS (4): lists the few-term kernel takes, <= 4 */
+  int32_t pruning;               /* SLG_MAXSCORE (-1): MaxScore classification, strategies Wand/Bmw.  -1 auto =
+                                    batches with a query of >= 5 terms are classified and keep it if block
+                                    skipping is expected to leave >= 15 % of the postings unread (else the
+                                    batch runs unclassified on the few-term kernel); 0 off; 1 on */
+  uint32_t uniform_max_terms;    /* SLG_UNIFORM_MAX_TERMS (8): lists the few-term kernel takes, <= 8 */
   uint32_t uniform_round_target; /* SLG_UNIFORM_ROUND_TARGET (0 = auto): postings per round */
   uint32_t multi_round_target;   /* SLG_MULTI_ROUND_TARGET (448) */
   uint32_t probe_target;         /* SLG_PROBE_TARGET (2048): postings per round incl. probed lists */
@@ -176,10 +178,11 @@ typedef struct {
                                     index keeps for reuse; auto = a quarter of the HBM free after
                                     staging, within [1 GiB, 24 GiB].  The pool is drained whenever a
                                     device allocation of the library fails (slg_index_trim_pool) */
-  uint32_t uniform_kernel;       /* SLG_UNIFORM_KERNEL (3): form of the few-term scoring kernel; 2 = the
-                                    round-2 kernel (kept for A/B timing on one device) */
+  uint32_t uniform_kernel;       /* SLG_UNIFORM_KERNEL (4): form of the few-term scoring kernel: 4 = blocked
+                                    layout, <= 8 lists; 3 = one list per 64-lane slot, <= 8 lists; 2 = the
+                                    round-2 kernel, <= 4 lists (both kept for A/B timing on one device) */
   uint32_t uniform_sigma_x100;   /* SLG_UNIFORM_SIGMA (0 = 160): the few-term planner keeps a round's
-                                    expected slots + this many hundredths of a sigma under 8.3 */
+                                    expected lanes (slots) + this many hundredths of a sigma under 64.3 (8.3) */
 } slg_tuning;
 void slg_tuning_default(slg_tuning *out);
 slg_index *slg_index_create_tuned(const slg_segment_desc *segs, uint32_t n_segs, int device,

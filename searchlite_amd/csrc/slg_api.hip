@@ -623,7 +623,7 @@ void slg_tuning_default(slg_tuning *t) {
   t->champions = env_i32("SLG_NO_CHAMPIONS", 0) == 0;
   t->allow_any_arch = env_i32("SLG_ALLOW_ANY_ARCH", 0) != 0;
   t->pruning = env_i32("SLG_MAXSCORE", -1);
-  t->uniform_max_terms = env_u32("SLG_UNIFORM_MAX_TERMS", 4);
+  t->uniform_max_terms = env_u32("SLG_UNIFORM_MAX_TERMS", 8);
   t->uniform_round_target = env_u32("SLG_UNIFORM_ROUND_TARGET", 0);
   t->multi_round_target = env_u32("SLG_MULTI_ROUND_TARGET", slg::kMultiTarget);
   t->probe_target = env_u32("SLG_PROBE_TARGET", 2048);

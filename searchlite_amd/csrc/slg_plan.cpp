@@ -104,6 +104,8 @@ struct Pass1Out {
   std::vector<slg::RoundQuery> sqs;
   std::vector<slg::TermRef> terms;
   std::vector<uint64_t> sq_postings, sq_postings_all;
+  std::vector<uint32_t> sq_longest_all;  // longest list of the sub-query, classification aside
+  double skip_est = 0.0;                 // postings block skipping is expected to leave unread
   uint64_t n_postings = 0, n_ess = 0, n_noness = 0;
   uint32_t max_terms = 0;
   bool any_plan = false, any_filter = false, any_nested = false;
@@ -254,8 +256,8 @@ void plan_queries(const Pass1Ctx &c, const uint32_t q_lo, const uint32_t q_hi, P
         if (nested) o.any_nested = true;
       }
       sq.theta0 = threshold_seed(sh, first, sq.n_terms, k, fq);
-      // MaxScore: on by default for batches that run on the many-term kernel (a query with >= 5
-      // terms), where probing the non-essential lists is cheaper than scoring them;
+      // MaxScore: by default for batches with a query of >= 5 terms (plan_batch drops the
+      // classification again when block skipping has nothing to gain);
       // slg_tuning.pruning = 1 / 0 forces it on / off.  Never with score plans in the batch (the
       // plan kernels have no classified path).
       uint32_t ess_mask = full_mask(sq.n_terms);
@@ -265,10 +267,14 @@ void plan_queries(const Pass1Ctx &c, const uint32_t q_lo, const uint32_t q_hi, P
       sq.ess_mask = ess_mask;
       // the round planner works on the essential lists only
       uint64_t P = 0, P_all = 0;
-      uint32_t longest = 0, longest_df = 0;
+      uint32_t longest = 0, longest_df = 0, longest_all = 0, longest_all_df = 0;
       for (uint32_t i = 0; i < sq.n_terms; i++) {
         const uint32_t df = first[i].df;
         P_all += df;
+        if (df > longest_all_df) {
+          longest_all_df = df;
+          longest_all = i;
+        }
         if (!((ess_mask >> i) & 1u)) continue;
         P += df;
         if (df > longest_df) {
@@ -284,7 +290,10 @@ void plan_queries(const Pass1Ctx &c, const uint32_t q_lo, const uint32_t q_hi, P
       if (c.tn.block_max)
         for (uint32_t i = 0; i < sq.n_terms && i < 32; i++) {
           const uint64_t df = first[i].df;
-          if (!((ess_mask >> i) & 1u) && 64ull * P < 2ull * df) sq.skip_mask |= 1u << i;
+          if (!((ess_mask >> i) & 1u) && 64ull * P < 2ull * df) {
+            sq.skip_mask |= 1u << i;
+            o.skip_est += (double)df * std::exp(-64.0 * (double)P / (double)df);  // blocks without a candidate doc
+          }
         }
       o.n_noness += P_all - P;
       c.q_postings[q] += P_all;
@@ -295,6 +304,7 @@ void plan_queries(const Pass1Ctx &c, const uint32_t q_lo, const uint32_t q_hi, P
       sqs.push_back(sq);
       o.sq_postings.push_back(P);
       o.sq_postings_all.push_back(P_all);
+      o.sq_longest_all.push_back(longest_all);
     }
   }
 }
@@ -309,7 +319,9 @@ void plan_queries(const Pass1Ctx &c, const uint32_t q_lo, const uint32_t q_hi, P
 uint32_t uniform_round_target(const slg::RoundQuery &sq, const slg::TermRef *t, uint64_t P, const slg_tuning &tn) {
   const uint32_t n = sq.n_terms;
   const double Pd = (double)P;
-  const double sigmas = tn.uniform_sigma_x100 ? tn.uniform_sigma_x100 / 100.0 : 1.6;
+  // sigmas to spare: blocked form 1.0 / 1.6 / 2.0 / 2.5 / 3.0 / 3.5 / 4.0 / 5.0 -> 0.0874 / 0.0791 / 0.0762 /
+  // 0.0744 / 0.0728 / 0.0727 / 0.0734 / 0.0752 ms on config 2 (an over-full round costs 2-3 rounds)
+  const double sigmas = tn.uniform_sigma_x100 ? tn.uniform_sigma_x100 / 100.0 : (tn.uniform_kernel >= 4 ? 3.2 : 1.6);
   uint32_t dflt;
   if (tn.uniform_kernel >= 4) {
     // blocked layout (slg_score_uni4.hpp): a list is padded to whole lanes of 8 postings, a round
@@ -494,13 +506,17 @@ void plan_batch(const std::vector<SegView> &segs, const slg_tuning &tn, const Ba
   out = Plan();
   out.q_postings.assign(nq, 0);
   std::vector<uint32_t> q_sq_begin(nq + 1, 0);
-  const bool maxscore_on = tn.pruning >= 0 ? tn.pruning != 0 : facts.max_nt > tn.uniform_max_terms;
+  // MaxScore classification: on request, or (auto) for batches with a query of more than 4 terms
+  const bool maxscore_on =
+      tn.pruning >= 0 ? tn.pruning != 0 : facts.max_nt > std::min<uint32_t>(tn.uniform_max_terms, slg::kUniMaxLists);
   Pass1Ctx ctx{segs, tn, in, facts, maxscore_on, q_sq_begin, out.q_postings};
 
   // Pass 1 is per query: large batches (config 4: 8192 queries x 8 segments = 65K sub-queries,
   // 15 ms on one thread, mostly cache misses in the champion tables) are planned by several
   // threads, each into its own vectors, stitched together in query order afterwards.
   std::vector<uint64_t> sq_postings, sq_postings_all;
+  std::vector<uint32_t> sq_longest_all;
+  double skip_est = 0.0;
   bool any_plan = false, any_filter = false;
   {
     const uint64_t work = (uint64_t)nq * n_segs;
@@ -536,13 +552,16 @@ void plan_batch(const std::vector<SegView> &segs, const slg_tuning &tn, const Ba
         out.terms.swap(pt.terms);
         sq_postings.swap(pt.sq_postings);
         sq_postings_all.swap(pt.sq_postings_all);
+        sq_longest_all.swap(pt.sq_longest_all);
       } else {
         for (auto &sq : pt.sqs) sq.term_begin += term_base;
         out.sqs.insert(out.sqs.end(), pt.sqs.begin(), pt.sqs.end());
         out.terms.insert(out.terms.end(), pt.terms.begin(), pt.terms.end());
         sq_postings.insert(sq_postings.end(), pt.sq_postings.begin(), pt.sq_postings.end());
         sq_postings_all.insert(sq_postings_all.end(), pt.sq_postings_all.begin(), pt.sq_postings_all.end());
+        sq_longest_all.insert(sq_longest_all.end(), pt.sq_longest_all.begin(), pt.sq_longest_all.end());
       }
+      skip_est += pt.skip_est;
       out.n_postings += pt.n_postings;
       out.n_postings_essential += pt.n_ess;
       out.n_postings_nonessential += pt.n_noness;
@@ -554,8 +573,26 @@ void plan_batch(const std::vector<SegView> &segs, const slg_tuning &tn, const Ba
   }
   q_sq_begin[nq] = (uint32_t)out.sqs.size();
 
-  // which kernel: the one-list-per-slot few-term kernel (slg_score_uni3.hpp) takes batches without
-  // plans and without non-essential lists; everything else runs on the many-term kernel
+  // Classified lists only pay through block skipping (the many-term kernel loads a non-essential
+  // list as it loads any other; what it saves is the blocks without a candidate doc).  A batch the
+  // few-term kernel could take keeps its classification only if the expected skipped postings are
+  // worth the slower kernel (config 3: lists of similar density, nothing to skip -> few-term kernel;
+  // a stop word next to rare terms: 74 % skipped -> many-term kernel).  slg_tuning.pruning = 1 keeps
+  // the classification whatever the estimate.
+  if (tn.pruning < 0 && out.max_terms <= tn.uniform_max_terms && !any_plan &&
+      skip_est < 0.15 * (double)out.n_postings) {
+    for (size_t i = 0; i < out.sqs.size(); i++) {
+      slg::RoundQuery &sq = out.sqs[i];
+      sq.ess_mask = full_mask(sq.n_terms);
+      sq.skip_mask = 0;
+      sq.longest = sq_longest_all[i];
+      sq_postings[i] = sq_postings_all[i];
+    }
+    out.n_postings_essential = out.n_postings;
+    out.n_postings_nonessential = 0;
+  }
+  // which kernel: the few-term kernel (slg_score_uni4.hpp) takes batches without plans and without
+  // non-essential lists; everything else runs on the many-term kernel
   out.uniform = out.max_terms <= tn.uniform_max_terms && !any_plan;
   for (const slg::RoundQuery &sq : out.sqs)
     if (sq.ess_mask != full_mask(sq.n_terms)) {

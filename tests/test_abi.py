@@ -155,7 +155,7 @@ def test_tuning_defaults_come_from_the_environment_once(lib, monkeypatch):
     from searchlite_amd import _native as N
     monkeypatch.delenv("SLG_MAXSCORE", raising=False)
     t = N.default_tuning()
-    assert t.struct_size == C.sizeof(N.Tuning) and t.pruning == -1 and t.uniform_max_terms == 4
+    assert t.struct_size == C.sizeof(N.Tuning) and t.pruning == -1 and t.uniform_max_terms == 8
     assert t.validate == 1 and t.champions == 1 and t.cand_mode == 1 and t.block_max == 1
     monkeypatch.setenv("SLG_MAXSCORE", "1")
     monkeypatch.setenv("SLG_UNIFORM_MAX_TERMS", "0")

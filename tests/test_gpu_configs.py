@@ -67,10 +67,15 @@ def test_config3_full_size_properties(gpu, oracle):
     assert_same_hits((d[:nchk], s[:nchk], sc[:nchk], c[:nchk]), want, 0.0, "config 3 sample")
 
 
-@pytest.mark.parametrize("tuning", [None, {"block_max": 0}, {"pruning": 0}])
+@pytest.mark.parametrize("tuning", [None, {"pruning": 1}, {"pruning": 1, "block_max": 0}, {"pruning": 0},
+                                    {"uniform_max_terms": 4}, {"uniform_kernel": 3}])
 def test_five_terms_top100_pruned_kernel_small(gpu, oracle, tuning):
-    """The kernel config 3 selects — score_multi_kernel<2, 1>: T = 5, k = 101 (two registers per
-    lane), classification on — on a corpus small enough for the oracle to check every query."""
+    """T = 5, k = 101 (two registers per lane) on a corpus small enough for the oracle to check
+    every query: the kernel config 3 selects (None: score_uniform4_kernel<2, 8>, the planner drops the
+    classification because block skipping has nothing to gain), the classified many-term kernel
+    score_multi_kernel<2, 1> (pruning: 1), the unclassified one (uniform_max_terms: 4 -> <2, 0> is
+    not reached: classification stays on; pruning: 0 with 8 lists -> few-term kernel), and the slot
+    form of the few-term kernel with 8-bit filter fields (uniform_kernel: 3)."""
     from searchlite_amd import corpus
     seg = corpus.zipf_segment(300_000, 1 << 16, seed=43)
     offs, terms, w = corpus.zipf_queries(192, 5, rank_lo=8, rank_hi=4096, seed=7, vocab=1 << 16)
@@ -79,7 +84,7 @@ def test_five_terms_top100_pruned_kernel_small(gpu, oracle, tuning):
         for strat in (gpu.Wand, gpu.Bmw, gpu.Bm25):
             got = ix.search_batch(offs, terms, w, 101, strat, want_stats=True)
             assert_same_hits(got[:4], want, 0.0, f"T=5 k=101 strategy {strat} tuning {tuning}")
-        if tuning is None:  # pruning really happened: fewer docs scored than the exhaustive strategy
+        if tuning == {"pruning": 1}:  # pruning really happened: fewer docs scored than the exhaustive strategy
             pr = ix.search_batch(offs, terms, w, 101, gpu.Wand, want_stats=True)[4]
             ex = ix.search_batch(offs, terms, w, 101, gpu.Bm25, want_stats=True)[4]
             assert sum(pr[q].scored_docs for q in range(192)) < sum(ex[q].scored_docs for q in range(192))

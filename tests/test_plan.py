@@ -56,9 +56,9 @@ def default_tuning(**over):
     t = N.Tuning()
     t.struct_size = C.sizeof(N.Tuning)
     t.validate, t.champions, t.pruning = 1, 1, -1
-    t.uniform_max_terms, t.multi_round_target, t.probe_target = 4, 448, 2048
+    t.uniform_max_terms, t.multi_round_target, t.probe_target = 8, 448, 2048
     t.slices_per_subquery, t.cand_mode, t.slice_order, t.block_max = 16, 1, 1, 1
-    t.uniform_kernel = 3
+    t.uniform_kernel = 4
     for k, v in over.items():
         setattr(t, k, v)
     return t
@@ -168,7 +168,7 @@ def check_structure(p, k):
             covered += rounds_of[s]
         assert covered == nr
         if f.uniform:
-            assert (rps + 1) * T <= 64 and T <= 4     # the slice's cut points fit one 64-word row
+            assert (rps + 1) * T <= 64 and T <= 8     # the slice's cut points fit one 64-word row
             assert rps <= 8
         tt = terms[int(sq["term_begin"]):int(sq["term_begin"]) + T]
         assert (np.diff(tt["leaf"].astype(np.int64)) >= 0).all()          # lists sorted by leaf
@@ -200,7 +200,7 @@ def test_round_and_slice_invariants(lib, T, k, n_segs):
         p = Planned(lib, segs, offs, terms, w, k, strategy=strat, champs=champs)
         assert p.h, p.err
         sqs, tr = check_structure(p, k)
-        assert p.facts.uniform == (T <= 4)
+        assert p.facts.uniform == (T <= 8)
         assert p.facts.cand_mode == (k > 256)
         want_postings = sum(int(s.df(int(terms[i, j]))) for i in range(terms.shape[0]) for j, s in enumerate(segs))
         assert p.facts.n_postings == want_postings
@@ -211,6 +211,47 @@ def test_round_and_slice_invariants(lib, T, k, n_segs):
                 assert int(t["off"]) == int(s.term_offsets[int(t["term"])]) + 64 * int(t["term"])
                 assert int(t["df"]) == s.df(int(t["term"]))
         p.close()
+
+
+def test_kernel_choice_follows_what_block_skipping_can_save(lib):
+    """5-term Wand batches are MaxScore-classified, and keep the classification (many-term kernel,
+    block skipping) only where skipping is expected to leave >= 15 % of the postings unread: lists of
+    similar density (config 3's shape) go to the few-term kernel unclassified; a stop word next to
+    rare terms stays classified.  pruning = 1 / 0 force either way; the slot form of the few-term
+    kernel plans smaller rounds than the blocked form."""
+    from searchlite_amd import corpus
+    seg = corpus.zipf_segment(200_000, 1 << 14, seed=5)
+    ch = champions_of(seg)
+    offs, terms, w = corpus.zipf_queries(64, 5, rank_lo=8, rank_hi=2048, seed=3, vocab=1 << 14)
+    p = Planned(lib, [seg], offs, terms, w, 101, strategy=1, champs=[ch])
+    assert p.h, p.err
+    sqs, _ = check_structure(p, 101)
+    assert p.facts.uniform and not p.facts.pruned and p.facts.n_postings_nonessential == 0
+    assert all(int(sq["ess_mask"]) == 31 and int(sq["skip_mask"]) == 0 for sq in sqs)
+    rounds_blocked = p.facts.n_rounds
+    p.close()
+    forced = Planned(lib, [seg], offs, terms, w, 101, strategy=1, champs=[ch], tuning=default_tuning(pruning=1))
+    check_structure(forced, 101)
+    assert forced.facts.pruned and forced.facts.multi and forced.facts.n_postings_nonessential > 0
+    forced.close()
+    slots = Planned(lib, [seg], offs, terms, w, 101, strategy=1, champs=[ch], tuning=default_tuning(uniform_kernel=3))
+    check_structure(slots, 101)
+    assert slots.facts.uniform and slots.facts.n_rounds > 1.2 * rounds_blocked
+    slots.close()
+    # one stop-word-like term (ranks 1..4) among four rare ones
+    rng = np.random.default_rng(4)
+    t2 = np.stack([np.concatenate([rng.integers(0, 4, 1), rng.choice(np.arange(3000, 12000), 4, replace=False)])
+                   for _ in range(64)]).astype(np.uint32)
+    for row in t2:
+        rng.shuffle(row)
+    skew = Planned(lib, [seg], offs, t2.reshape(-1), w, 11, strategy=1, champs=[ch])
+    assert skew.h, skew.err
+    check_structure(skew, 11)
+    assert skew.facts.pruned and skew.facts.multi and any(int(sq["skip_mask"]) for sq in skew.array(0, RQ))
+    skew.close()
+    off = Planned(lib, [seg], offs, t2.reshape(-1), w, 11, strategy=1, champs=[ch], tuning=default_tuning(pruning=0))
+    assert off.facts.uniform and not off.facts.pruned
+    off.close()
 
 
 def test_threshold_seed_never_exceeds_the_true_kth_score(lib, oracle):
