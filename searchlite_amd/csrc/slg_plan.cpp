@@ -400,9 +400,10 @@ void plan_rounds(const std::vector<SegView> &segs, const slg_tuning &tn, uint32_
                             (uint32_t)slg::kMaxRoundsPerSlice));
   // longest slices: 8 rounds on the few-term kernel (measured on config 2: the heaviest
   // sub-queries' 16-round slices were the tail of the launch), 16 on the many-term kernel
+  const bool blocked8 = out.uniform && tn.uniform_kernel >= 4 && out.max_terms > (uint32_t)slg::kUniMaxLists;
   const uint32_t rps_cap = std::max<uint32_t>(
       max_rps, tn.max_rounds_per_slice ? tn.max_rounds_per_slice
-                                       : (out.uniform ? 8u : (uint32_t)slg::kMaxRoundsPerSlice));
+                                       : (out.uniform && !blocked8 ? 8u : (uint32_t)slg::kMaxRoundsPerSlice));
   const uint32_t slices_per_sq = tn.slices_per_subquery;
   const bool slice_lists = !out.cand_mode;
   for (size_t i = 0; i < sqs.size(); i++) {
@@ -422,9 +423,11 @@ void plan_rounds(const std::vector<SegView> &segs, const slg_tuning &tn, uint32_
     uint32_t want_rps = max_rps;
     if (!rps_pinned)
       want_rps = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(max_rps, (nr + slices_per_sq - 1) / slices_per_sq), rps_cap);
-    // (the few-term kernel keeps a slice's cut points in one 64-word row: (rps+1)*T <= 64)
+    // (the few-term kernel keeps a slice's cut points in one row of 64 words, 128 in the 5..8-list
+    //  instance of the blocked form: (rps+1)*T <= 64 / 128)
+    const uint32_t row = blocked8 && sq.n_terms > (uint32_t)slg::kUniMaxLists ? 128u : 64u;
     const uint32_t rps = out.multi ? std::max<uint32_t>(1, want_rps)
-                                   : std::max<uint32_t>(1, std::min<uint32_t>(want_rps, 64 / sq.n_terms - 1));
+                                   : std::max<uint32_t>(1, std::min<uint32_t>(want_rps, row / sq.n_terms - 1));
     const uint64_t S = (nr + rps - 1) / rps;
     // (the per-slice candidate lists, n_slices * k entries indexed with 32 bits, exist only for
     //  k <= 256; larger k goes through the candidate array, one slot per posting)

@@ -44,7 +44,36 @@ struct RoundPartParams {
   uint32_t tpb_shift;  // log2(threads per boundary): 2 when no sub-query has more than 4 lists, else 3
 };
 
+// first index of d[0, df) with d[idx] >= target, looked for in the 128 postings from `a` on: nine
+// pivots 16 postings apart (independent loads, one latency) bracket it to 16 postings, which are then
+// read whole (one more latency) — two dependent loads instead of a bisection's ~8; false if the
+// answer lies outside the window.  The list is
+// followed by kListPad sentinels (0xFFFFFFFF), so positions up to df + 63 may be read.
+__device__ __forceinline__ bool lower_bound_window(const uint32_t *d, uint32_t df, uint32_t target, uint32_t a,
+                                                   uint32_t &pos) {
+  uint32_t below = 0;  // pivots d[a + 16 i - 1], i = 0..8, that are < target (i = 0 at a == 0: -inf)
+#pragma unroll
+  for (uint32_t i = 0; i <= 8; i++) {
+    const uint32_t at = a + 16u * i;
+    const uint32_t idx = at - 1u < df ? at - 1u : df;  // (past the end: the first sentinel)
+    const uint32_t v = d[at == 0u ? 0u : idx];
+    below += (at == 0u || v < target) ? 1u : 0u;
+  }
+  if (below < 1u || below > 8u) return false;
+  const uint32_t base = a + 16u * (below - 1u);  // d[base - 1] < target <= d[base + 15]
+  uint32_t cnt = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < 16; i++) cnt += d[base + i] < target ? 1u : 0u;
+  pos = base + cnt;
+  return true;
+}
+
 // 4 or 8 threads per boundary: thread u handles lists u, u + threads, ...
+// (Measured on config 3, where the kernel takes 1.6 ms: it is bound by the HBM lines it fetches —
+// with a round's postings of a list inside one or two lines, the cut points of all rounds touch
+// every line of every list but the longest, at scattered-access efficiency.  Giving a thread 8
+// consecutive boundaries, each searched behind its predecessor, fetches the same lines and was
+// slower: 2.2 ms.)
 static __global__ void __launch_bounds__(256) partition_rounds_kernel(RoundPartParams p) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid < p.nq) p.q_scored[gid] = 0;
@@ -97,23 +126,25 @@ static __global__ void __launch_bounds__(256) partition_rounds_kernel(RoundPartP
     } else {
       const uint32_t *d = docs + me.off;
       uint32_t lo = 0, hi = me.df;  // first index with d[idx] >= target
-      // bracket around the position a uniform doc-id distribution predicts (widened until it
-      // holds the answer), then bisect: ~10 dependent loads instead of ~log2(df)
-      {
-        const uint32_t nd = p.segs[s.seg].n_docs;
-        // (doc ids are validated < n_docs at staging, so g <= df)
-        uint32_t g = (uint32_t)(((uint64_t)me.df * target) / (nd ? nd : 1u));
-        g = g < me.df ? g : me.df;
-        // (64-bit width: a list may hold up to 2^32 - 2 postings and w grows by 8x per step)
-        for (uint64_t w = 64; w < me.df; w <<= 3) {
+      const uint32_t nd = p.segs[s.seg].n_docs;
+      // the position a uniform doc-id distribution predicts (doc ids are validated < n_docs at
+      // staging, so g <= df)
+      uint32_t g = (uint32_t)(((uint64_t)me.df * target) / (nd ? nd : 1u));
+      g = g < me.df ? g : me.df;
+      if (lower_bound_window(d, me.df, target, g > 64u ? g - 64u : 0u, lo)) {
+        hi = lo;
+      } else {
+        // the guess was off by more than 64 postings: bracket widened until it holds the answer
+        // (64-bit width: a list may hold up to 2^32 - 2 postings and w grows by 8x per step), then bisect
+        lo = 0;
+        for (uint64_t w = 512; w < me.df; w <<= 3) {
           const uint32_t a = g > w ? (uint32_t)(g - w) : 0u;
-          const uint32_t b = (uint64_t)g + w < me.df ? (uint32_t)(g + w) : me.df;
+          const uint32_t e = (uint64_t)g + w < me.df ? (uint32_t)(g + w) : me.df;
           const bool lo_ok = a == 0u || d[a - 1] < target;   // answer >= a
-          const bool hi_ok = b == me.df || d[b - 1] >= target;  // answer <= b - 1 < b
+          const bool hi_ok = e == me.df || d[e - 1] >= target;  // answer <= e - 1
           if (lo_ok && hi_ok) {
             lo = a;
-            hi = b == me.df ? me.df : b - 1;  // d[b-1] >= target: answer <= b-1
-            if (b != me.df) hi = b - 1;
+            hi = e == me.df ? me.df : e - 1;
             break;
           }
         }

@@ -28,12 +28,13 @@
 
 namespace slg {
 
-// per-wave LDS: [filter / join queue][top-k buffer][cut points (64 words), list offsets, weights]
+// per-wave LDS: [filter / join queue][top-k buffer][cut points (64 / 128 words), list offsets, weights]
 //               [list table: 9 rows (8 planned rounds + the chunk row) x (ML + 1) entries of 16 B]
 //               [row headers: 9 x 16 B][round end docs]
 constexpr int kU4Rows = 9;
 constexpr int u4_plan_off(int kregs, int fw) { return fw * 4 + (uni_buffered(kregs) ? buftopk_lds(kregs) : 0); }
-constexpr int u4_plan_lds(int ml) { return 64 * 4 + 3 * ml * 4; }
+constexpr int u4_cut_words(int ml) { return ml <= 4 ? 64 : 128; }  // a slice's cut points: (rounds + 1) * lists
+constexpr int u4_plan_lds(int ml) { return u4_cut_words(ml) * 4 + 3 * ml * 4; }
 constexpr int u4_tbl_off(int kregs, int ml, int fw) { return u4_plan_off(kregs, fw) + ((u4_plan_lds(ml) + 15) & ~15); }
 constexpr int u4_tbl_bytes(int ml) { return kU4Rows * (ml + 1) * 16 + kU4Rows * 16; }
 constexpr int u4_end_bytes() { return ((kMaxRoundsPerSlice + 1) * 4 + 15) & ~15; }
@@ -62,6 +63,7 @@ score_uniform4_kernel(RoundScoreParams p) {
   constexpr int NS = kUniSlots;            // postings per lane and round
   constexpr int FW = u4_filter_words(ML);  // filter words
   constexpr int TE = ML + 1;               // table entries per row: the lists + the idle-lane entry
+  constexpr uint32_t BW = u4_cut_words(ML);  // words of the slice's cut-point row
   constexpr uint32_t LB = ML <= 4 ? 4u : 8u;  // list bits per filter field
   constexpr uint32_t LBM = (1u << LB) - 1u;
   // field of a doc: word = doc mod FW, shift = LB * ((doc / FW) mod (32 / LB))
@@ -100,14 +102,15 @@ score_uniform4_kernel(RoundScoreParams p) {
   // lane t < T: list t's weight and posting offset; all cut points of the slice (entry r*T + t:
   // where round r starts in list t); the end doc of every round
   uint32_t *const bflat = reinterpret_cast<uint32_t *>(smem + u4_plan_off(KREGS, FW));
-  uint32_t *const off_lo = bflat + 64, *const off_hi = off_lo + ML, *const wts = off_hi + ML;
+  uint32_t *const off_lo = bflat + BW, *const off_hi = off_lo + ML, *const wts = off_hi + ML;
   if (lane < T) {
     const TermRef tr = p.terms[sl.term_begin + lane];
     wts[lane] = __float_as_uint(tr.weight);
     off_lo[lane] = (uint32_t)tr.off;
     off_hi[lane] = (uint32_t)(tr.off >> 32);
   }
-  bflat[lane] = lane < (n_r + 1) * T ? p.bounds[sl.bounds_off + lane] : 0u;
+#pragma unroll
+  for (uint32_t i = 0; i < BW; i += 64) bflat[i + lane] = i + lane < (n_r + 1) * T ? p.bounds[sl.bounds_off + i + lane] : 0u;
   if (lane < n_r) rend[lane] = p.rdoc[sl.rdoc_off + lane + 1];
   wave_fence();
   auto list_off = [&](const uint32_t t) { return ((uint64_t)off_hi[t] << 32) | off_lo[t]; };
@@ -166,9 +169,9 @@ score_uniform4_kernel(RoundScoreParams p) {
     const uint32_t lane = fresh_lane();
     const uint32_t i = lane >> 3, t = lane & 7u, ri = g0 + i;
     const bool rv = ri < n_r && t < T;
-    const uint32_t src = (ri * T + t) & 63u;
+    const uint32_t src = (ri * T + t) & (BW - 1u);
     const uint32_t lo_t = bflat[src];
-    const uint32_t c = rv ? bflat[(src + T) & 63u] - lo_t : 0u;  // postings of list t in the round
+    const uint32_t c = rv ? bflat[(src + T) & (BW - 1u)] - lo_t : 0u;  // postings of list t in the round
     const uint32_t m = (c + 7u) >> 3;
     uint32_t incl = m;  // prefix sum over the round's 8 lanes
 #pragma unroll
@@ -486,7 +489,7 @@ score_uniform4_kernel(RoundScoreParams p) {
   // lane t < T: cut points of round rr and rr + 1 of this slice
   auto cuts = [&](const uint32_t rr, uint32_t &lo, uint32_t &hi) {
     const uint32_t src = rr * T + lane;
-    const uint32_t a = bflat[src & 63], b = bflat[(src + T) & 63];
+    const uint32_t a = bflat[src & (BW - 1u)], b = bflat[(src + T) & (BW - 1u)];
     lo = lane < T ? a : 0u;
     hi = lane < T ? b : 0u;
   };

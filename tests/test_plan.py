@@ -168,8 +168,8 @@ def check_structure(p, k):
             covered += rounds_of[s]
         assert covered == nr
         if f.uniform:
-            assert (rps + 1) * T <= 64 and T <= 8     # the slice's cut points fit one 64-word row
-            assert rps <= 8
+            assert (rps + 1) * T <= (128 if T > 4 else 64) and T <= 8     # the slice's cut points fit one row
+            assert rps <= (16 if f.max_terms > 4 else 8)
         tt = terms[int(sq["term_begin"]):int(sq["term_begin"]) + T]
         assert (np.diff(tt["leaf"].astype(np.int64)) >= 0).all()          # lists sorted by leaf
         ess = int(sq["ess_mask"])

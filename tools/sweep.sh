@@ -5,5 +5,5 @@
 CFG=${2:-c2}
 for kv in $1; do
   out=$(env ${kv//,/ } python3 bench.py --config $CFG --steps 16 --warmup 2 --no-cpu-baseline --check 0 --kernel-leg-only 2>/dev/null | tail -1)
-  echo "$kv kernel_ms=$(echo "$out" | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["roofline"]["kernel_ms"], "frac", d["roofline"]["frac"], "slices", d["config"]["slices"])')"
+  echo "$kv kernel_ms=$(echo "$out" | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["roofline"]["kernel_ms"], "frac", d["roofline"]["frac"], "slices", d["config"]["slices"], "resident_qps", d["config"]["kernel_only_qps"])')"
 done
