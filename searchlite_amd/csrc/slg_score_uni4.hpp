@@ -49,6 +49,10 @@ constexpr int u4_wave_lds(int kregs, int ml, int fw) { return u4_tbl_off(kregs, 
 #ifndef SLG_U4_FW8
 #define SLG_U4_FW8 1024  // filter words of the 5..8-list form (2048 at 4 waves: 6.37 vs 5.68 ms on config 3)
 #endif
+#ifndef SLG_U4_JOIN_PAIRS
+#define SLG_U4_JOIN_PAIRS 64
+#endif
+constexpr int kU4JoinPairs = SLG_U4_JOIN_PAIRS;  // queues up to this many entries are joined all-pairs (<= 64: one lane per entry)
 constexpr int u4_filter_words(int ml) { return ml <= 4 ? kJoinWords : SLG_U4_FW8; }
 constexpr int u4_waves(int kregs, int ml) { return ml > 4 ? SLG_U4_WAVES8 : (kregs >= 4 ? 5 : SLG_U4_WAVES); }
 
@@ -375,7 +379,7 @@ score_uniform4_kernel(RoundScoreParams p) {
       }
       // the all-pairs join reads the queue in groups of 8 entries: pad the last group with entries
       // no doc matches (what lies behind the queue is filter words, i.e. arbitrary bit patterns)
-      if (lane >= n && lane < ((n + 7u) & ~7u) && n <= (uint32_t)kJoinPairs) queue[lane] = make_uint2(kDocEnd, 0u);
+      if (lane >= n && lane < ((n + 7u) & ~7u) && n <= (uint32_t)kU4JoinPairs) queue[lane] = make_uint2(kDocEnd, 0u);
       wave_fence();
       n_scored -= n;
     }
@@ -386,26 +390,26 @@ score_uniform4_kernel(RoundScoreParams p) {
     // P4: join.  The queue is sorted by (list, doc).  A doc's sum is ((0.0 + x_a) + x_b) + ... over
     // the lists that hold it, in list order (= the reference's term order); its entry in the lowest
     // list owns the result.
-    if (n != 0u && n <= (uint32_t)kJoinPairs) {
-      // few entries (the usual case): all pairs.  Sender l is read by a BROADCAST ds_read (uniform
-      // address); same = (doc_l == my doc) as an all-ones mask; acc += same ? x_l : +0.0 (adding
-      // +0.0 is exact: a sum that starts at +0.0 is never -0.0); first = the lowest l holding my doc
+    if (n != 0u && n <= (uint32_t)kU4JoinPairs) {
+      // up to a wave of entries (the usual case): all pairs.  Sender l is read by a BROADCAST ds_read
+      // (uniform address); same = (doc_l == my doc) as an all-ones mask; acc += same ? x_l : +0.0
+      // (adding +0.0 is exact: a sum that starts at +0.0 is never -0.0); first = the lowest l holding
+      // my doc.  7 plain VALU instructions per sender and no dependent LDS chain: cheaper than the
+      // binary searches below up to 64 entries (config 3 queues ~34 entries per round: with the
+      // searches from 25 entries on, the join was 61 % of the kernel)
       const bool have = lane < n;
       const uint2 me = have ? queue[lane] : make_uint2(kDocEnd, 0u);
       float acc = 0.0f;
       uint32_t first = 64u;
+      for (uint32_t g = 0; g < n; g += 8) {
 #pragma unroll
-      for (int g = 0; g < kJoinPairs; g += 8) {
-        if ((uint32_t)g < n) {
-#pragma unroll
-          for (int l = g; l < g + 8; l++) {
-            const uint2 sq = queue[l];
-            const uint32_t diff = sq.x ^ me.x;
-            const uint32_t nm = 0u - (diff < 1u ? diff : 1u);  // 0: same doc, ~0: another doc
-            acc += __uint_as_float(sq.y & ~nm);
-            const uint32_t cand = (uint32_t)l | nm;
-            first = cand < first ? cand : first;
-          }
+        for (uint32_t l = 0; l < 8; l++) {
+          const uint2 sq = queue[g + l];
+          const uint32_t diff = sq.x ^ me.x;
+          const uint32_t nm = 0u - (diff < 1u ? diff : 1u);  // 0: same doc, ~0: another doc
+          acc += __uint_as_float(sq.y & ~nm);
+          const uint32_t cand = (g + l) | nm;
+          first = cand < first ? cand : first;
         }
       }
       const bool own = have && first == lane;

@@ -28,7 +28,7 @@ T_ = int(os.environ.get("TERMS", "3"))
 names = (["0 describe + issue next", "1 chunk setup / loop", "2 P0+P1 clear+or", "3 P2+P3 read back + flags", "4 queue build",
           "5 -", "6 join + candidates", "7 wait loads + settle"] if os.environ.get("SLG_UNIFORM_KERNEL", "3") != "2" else
          ["0 plan/issue next", "1 chunk setup", "2 P0+P1 clear+or", "3 P2 read back", "4 P3 queue",
-          "5 singles", "6 P4 join", "7 wait loads+copy"]) if T_ <= int(os.environ.get("SLG_UNIFORM_MAX_TERMS", "4")) else \
+          "5 singles", "6 P4 join", "7 wait loads+copy"]) if T_ <= int(os.environ.get("SLG_UNIFORM_MAX_TERMS", "8")) else \
         ["0 round setup (bounds, describe)", "1 P0 clear", "2 sweep A (bits)", "3 P2 prefix", "4 sweep C (accumulate)",
          "5 P4 top-k", "6 advance / tail", "7 -"]
 ins = out[:, 8] & np.uint64(0xFFFFFFFF); queued = out[:, 8] >> np.uint64(32)
