@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SLG_ABI_VERSION 2u  /* 2: slg_tuning grew (pool_cap_mb, uniform_kernel, uniform_sigma_x100); shard groups; slg_batch_prepare_plans */
+#define SLG_ABI_VERSION 2u  /* 2: slg_tuning grew (pool_cap_mb, uniform_kernel, uniform_sigma_x100, inline_cuts); shard groups; slg_batch_prepare_plans */
 #define SLG_NO_TERM 0xFFFFFFFFu      /* term absent from a segment (api/reader.rs:2989) */
 #define SLG_NO_VECTOR 0xFFFFFFFFu    /* vectors/mod.rs:65-67 (u32::MAX offset) */
 #define SLG_MAX_QUERY_TERMS 32u      /* scored terms per query per segment */
@@ -183,6 +183,9 @@ typedef struct {
                                     round-2 kernel, <= 4 lists (both kept for A/B timing on one device) */
   uint32_t uniform_sigma_x100;   /* SLG_UNIFORM_SIGMA (0 = 160): the few-term planner keeps a round's
                                     expected lanes (slots) + this many hundredths of a sigma under 64.3 (8.3) */
+  int32_t inline_cuts;           /* SLG_INLINE_CUTS (-1 = auto: on): the blocked few-term kernel cuts the lists at
+                                    its slice's round boundaries itself instead of reading cut points that
+                                    partition_rounds_kernel wrote for the whole batch; 0 off; 1 on */
 } slg_tuning;
 void slg_tuning_default(slg_tuning *out);
 slg_index *slg_index_create_tuned(const slg_segment_desc *segs, uint32_t n_segs, int device,

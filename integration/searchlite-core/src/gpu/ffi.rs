@@ -27,7 +27,7 @@ pub struct slg_tuning {
     pub uniform_max_terms: u32, pub uniform_round_target: u32, pub multi_round_target: u32,
     pub probe_target: u32, pub rounds_per_slice: u32, pub max_rounds_per_slice: u32,
     pub slices_per_subquery: u32, pub cand_mode: i32, pub slice_order: i32, pub block_max: i32,
-    pub pool_cap_mb: u32, pub uniform_kernel: u32, pub uniform_sigma_x100: u32,
+    pub pool_cap_mb: u32, pub uniform_kernel: u32, pub uniform_sigma_x100: u32, pub inline_cuts: i32,
 }
 #[repr(C)] pub struct slg_vector_field_desc {
     pub vec_dim: u32, pub vec_metric: i32, pub vec_offsets: *const u32, pub vec_values: *const c_float, pub vec_rows: u32,

@@ -62,7 +62,8 @@ class Tuning(C.Structure):
                 ("rounds_per_slice", C.c_uint32), ("max_rounds_per_slice", C.c_uint32),
                 ("slices_per_subquery", C.c_uint32), ("cand_mode", C.c_int32),
                 ("slice_order", C.c_int32), ("block_max", C.c_int32), ("pool_cap_mb", C.c_uint32),
-                ("uniform_kernel", C.c_uint32), ("uniform_sigma_x100", C.c_uint32)]
+                ("uniform_kernel", C.c_uint32), ("uniform_sigma_x100", C.c_uint32),
+                ("inline_cuts", C.c_int32)]
 
 
 class ScorePlans(C.Structure):

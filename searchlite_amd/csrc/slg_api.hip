@@ -636,6 +636,7 @@ void slg_tuning_default(slg_tuning *t) {
   t->pool_cap_mb = env_u32("SLG_POOL_CAP_MB", 0);
   t->uniform_kernel = env_u32("SLG_UNIFORM_KERNEL", 4);
   t->uniform_sigma_x100 = env_u32("SLG_UNIFORM_SIGMA", 0);
+  t->inline_cuts = env_i32("SLG_INLINE_CUTS", -1);
 }
 
 slg_index *slg_index_create(const slg_segment_desc *segs, uint32_t n_segs, int device) {
@@ -1082,11 +1083,14 @@ int slg_batch_run(slg_batch *b) {
       pp.slice_order = b->d_slice_order;
       pp.slice_desc = b->d_slice_desc.as<slg::SliceDesc>();
       pp.nq = b->nq;
-      pp.n_boundaries = b->n_boundaries;
+      // the blocked few-term kernel can cut its slices itself (slg_tuning.inline_cuts)
+      const bool inline_cuts = b->uniform && ix->tune.uniform_kernel >= 4 &&
+                               (ix->tune.inline_cuts >= 0 ? ix->tune.inline_cuts != 0 : true);
+      pp.n_boundaries = inline_cuts ? 0u : b->n_boundaries;
       pp.n_slices = b->n_slices;
       pp.tpb_shift = b->max_terms <= 4 ? 2u : 3u;
       const uint64_t pthreads = std::max<uint64_t>(
-          std::max<uint64_t>((uint64_t)b->n_boundaries << pp.tpb_shift, (uint64_t)b->nq + 1), b->n_slices);
+          std::max<uint64_t>((uint64_t)pp.n_boundaries << pp.tpb_shift, (uint64_t)b->nq + 1), b->n_slices);
       hipLaunchKernelGGL(slg::partition_rounds_kernel, dim3((uint32_t)((pthreads + 255) / 256)),
                          dim3(256), 0, st, pp);
       SLG_HIP(hipGetLastError());
@@ -1104,8 +1108,8 @@ int slg_batch_run(slg_batch *b) {
       sp.slice_cbeg = b->d_slice_cbeg.as<uint64_t>();
       sp.slice_ccnt = b->d_slice_ccnt.as<uint32_t>();
       sp.segs = ix->d_segs.as<slg::SegDev>();
-      sp.bounds = b->d_bounds.as<uint32_t>();
-      sp.rdoc = b->d_rdoc.as<uint32_t>();
+      sp.bounds = inline_cuts ? nullptr : b->d_bounds.as<uint32_t>();
+      sp.rdoc = inline_cuts ? nullptr : b->d_rdoc.as<uint32_t>();
       sp.slice_tk = b->d_slice_tk.as<int32_t>();
       sp.slice_doc = b->d_slice_doc.as<uint32_t>();
       sp.q_scored = b->d_q_scored.as<uint32_t>();

@@ -101,6 +101,9 @@ struct SliceDesc {
   uint32_t q;
   float theta0;
   uint32_t cand_lo, cand_hi;
+  // for waves that cut their slice themselves (slg_score_uni4.hpp with RoundScoreParams::bounds ==
+  // nullptr): the slice's first round, the sub-query's rounds, its splitter list
+  uint32_t first_round, sq_rounds, longest, pad_;
 };
 
 struct QueryRef {

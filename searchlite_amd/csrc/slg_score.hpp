@@ -49,7 +49,8 @@ struct RoundPartParams {
 // read whole (one more latency) — two dependent loads instead of a bisection's ~8; false if the
 // answer lies outside the window.  The list is
 // followed by kListPad sentinels (0xFFFFFFFF), so positions up to df + 63 may be read.
-__device__ __forceinline__ bool lower_bound_window(const uint32_t *d, uint32_t df, uint32_t target, uint32_t a,
+template <typename DocPtr>
+__device__ __forceinline__ bool lower_bound_window(const DocPtr d, uint32_t df, uint32_t target, uint32_t a,
                                                    uint32_t &pos) {
   uint32_t below = 0;  // pivots d[a + 16 i - 1], i = 0..8, that are < target (i = 0 at a == 0: -inf)
 #pragma unroll
@@ -66,6 +67,38 @@ __device__ __forceinline__ bool lower_bound_window(const uint32_t *d, uint32_t d
   for (uint32_t i = 0; i < 16; i++) cnt += d[base + i] < target ? 1u : 0u;
   pos = base + cnt;
   return true;
+}
+
+// first index of d[0, df) with d[idx] >= target: the window around the position a uniform doc-id
+// distribution predicts (doc ids are validated < n_docs at staging, so the guess is <= df); if the
+// guess was off by more than 64 postings, a bracket widened until it holds the answer (64-bit
+// width: a list may hold up to 2^32 - 2 postings and w grows by 8x per step), then a bisection
+template <typename DocPtr>
+__device__ __forceinline__ uint32_t lower_bound_guess(const DocPtr d, uint32_t df, uint32_t target, uint32_t n_docs) {
+  uint32_t g = (uint32_t)(((uint64_t)df * target) / (n_docs ? n_docs : 1u));
+  g = g < df ? g : df;
+  uint32_t lo = 0, hi = df;
+  if (lower_bound_window(d, df, target, g > 64u ? g - 64u : 0u, lo)) return lo;
+  lo = 0;
+  for (uint64_t w = 512; w < df; w <<= 3) {
+    const uint32_t a = g > w ? (uint32_t)(g - w) : 0u;
+    const uint32_t e = (uint64_t)g + w < df ? (uint32_t)(g + w) : df;
+    const bool lo_ok = a == 0u || d[a - 1] < target;   // answer >= a
+    const bool hi_ok = e == df || d[e - 1] >= target;  // answer <= e - 1
+    if (lo_ok && hi_ok) {
+      lo = a;
+      hi = e == df ? df : e - 1;
+      break;
+    }
+  }
+  while (lo < hi) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (d[mid] < target)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
 }
 
 // 4 or 8 threads per boundary: thread u handles lists u, u + threads, ...
@@ -95,6 +128,10 @@ static __global__ void __launch_bounds__(256) partition_rounds_kernel(RoundPartP
     d.theta0 = s.theta0;
     d.cand_lo = s.cand_lo;
     d.cand_hi = s.cand_hi;
+    d.first_round = r0;
+    d.sq_rounds = s.n_rounds;
+    d.longest = s.longest;
+    d.pad_ = 0;
     p.slice_desc[gid] = d;
   }
   const uint32_t tpb = 1u << p.tpb_shift;
@@ -124,39 +161,7 @@ static __global__ void __launch_bounds__(256) partition_rounds_kernel(RoundPartP
     } else if (t == s.longest) {
       out = (uint32_t)posL;
     } else {
-      const uint32_t *d = docs + me.off;
-      uint32_t lo = 0, hi = me.df;  // first index with d[idx] >= target
-      const uint32_t nd = p.segs[s.seg].n_docs;
-      // the position a uniform doc-id distribution predicts (doc ids are validated < n_docs at
-      // staging, so g <= df)
-      uint32_t g = (uint32_t)(((uint64_t)me.df * target) / (nd ? nd : 1u));
-      g = g < me.df ? g : me.df;
-      if (lower_bound_window(d, me.df, target, g > 64u ? g - 64u : 0u, lo)) {
-        hi = lo;
-      } else {
-        // the guess was off by more than 64 postings: bracket widened until it holds the answer
-        // (64-bit width: a list may hold up to 2^32 - 2 postings and w grows by 8x per step), then bisect
-        lo = 0;
-        for (uint64_t w = 512; w < me.df; w <<= 3) {
-          const uint32_t a = g > w ? (uint32_t)(g - w) : 0u;
-          const uint32_t e = (uint64_t)g + w < me.df ? (uint32_t)(g + w) : me.df;
-          const bool lo_ok = a == 0u || d[a - 1] < target;   // answer >= a
-          const bool hi_ok = e == me.df || d[e - 1] >= target;  // answer <= e - 1
-          if (lo_ok && hi_ok) {
-            lo = a;
-            hi = e == me.df ? me.df : e - 1;
-            break;
-          }
-        }
-      }
-      while (lo < hi) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (d[mid] < target)
-          lo = mid + 1;
-        else
-          hi = mid;
-      }
-      out = lo;
+      out = lower_bound_guess(docs + me.off, me.df, target, p.segs[s.seg].n_docs);
     }
     p.bounds[s.bounds_begin + j * s.n_terms + t] = out;
   }

@@ -28,20 +28,20 @@
 
 namespace slg {
 
-// per-wave LDS: [filter / join queue][top-k buffer][cut points (64 / 128 words), list offsets, weights]
+// per-wave LDS: [filter / join queue][top-k buffer][cut points (64 / 128 words), list offsets, weights, lengths]
 //               [list table: 9 rows (8 planned rounds + the chunk row) x (ML + 1) entries of 16 B]
 //               [row headers: 9 x 16 B][round end docs]
 constexpr int kU4Rows = 9;
 constexpr int u4_plan_off(int kregs, int fw) { return fw * 4 + (uni_buffered(kregs) ? buftopk_lds(kregs) : 0); }
 constexpr int u4_cut_words(int ml) { return ml <= 4 ? 64 : 128; }  // a slice's cut points: (rounds + 1) * lists
-constexpr int u4_plan_lds(int ml) { return u4_cut_words(ml) * 4 + 3 * ml * 4; }
+constexpr int u4_plan_lds(int ml) { return u4_cut_words(ml) * 4 + 4 * ml * 4; }
 constexpr int u4_tbl_off(int kregs, int ml, int fw) { return u4_plan_off(kregs, fw) + ((u4_plan_lds(ml) + 15) & ~15); }
 constexpr int u4_tbl_bytes(int ml) { return kU4Rows * (ml + 1) * 16 + kU4Rows * 16; }
 constexpr int u4_end_bytes() { return ((kMaxRoundsPerSlice + 1) * 4 + 15) & ~15; }
 constexpr int u4_wave_lds(int kregs, int ml, int fw) { return u4_tbl_off(kregs, ml, fw) + u4_tbl_bytes(ml) + u4_end_bytes(); }
 
 #ifndef SLG_U4_WAVES
-#define SLG_U4_WAVES 5
+#define SLG_U4_WAVES 6
 #endif
 #ifndef SLG_U4_WAVES8
 #define SLG_U4_WAVES8 5
@@ -54,7 +54,7 @@ constexpr int u4_wave_lds(int kregs, int ml, int fw) { return u4_tbl_off(kregs, 
 #endif
 constexpr int kU4JoinPairs = SLG_U4_JOIN_PAIRS;  // queues up to this many entries are joined all-pairs (<= 64: one lane per entry)
 constexpr int u4_filter_words(int ml) { return ml <= 4 ? kJoinWords : SLG_U4_FW8; }
-constexpr int u4_waves(int kregs, int ml) { return ml > 4 ? SLG_U4_WAVES8 : (kregs >= 4 ? 5 : SLG_U4_WAVES); }
+constexpr int u4_waves(int kregs, int ml) { return ml > 4 ? SLG_U4_WAVES8 : (kregs == 4 ? 5 : SLG_U4_WAVES); }  // (k 129..256: LDS)
 
 // 16-byte loads at 4-byte alignment (a lane's 8 postings start at any posting)
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -106,16 +106,54 @@ score_uniform4_kernel(RoundScoreParams p) {
   // lane t < T: list t's weight and posting offset; all cut points of the slice (entry r*T + t:
   // where round r starts in list t); the end doc of every round
   uint32_t *const bflat = reinterpret_cast<uint32_t *>(smem + u4_plan_off(KREGS, FW));
-  uint32_t *const off_lo = bflat + BW, *const off_hi = off_lo + ML, *const wts = off_hi + ML;
+  uint32_t *const off_lo = bflat + BW, *const off_hi = off_lo + ML, *const wts = off_hi + ML, *const dfs = wts + ML;
   if (lane < T) {
     const TermRef tr = p.terms[sl.term_begin + lane];
     wts[lane] = __float_as_uint(tr.weight);
     off_lo[lane] = (uint32_t)tr.off;
     off_hi[lane] = (uint32_t)(tr.off >> 32);
+    dfs[lane] = tr.df;
   }
+  if (p.bounds != nullptr) {  // cut points from partition_rounds_kernel
 #pragma unroll
-  for (uint32_t i = 0; i < BW; i += 64) bflat[i + lane] = i + lane < (n_r + 1) * T ? p.bounds[sl.bounds_off + i + lane] : 0u;
-  if (lane < n_r) rend[lane] = p.rdoc[sl.rdoc_off + lane + 1];
+    for (uint32_t i = 0; i < BW; i += 64) bflat[i + lane] = i + lane < (n_r + 1) * T ? p.bounds[sl.bounds_off + i + lane] : 0u;
+    if (lane < n_r) rend[lane] = p.rdoc[sl.rdoc_off + lane + 1];
+  } else {
+    // The wave cuts its own slice (what partition_rounds_kernel does for every boundary of the batch,
+    // restricted to this slice's (rounds + 1) x lists boundaries): boundary j of the sub-query is the
+    // doc id at position j * stride of its longest list, every other list is cut at its first
+    // posting with doc >= that id.  The lines the searches fetch are the lines the rounds below
+    // load: on config 3 the separate kernel read every list but the longest a second time at
+    // scattered-access efficiency (1.6 ms per batch).
+    wave_fence();
+    const uint32_t lg = rfl(sl.longest), sq_rounds = rfl(sl.sq_rounds), r0 = rfl(sl.first_round);
+    const uint64_t l_off = ((uint64_t)rfl(off_hi[lg]) << 32) | rfl(off_lo[lg]);
+    const uint32_t l_df = rfl(dfs[lg]);
+    const uint32_t stride = (l_df + sq_rounds - 1u) / sq_rounds;
+    const float inv_t = 1.0f / (float)T;
+    for (uint32_t task = lane; task < (n_r + 1u) * T; task += 64u) {
+      const uint32_t i = (uint32_t)(((float)task + 0.5f) * inv_t);  // (exact: task < 128, T <= 8)
+      const uint32_t t = task - i * T;
+      const uint32_t j = r0 + i;
+      const uint64_t pos_l = (uint64_t)j * stride;
+      const bool first_b = j == 0u, last_b = j >= sq_rounds || pos_l >= l_df;
+      uint32_t target = 0;
+      if (!first_b && !last_b) target = gdocs[l_off + pos_l];
+      const uint32_t df_t = dfs[t];
+      uint32_t out;
+      if (first_b)
+        out = 0u;
+      else if (last_b)
+        out = df_t;
+      else if (t == lg)
+        out = (uint32_t)pos_l;
+      else
+        out = lower_bound_guess(gdocs + (((uint64_t)off_hi[t] << 32) | off_lo[t]), df_t, target, sd.n_docs);
+      bflat[task] = out;
+      // the end doc of round i - 1 (sentinels are 0xFFFFFFFF: never below it)
+      if (t == 0u && i >= 1u) rend[i - 1u] = last_b ? kDocEnd : target;
+    }
+  }
   wave_fence();
   auto list_off = [&](const uint32_t t) { return ((uint64_t)off_hi[t] << 32) | off_lo[t]; };
 
@@ -155,7 +193,9 @@ score_uniform4_kernel(RoundScoreParams p) {
   //      the first lane of lists 1..8 as bytes (127: no such list) and the lanes in use. ----
   auto boundary_byte = [&](const uint32_t u, const uint32_t first, const uint32_t used) {
     // the byte list u >= 1 contributes: its first lane; the idle entry (u == T) starts at `used`
-    return u < T ? (first < 127u ? first : 127u) : (u == T ? used : 127u);
+    // (127 - x with x selected against 0: no constant has to live in a register)
+    const uint32_t f = first < 127u ? first : 127u;
+    return 127u - (u < T ? 127u - f : (u == T ? 127u - used : 0u));
   };
   // ---- 8 consecutive planned rounds at once: lane 8 i + t = list t of round g0 + i -> row i ----
   // (rare paths take their own copy of the lane id through an empty asm: values derived from it are
@@ -268,8 +308,12 @@ score_uniform4_kernel(RoundScoreParams p) {
 
   // ---- candidates -> top-k (one take_checked site per source; BufTopK::compact is large) ----
   auto threshold_score = [&]() {  // score part of the current threshold as a float (-inf: none)
-    const uint32_t hi = (uint32_t)(btop.th >> 32);
-    return hi < 0x00800000u ? -INFINITY : key_to_float((int32_t)(hi ^ 0x80000000u));
+    // (uniform; the empty asm keeps the compare a 32-bit scalar one: folded into a 64-bit compare of
+    //  the whole threshold it runs on the vector unit against constants held in registers)
+    uint32_t hi = rfl((uint32_t)(btop.th >> 32));
+    asm volatile("" : "+s"(hi));
+    const uint32_t bits = hi < 0x00800000u ? 0xFF800000u : __float_as_uint(key_to_float((int32_t)(hi ^ 0x80000000u)));
+    return __uint_as_float(rfl(bits));
   };
   auto take_checked = [&](const bool cand, const float score, const uint32_t doc) {
     const uint32_t ok = ordered_score(score);

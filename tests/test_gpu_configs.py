@@ -68,14 +68,15 @@ def test_config3_full_size_properties(gpu, oracle):
 
 
 @pytest.mark.parametrize("tuning", [None, {"pruning": 1}, {"pruning": 1, "block_max": 0}, {"pruning": 0},
-                                    {"uniform_max_terms": 4}, {"uniform_kernel": 3}])
+                                    {"uniform_max_terms": 4}, {"uniform_kernel": 3}, {"inline_cuts": 0}])
 def test_five_terms_top100_pruned_kernel_small(gpu, oracle, tuning):
     """T = 5, k = 101 (two registers per lane) on a corpus small enough for the oracle to check
     every query: the kernel config 3 selects (None: score_uniform4_kernel<2, 8>, the planner drops the
     classification because block skipping has nothing to gain), the classified many-term kernel
     score_multi_kernel<2, 1> (pruning: 1), the unclassified one (uniform_max_terms: 4 -> <2, 0> is
     not reached: classification stays on; pruning: 0 with 8 lists -> few-term kernel), and the slot
-    form of the few-term kernel with 8-bit filter fields (uniform_kernel: 3)."""
+    form of the few-term kernel with 8-bit filter fields (uniform_kernel: 3); inline_cuts: 0 = cut points
+    from partition_rounds_kernel instead of the scoring waves' own."""
     from searchlite_amd import corpus
     seg = corpus.zipf_segment(300_000, 1 << 16, seed=43)
     offs, terms, w = corpus.zipf_queries(192, 5, rank_lo=8, rank_hi=4096, seed=7, vocab=1 << 16)
