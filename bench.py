@@ -340,6 +340,7 @@ def main():
             L.slh_first_result.restype = C.c_int
             L.slh_first_result.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
             L.slh_destroy.argtypes = [C.c_void_p]
+            L.slh_stats.argtypes = [C.c_void_p, C.c_void_p]
             self.L, self.C = L, C
             self.keep = [(np.ascontiguousarray(o, np.uint32), np.ascontiguousarray(t, np.uint32),
                           np.ascontiguousarray(w_, np.float32)) for o, t, w_ in qs]
@@ -358,11 +359,19 @@ def main():
             ok = self.L.slh_first_result(self.h, j, d.ctypes.data, s_.ctypes.data, sc.ctypes.data, c.ctypes.data)
             return (d, s_, sc, c) if ok else None
 
+        def stats(self):
+            import ctypes as C
+            out = (C.c_double * 4)()
+            self.L.slh_stats(self.h, out)
+            return {"prepare_ms": round(out[0], 4), "run_ms": round(out[1], 4), "fetch_ms": round(out[2], 4),
+                    "is": "mean time per batch a caller thread spends inside slg_batch_prepare / set_stream + run / "
+                          "fetch + destroy (warm-up included)"}
+
         def close(self):
             self.L.slh_destroy(self.h)
             self.h = None
 
-    value = ms_per_step = value_spread = None
+    value = ms_per_step = value_spread = host_ms = None
     if not rerank and not args.kernel_leg_only:
         pool = HostPool()
         # untimed: --warmup steps, and at least three batches per caller thread so that every
@@ -382,6 +391,7 @@ def main():
         hp0 = pool.first_result(0)
         if hp0 is not None:
             first_results[0] = hp0
+        host_ms = pool.stats()
         pool.close()
         elapsed = float(np.median(region_s))
         ms_per_step = elapsed / args.steps * 1e3
@@ -494,6 +504,7 @@ def main():
                                     if not rerank else
                                     "device-resident pipeline BM25 top-1000 -> rerank -> top-10 of pre-planned batches"),
                        "host_threads": None if rerank else n_thr,
+                       "host_call_ms": host_ms,
                        "host_warmup_steps": None if (rerank or args.kernel_leg_only) else host_warm,
                        "rotating_query_sets": n_sets,
                        "posting_working_set_bytes": int(8 * sum(i["n_postings"] for i in infos)),

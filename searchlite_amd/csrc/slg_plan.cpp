@@ -163,7 +163,31 @@ void plan_queries(const Pass1Ctx &c, const uint32_t q_lo, const uint32_t q_hi, P
   const uint32_t k = in.k;
   auto &sqs = o.sqs;
   auto &terms = o.terms;
+  sqs.reserve((size_t)(q_hi - q_lo) * n_segs);
+  terms.reserve((size_t)(in.q_offsets[q_hi] - in.q_offsets[q_lo]) * n_segs);
+  o.sq_postings.reserve(sqs.capacity());
+  o.sq_postings_all.reserve(sqs.capacity());
+  o.sq_longest_all.reserve(sqs.capacity());
+  // the champion table is tens of MB (config 2: 71 MB) and a query touches one line of it per term
+  // (cold for queries that were not planned just before): the lines of the query 8 ahead are
+  // requested while this one is planned
+  auto prefetch_query = [&](const uint32_t q) {
+    const uint32_t t0 = in.q_offsets[q], nt = in.q_offsets[q + 1] - t0;
+    for (uint32_t i = 0; i < nt; i++)
+      for (uint32_t s = 0; s < n_segs; s++) {
+        const uint32_t tid = in.q_term_ids[(size_t)(t0 + i) * n_segs + s];
+        const SegView &sh = c.segs[s];
+        if (tid == SLG_NO_TERM || tid >= sh.n_terms) continue;
+        __builtin_prefetch(&sh.term_offsets[tid]);
+        if (sh.champ && k <= 1024u) {
+          __builtin_prefetch(&sh.champ[(size_t)tid * slg::kChampions + slg::champ_index(k)]);
+          if (c.maxscore_on) __builtin_prefetch(&sh.champ[(size_t)tid * slg::kChampions]);
+        }
+      }
+  };
+  for (uint32_t q = q_lo; q < std::min(q_hi, q_lo + 8u); q++) prefetch_query(q);
   for (uint32_t q = q_lo; q < q_hi; q++) {
+    if (q + 8u < q_hi) prefetch_query(q + 8u);
     c.q_sq_begin[q] = (uint32_t)sqs.size();
     const uint32_t t0 = in.q_offsets[q], nt = in.q_offsets[q + 1] - t0;
     uint32_t fq = 0;  // doc filter of the query (0 none, id + 1)
@@ -238,8 +262,9 @@ void plan_queries(const Pass1Ctx &c, const uint32_t q_lo, const uint32_t q_hi, P
         // which the reference adds them, wand.rs:488-497; a group's leaves are consecutive, so the
         // lists are sorted by group too).  plan 0 = the flat term-order sum, which is what Sum
         // gives when no leaf holds two terms.
-        std::stable_sort(first, first + sq.n_terms,
-                         [](const slg::TermRef &a, const slg::TermRef &b) { return a.leaf < b.leaf; });
+        if (pl.q_leaf)  // (without leaves given, leaf = term position: already in order)
+          std::stable_sort(first, first + sq.n_terms,
+                           [](const slg::TermRef &a, const slg::TermRef &b) { return a.leaf < b.leaf; });
         bool shared = false;
         uint32_t present = 0;
         for (uint32_t i = 0; i < sq.n_terms; i++) {
@@ -328,8 +353,8 @@ uint32_t uniform_round_target(const slg::RoundQuery &sq, const slg::TermRef *t, 
     // has 64 lanes.  ceil(c / 8) has mean c/8 + 7/16 and variance c/64 + 1/12 (c roughly Poisson)
     dflt = (uint32_t)slg::kUniCap;
     if (!tn.uniform_round_target && n > 1) {
-      uint32_t best = 64;
-      for (uint32_t R = 96; R <= (uint32_t)slg::kUniCap; R += 8) {
+      // lanes a round of R postings is expected to need, plus `sigmas` standard deviations
+      auto lanes_needed = [&](const uint32_t R) {
         double mu = 0.0, var = 0.0;
         for (uint32_t j = 0; j < n; j++) {
           const double c = (double)R * (double)t[j].df / Pd;
@@ -340,10 +365,25 @@ uint32_t uniform_round_target(const slg::RoundQuery &sq, const slg::TermRef *t, 
             var += c / 64.0 + 1.0 / 12.0;
           }
         }
-        if (mu + sigmas * std::sqrt(var) > 64.3) break;
-        best = R;
+        return mu + sigmas * std::sqrt(var);
+      };
+      // the largest R (steps of 8) that stays under 64.3 lanes.  With f = the longest list's share of
+      // the postings: mu ~ R/8 + b, var = c R + d (b = 7/16 (n-1) + 1/2, c = (1-f)/64, d = (n-1)/12);
+      // R/8 + b + s sqrt(c R + d) = 64.3 is a quadratic in y = sqrt(c R + d); the root is then
+      // corrected against the exact count (the ceil) in steps of 8 — usually two evaluations (a scan
+      // over all 53 candidates cost 70 ms of planning on config 4's 65 536 sub-queries)
+      const double f = (double)t[sq.longest].df / Pd;
+      const double b = 7.0 / 16.0 * (n - 1) + 0.5, c = (1.0 - f) / 64.0, d = (n - 1) / 12.0;
+      double x = (64.3 - b) * 8.0;
+      if (c > 1e-9) {
+        const double qa = 1.0 / (8.0 * c), qc = b - 64.3 - d / (8.0 * c);
+        const double y = (-sigmas + std::sqrt(sigmas * sigmas - 4.0 * qa * qc)) / (2.0 * qa);
+        x = (y * y - d) / c;
       }
-      dflt = best;
+      uint32_t R = (uint32_t)std::min(std::max(x, 64.0), (double)slg::kUniCap) & ~7u;
+      while (R > 64 && lanes_needed(R) > 64.3) R -= 8;
+      while (R + 8 <= (uint32_t)slg::kUniCap && lanes_needed(R + 8) <= 64.3) R += 8;
+      dflt = R;
     }
   } else {
     dflt = 64u * (slg::kUniSlots > (int)n ? slg::kUniSlots - n : 0u) + 64u;
@@ -406,12 +446,33 @@ void plan_rounds(const std::vector<SegView> &segs, const slg_tuning &tn, uint32_
                                        : (out.uniform && !blocked8 ? 8u : (uint32_t)slg::kMaxRoundsPerSlice));
   const uint32_t slices_per_sq = tn.slices_per_subquery;
   const bool slice_lists = !out.cand_mode;
+  // the round targets are independent per sub-query: large batches (config 4: 65 536 sub-queries)
+  // compute them on several threads; the offsets below are a serial prefix
+  std::vector<uint32_t> targets(sqs.size());
+  {
+    auto fill = [&](size_t a, size_t b) {
+      for (size_t i = a; i < b; i++) {
+        const slg::RoundQuery &sq = sqs[i];
+        const slg::TermRef *t = out.terms.data() + sq.term_begin;
+        targets[i] = out.uniform ? uniform_round_target(sq, t, sq_postings[i], tn)
+                                 : multi_round_target(sq_postings[i], segs[sq.seg].n_docs, tn);
+      }
+    };
+    const size_t n_thr = sqs.size() >= 8192 ? std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    if (n_thr <= 1) {
+      fill(0, sqs.size());
+    } else {
+      std::vector<std::thread> pool;
+      for (size_t th = 0; th < n_thr; th++)
+        pool.emplace_back(fill, sqs.size() * th / n_thr, sqs.size() * (th + 1) / n_thr);
+      for (auto &th : pool) th.join();
+    }
+  }
   for (size_t i = 0; i < sqs.size(); i++) {
     slg::RoundQuery &sq = sqs[i];
     const slg::TermRef *t = out.terms.data() + sq.term_begin;
     const uint32_t dfL = t[sq.longest].df;
-    const uint32_t round_target = out.uniform ? uniform_round_target(sq, t, sq_postings[i], tn)
-                                              : multi_round_target(sq_postings[i], segs[sq.seg].n_docs, tn);
+    const uint32_t round_target = targets[i];
     // a round holds <= ~round_target postings of the essential lists (register slots) and
     // <= ~probe_target postings overall (non-essential lists are streamed per round), so
     // slices stay balanced whatever the mix

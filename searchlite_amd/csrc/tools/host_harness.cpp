@@ -11,11 +11,13 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstring>
 #include <deque>
 #include <mutex>
+#include <algorithm>
 #include <string>
 #include <thread>
 #include <vector>
@@ -48,6 +50,8 @@ struct Harness {
   std::condition_variable done_cv;
   int64_t done = 0;
   std::string error;
+  // time the caller threads spent inside the C ABI, summed over all batches (ns) and their count
+  std::atomic<uint64_t> ns_prepare{0}, ns_run{0}, ns_fetch{0}, n_timed{0};
   // results of the first batch of every query set (bench.py compares them with the other legs)
   std::vector<std::vector<uint32_t>> first_doc, first_seg, first_count;
   std::vector<std::vector<float>> first_score;
@@ -62,8 +66,10 @@ struct Pending {
 void collect(Harness *h, Pending &p, std::vector<uint32_t> &doc, std::vector<uint32_t> &seg,
              std::vector<float> &score, std::vector<uint32_t> &count) {
   if (!p.b) return;
+  const auto t0 = std::chrono::steady_clock::now();
   const int rc = slg_batch_fetch(p.b, doc.data(), seg.data(), score.data(), count.data(), nullptr);
   slg_batch_destroy(p.b);
+  h->ns_fetch += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
   const size_t set = (size_t)(p.step % (int64_t)h->sets.size());
   {
     std::lock_guard<std::mutex> lk(h->done_mu);
@@ -105,10 +111,16 @@ void worker_main(Harness *h, Worker *w) {
       continue;
     }
     const QuerySet &qs = h->sets[(size_t)(step % (int64_t)h->sets.size())];
+    const auto t0 = std::chrono::steady_clock::now();
     slg_batch *b = slg_batch_prepare(h->ix, h->nq, qs.offs, qs.terms, qs.w, h->k, h->strategy);
+    const auto t1 = std::chrono::steady_clock::now();
     int rc = b ? SLG_OK : slg_last_error_code();
     if (b) rc = slg_batch_set_stream(b, (void *)w->streams[lap++ & 1u]);
     if (b && rc == SLG_OK) rc = slg_batch_run(b);
+    const auto t2 = std::chrono::steady_clock::now();
+    h->ns_prepare += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+    h->ns_run += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count();
+    h->n_timed++;
     if (rc != SLG_OK) {
       std::lock_guard<std::mutex> lk(h->done_mu);
       if (h->error.empty()) h->error = std::string("prepare/run: ") + slg_last_error();
@@ -184,6 +196,16 @@ int slh_run(void *hp, int64_t first, int64_t n_steps) {
   std::unique_lock<std::mutex> lk(h->done_mu);
   h->done_cv.wait(lk, [&] { return h->done >= target; });
   return h->error.empty() ? 0 : -1;
+}
+
+// mean time per batch a caller thread spent in prepare / set_stream + run / fetch + destroy (ms), batches timed
+void slh_stats(void *hp, double *out4) {
+  auto *h = static_cast<Harness *>(hp);
+  const double n = (double)std::max<uint64_t>(1, h->n_timed.load());
+  out4[0] = (double)h->ns_prepare.load() / n * 1e-6;
+  out4[1] = (double)h->ns_run.load() / n * 1e-6;
+  out4[2] = (double)h->ns_fetch.load() / n * 1e-6;
+  out4[3] = (double)h->n_timed.load();
 }
 
 const char *slh_error(void *hp) { return static_cast<Harness *>(hp)->error.c_str(); }
