@@ -103,7 +103,9 @@ struct SliceDesc {
   uint32_t cand_lo, cand_hi;
   // for waves that cut their slice themselves (slg_score_uni4.hpp with RoundScoreParams::bounds ==
   // nullptr): the slice's first round, the sub-query's rounds, its splitter list
-  uint32_t first_round, sq_rounds, longest, pad_;
+  uint32_t first_round, sq_rounds, longest;
+  uint32_t l_df;   // the splitter list's length and posting offset: its stride positions are read
+  uint64_t l_off;  // straight off this record, beside the TermRef loads instead of behind them
 };
 
 struct QueryRef {

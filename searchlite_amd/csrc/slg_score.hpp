@@ -131,7 +131,11 @@ static __global__ void __launch_bounds__(256) partition_rounds_kernel(RoundPartP
     d.first_round = r0;
     d.sq_rounds = s.n_rounds;
     d.longest = s.longest;
-    d.pad_ = 0;
+    {
+      const TermRef L = p.terms[s.term_begin + s.longest];
+      d.l_df = L.df;
+      d.l_off = L.off;
+    }
     p.slice_desc[gid] = d;
   }
   const uint32_t tpb = 1u << p.tpb_shift;

@@ -107,38 +107,55 @@ score_uniform4_kernel(RoundScoreParams p) {
   // where round r starts in list t); the end doc of every round
   uint32_t *const bflat = reinterpret_cast<uint32_t *>(smem + u4_plan_off(KREGS, FW));
   uint32_t *const off_lo = bflat + BW, *const off_hi = off_lo + ML, *const wts = off_hi + ML, *const dfs = wts + ML;
+  const bool inline_cuts = p.bounds == nullptr;
+  TermRef tr{};
+  if (lane < T) tr = p.terms[sl.term_begin + lane];
+  // The wave cuts its own slice (what partition_rounds_kernel does for every boundary of the batch,
+  // restricted to this slice's (rounds + 1) x lists boundaries): boundary j of the sub-query is the
+  // doc id at position j * stride of its longest list, every other list is cut at its first
+  // posting with doc >= that id.  The lines the searches fetch are the lines the rounds below
+  // load: on config 3 the separate kernel read every list but the longest a second time at
+  // scattered-access efficiency (1.6 ms per batch).
+  const uint32_t lg = rfl(sl.longest), sq_rounds = rfl(sl.sq_rounds), r0 = rfl(sl.first_round);
+  const uint64_t l_off = ((uint64_t)rfl((uint32_t)(sl.l_off >> 32)) << 32) | rfl((uint32_t)sl.l_off);
+  const uint32_t l_df = rfl(sl.l_df);
+  const uint32_t stride = inline_cuts ? (l_df + sq_rounds - 1u) / sq_rounds : 0u;
+  const float inv_t = 1.0f / (float)T;
+  // (the boundary docs are loaded straight off the slice record, beside the TermRef loads)
+  constexpr int NTASK = (int)(BW / 64u);
+  uint32_t tgt[NTASK];
+  if (inline_cuts) {
+#pragma unroll
+    for (int u = 0; u < NTASK; u++) {
+      const uint32_t task = lane + 64u * u;
+      const uint32_t i = (uint32_t)(((float)task + 0.5f) * inv_t);  // (exact: task < 128, T <= 8)
+      const uint64_t pos_l = (uint64_t)(r0 + i) * stride;
+      const bool mid = task < (n_r + 1u) * T && r0 + i != 0u && r0 + i < sq_rounds && pos_l < l_df;
+      tgt[u] = mid ? gdocs[l_off + pos_l] : 0u;
+    }
+  }
   if (lane < T) {
-    const TermRef tr = p.terms[sl.term_begin + lane];
     wts[lane] = __float_as_uint(tr.weight);
     off_lo[lane] = (uint32_t)tr.off;
     off_hi[lane] = (uint32_t)(tr.off >> 32);
     dfs[lane] = tr.df;
   }
-  if (p.bounds != nullptr) {  // cut points from partition_rounds_kernel
+  if (!inline_cuts) {  // cut points from partition_rounds_kernel
 #pragma unroll
     for (uint32_t i = 0; i < BW; i += 64) bflat[i + lane] = i + lane < (n_r + 1) * T ? p.bounds[sl.bounds_off + i + lane] : 0u;
     if (lane < n_r) rend[lane] = p.rdoc[sl.rdoc_off + lane + 1];
   } else {
-    // The wave cuts its own slice (what partition_rounds_kernel does for every boundary of the batch,
-    // restricted to this slice's (rounds + 1) x lists boundaries): boundary j of the sub-query is the
-    // doc id at position j * stride of its longest list, every other list is cut at its first
-    // posting with doc >= that id.  The lines the searches fetch are the lines the rounds below
-    // load: on config 3 the separate kernel read every list but the longest a second time at
-    // scattered-access efficiency (1.6 ms per batch).
     wave_fence();
-    const uint32_t lg = rfl(sl.longest), sq_rounds = rfl(sl.sq_rounds), r0 = rfl(sl.first_round);
-    const uint64_t l_off = ((uint64_t)rfl(off_hi[lg]) << 32) | rfl(off_lo[lg]);
-    const uint32_t l_df = rfl(dfs[lg]);
-    const uint32_t stride = (l_df + sq_rounds - 1u) / sq_rounds;
-    const float inv_t = 1.0f / (float)T;
-    for (uint32_t task = lane; task < (n_r + 1u) * T; task += 64u) {
-      const uint32_t i = (uint32_t)(((float)task + 0.5f) * inv_t);  // (exact: task < 128, T <= 8)
+#pragma unroll
+    for (int u = 0; u < NTASK; u++) {
+      const uint32_t task = lane + 64u * u;
+      if (task >= (n_r + 1u) * T) continue;
+      const uint32_t i = (uint32_t)(((float)task + 0.5f) * inv_t);
       const uint32_t t = task - i * T;
       const uint32_t j = r0 + i;
       const uint64_t pos_l = (uint64_t)j * stride;
       const bool first_b = j == 0u, last_b = j >= sq_rounds || pos_l >= l_df;
-      uint32_t target = 0;
-      if (!first_b && !last_b) target = gdocs[l_off + pos_l];
+      const uint32_t target = tgt[u];
       const uint32_t df_t = dfs[t];
       uint32_t out;
       if (first_b)
