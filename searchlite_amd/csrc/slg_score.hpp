@@ -44,23 +44,23 @@ struct RoundPartParams {
   uint32_t tpb_shift;  // log2(threads per boundary): 2 when no sub-query has more than 4 lists, else 3
 };
 
-// first index of d[0, df) with d[idx] >= target, looked for in the 128 postings from `a` on: nine
+// first index of d[0, df) with d[idx] >= target, looked for in the 16 NP postings from `a` on: NP + 1
 // pivots 16 postings apart (independent loads, one latency) bracket it to 16 postings, which are then
 // read whole (one more latency) — two dependent loads instead of a bisection's ~8; false if the
 // answer lies outside the window.  The list is
 // followed by kListPad sentinels (0xFFFFFFFF), so positions up to df + 63 may be read.
-template <typename DocPtr>
+template <int NP = 8, typename DocPtr>
 __device__ __forceinline__ bool lower_bound_window(const DocPtr d, uint32_t df, uint32_t target, uint32_t a,
                                                    uint32_t &pos) {
-  uint32_t below = 0;  // pivots d[a + 16 i - 1], i = 0..8, that are < target (i = 0 at a == 0: -inf)
+  uint32_t below = 0;  // pivots d[a + 16 i - 1], i = 0..NP, that are < target (i = 0 at a == 0: -inf)
 #pragma unroll
-  for (uint32_t i = 0; i <= 8; i++) {
+  for (uint32_t i = 0; i <= (uint32_t)NP; i++) {
     const uint32_t at = a + 16u * i;
     const uint32_t idx = at - 1u < df ? at - 1u : df;  // (past the end: the first sentinel)
     const uint32_t v = d[at == 0u ? 0u : idx];
     below += (at == 0u || v < target) ? 1u : 0u;
   }
-  if (below < 1u || below > 8u) return false;
+  if (below < 1u || below > (uint32_t)NP) return false;
   const uint32_t base = a + 16u * (below - 1u);  // d[base - 1] < target <= d[base + 15]
   uint32_t cnt = 0;
 #pragma unroll
@@ -78,7 +78,7 @@ __device__ __forceinline__ uint32_t lower_bound_guess(const DocPtr d, uint32_t d
   uint32_t g = (uint32_t)(((uint64_t)df * target) / (n_docs ? n_docs : 1u));
   g = g < df ? g : df;
   uint32_t lo = 0, hi = df;
-  if (lower_bound_window(d, df, target, g > 64u ? g - 64u : 0u, lo)) return lo;
+  if (lower_bound_window<8>(d, df, target, g > 64u ? g - 64u : 0u, lo)) return lo;
   lo = 0;
   for (uint64_t w = 512; w < df; w <<= 3) {
     const uint32_t a = g > w ? (uint32_t)(g - w) : 0u;

@@ -49,6 +49,9 @@ constexpr int u4_wave_lds(int kregs, int ml, int fw) { return u4_tbl_off(kregs, 
 #ifndef SLG_U4_FW8
 #define SLG_U4_FW8 1024  // filter words of the 5..8-list form (2048 at 4 waves: 6.37 vs 5.68 ms on config 3)
 #endif
+#ifndef SLG_U4_TWO_PHASE_MIN
+#define SLG_U4_TWO_PHASE_MIN 9  // slices of this many rounds cut their inner boundaries by interpolation
+#endif
 #ifndef SLG_U4_JOIN_PAIRS
 #define SLG_U4_JOIN_PAIRS 64
 #endif
@@ -146,29 +149,71 @@ score_uniform4_kernel(RoundScoreParams p) {
     if (lane < n_r) rend[lane] = p.rdoc[sl.rdoc_off + lane + 1];
   } else {
     wave_fence();
+    // the boundaries' docs: rend[i - 1] = end doc of round i - 1 (sentinels are 0xFFFFFFFF: never below
+    // kDocEnd); rend[kMaxRoundsPerSlice + 1] = the doc the slice starts at
+    uint32_t *const row0_doc = rend + kMaxRoundsPerSlice + 1;
+#pragma unroll
+    for (int u = 0; u < NTASK; u++) {
+      const uint32_t task = lane + 64u * u;
+      const uint32_t i = (uint32_t)(((float)task + 0.5f) * inv_t);
+      const uint64_t pos_l = (uint64_t)(r0 + i) * stride;
+      const bool last_b = r0 + i >= sq_rounds || pos_l >= l_df;
+      if (task < (n_r + 1u) * T && task == i * T) {
+        if (i >= 1u)
+          rend[i - 1u] = last_b ? kDocEnd : tgt[u];
+        else
+          *row0_doc = tgt[u];  // (0 for the sub-query's first boundary)
+      }
+    }
+    // one boundary of one list: first posting with doc >= the boundary's doc
+    auto cut_one = [&](const uint32_t i, const uint32_t t, const uint32_t target, const bool inner) {
+      const uint32_t j = r0 + i;
+      const uint64_t pos_l = (uint64_t)j * stride;
+      const bool first_b = j == 0u, last_b = j >= sq_rounds || pos_l >= l_df;
+      const uint32_t df_t = dfs[t];
+      if (first_b) return 0u;
+      if (last_b) return df_t;
+      if (t == lg) return (uint32_t)pos_l;
+      const gu32_t d = gdocs + (((uint64_t)off_hi[t] << 32) | off_lo[t]);
+      if (!inner) return lower_bound_guess(d, df_t, target, sd.n_docs);
+      // between the slice's own first and last cut points the postings are spread evenly enough for a
+      // 64-posting window around the interpolated position (half the lines of the global guess's
+      // window; a miss bisects between the two known cuts)
+      uint32_t lo = bflat[t], hi = bflat[n_r * T + t];
+      const uint32_t d0 = *row0_doc, d1e = rend[n_r - 1u];
+      const uint32_t d1 = d1e < sd.n_docs ? d1e : sd.n_docs;
+      const float fr = d1 > d0 ? (float)(target - d0) / (float)(d1 - d0) : 0.0f;
+      uint32_t g = lo + (uint32_t)((float)(hi - lo) * fr);
+      g = g < hi ? g : hi;
+      uint32_t pos;
+      if (lower_bound_window<4>(d, df_t, target, g > lo + 32u ? g - 32u : lo, pos)) return pos;
+      while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (d[mid] < target)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      return lo;
+    };
+    const bool two_phase = n_r >= (uint32_t)SLG_U4_TWO_PHASE_MIN;
+    if (two_phase) {
+      wave_fence();
+      if (lane < 2u * T) {  // the slice's first and last boundary, every list
+        const uint32_t t = lane < T ? lane : lane - T, i = lane < T ? 0u : n_r;
+        const uint32_t target = i == 0u ? *row0_doc : rend[n_r - 1u];
+        bflat[i * T + t] = cut_one(i, t, target, false);
+      }
+      wave_fence();
+    }
 #pragma unroll
     for (int u = 0; u < NTASK; u++) {
       const uint32_t task = lane + 64u * u;
       if (task >= (n_r + 1u) * T) continue;
       const uint32_t i = (uint32_t)(((float)task + 0.5f) * inv_t);
       const uint32_t t = task - i * T;
-      const uint32_t j = r0 + i;
-      const uint64_t pos_l = (uint64_t)j * stride;
-      const bool first_b = j == 0u, last_b = j >= sq_rounds || pos_l >= l_df;
-      const uint32_t target = tgt[u];
-      const uint32_t df_t = dfs[t];
-      uint32_t out;
-      if (first_b)
-        out = 0u;
-      else if (last_b)
-        out = df_t;
-      else if (t == lg)
-        out = (uint32_t)pos_l;
-      else
-        out = lower_bound_guess(gdocs + (((uint64_t)off_hi[t] << 32) | off_lo[t]), df_t, target, sd.n_docs);
-      bflat[task] = out;
-      // the end doc of round i - 1 (sentinels are 0xFFFFFFFF: never below it)
-      if (t == 0u && i >= 1u) rend[i - 1u] = last_b ? kDocEnd : target;
+      if (two_phase && (i == 0u || i == n_r)) continue;
+      bflat[task] = cut_one(i, t, tgt[u], two_phase);
     }
   }
   wave_fence();
