@@ -532,8 +532,23 @@ __global__ void __launch_bounds__(256) rerank_multi_kernel(RerankMultiParams mp)
     return off == 0xFFFFFFFFu ? nullptr : vd.values + (size_t)off * dim;
   };
 
-  if (metric == 0 && (dim & 15u) == 0) {
-    // ---- cosine on the matrix cores: tiles of 16 candidates, round-robin over the 4 waves.
+  // L2 with >= 3 clauses also runs its products on the matrix cores: |q - x|^2 = |q|^2 + |x|^2 - 2 q.x
+  // (|x|^2 from the row pieces a lane holds anyway, |q|^2 once per clause).  The identity cancels for
+  // near-duplicate vectors, so a pair whose distance comes out below 5 % of |q|^2 + |x|^2 is
+  // recomputed as the plain sum of squared differences (vectors/mod.rs:98-105) by the whole wave.
+  const bool l2_mfma = metric != 0 && NC >= 3u && (dim & 15u) == 0;
+  float *s_qq = s_vsum + p.max_cand;  // [NC] squared norms of the clause vectors (l2_mfma)
+  if (l2_mfma) {
+    for (uint32_t cc = wave; cc < NC; cc += 4) {
+      float a = 0.0f;
+      for (uint32_t i = lane; i < dim; i += 64) a = __builtin_fmaf(s_q[cc * qs + i], s_q[cc * qs + i], a);
+      const float t = wave_sum_f(a);
+      if (lane == 0) s_qq[cc] = t;
+    }
+    __syncthreads();
+  }
+  if ((metric == 0 || l2_mfma) && (dim & 15u) == 0) {
+    // ---- cosine (and many-clause L2) on the matrix cores: tiles of 16 candidates, round-robin over the 4 waves.
     //      Row loads go through global-address-space pointers (a pointer read from memory is
     //      generic: flat loads would share the LDS counter with the clause-vector reads), a
     //      candidate without a vector reads the query (its products are never used), four
@@ -546,6 +561,8 @@ __global__ void __launch_bounds__(256) rerank_multi_kernel(RerankMultiParams mp)
     const float *nrow = row_of(wave * 16 + cl);
     for (uint32_t t0 = wave * 16; t0 < n; t0 += 64) {
       const grow_t row = (grow_t)(nrow ? nrow : dummy);
+      const bool has_row = nrow != nullptr;
+      float xx = 0.0f;  // l2_mfma: squared norm of the pieces of my candidate's row that I hold
       f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
       uint32_t kb = g;  // in units of 4 floats; lane g takes pieces g, g + 4, ...
       const uint32_t kend = dim >> 2;
@@ -567,18 +584,57 @@ __global__ void __launch_bounds__(256) rerank_multi_kernel(RerankMultiParams mp)
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+          if (l2_mfma)
+            xx = __builtin_fmaf(a.x, a.x, __builtin_fmaf(a.y, a.y, __builtin_fmaf(a.z, a.z, __builtin_fmaf(a.w, a.w, xx))));
         };
         step(c0, kb);
         if (kb + 4 < kend) step(c1, kb + 4);
         if (kb + 8 < kend) step(c2, kb + 8);
         if (kb + 12 < kend) step(c3, kb + 12);
       }
-      if (cl < NC) {  // lane holds D[candidate t0 + 4g + r][clause cl]
+      if (!l2_mfma) {
+        if (cl < NC) {  // lane holds D[candidate t0 + 4g + r][clause cl]
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const uint32_t c = t0 + 4 * g + r;
+            const float d = acc[r];
+            if (c < n) s_vs[cl * p.max_cand + c] = d != d ? 0.0f : d;  // vectors/mod.rs:112-116 NaN -> 0
+          }
+        }
+      } else {
+        // |x|^2 of candidate t0 + cl: the four lanes of its column hold a quarter of the row each
+        xx += __shfl_xor(xx, 16, 64);
+        xx += __shfl_xor(xx, 32, 64);
+        const float qq = s_qq[cl < NC ? cl : 0u];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const uint32_t c = t0 + 4 * g + r;
-          const float d = acc[r];
-          if (c < n) s_vs[cl * p.max_cand + c] = d != d ? 0.0f : d;  // vectors/mod.rs:112-116 NaN -> 0
+          const float xc = __shfl(xx, (int)(4 * g + r), 64);
+          const bool hc = __shfl((int)has_row, (int)(4 * g + r), 64) != 0;
+          const float ssum = qq + xc;
+          const float d2 = ssum - 2.0f * acc[r];
+          const bool mine = cl < NC && c < n && hc;
+          const bool near = mine && !(d2 >= 0.05f * ssum);  // (also: NaN)
+          if (mine && !near) s_vs[cl * p.max_cand + c] = -sqrtf(d2);
+          // near-duplicates: the exact sum, one pair at a time, all 64 lanes on it
+          uint64_t todo = __ballot(near);
+          while (todo) {
+            const uint32_t l = (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t pc = t0 + 4 * (l >> 4) + r, pcl = l & 15u;  // the pair's candidate and clause
+            const uint32_t src = pc - t0;                              // a lane that holds its row pointer
+            const uint64_t rp = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)((uint64_t)(uintptr_t)row >> 32), (int)src) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uintptr_t)row, (int)src);
+            typedef const __attribute__((address_space(1))) float *gf_t;
+            const gf_t prow = (gf_t)(uintptr_t)rp;
+            float a = 0.0f;
+            for (uint32_t i = lane; i < dim; i += 64) {
+              const float df = s_q[pcl * qs + i] - prow[i];
+              a += df * df;
+            }
+            const float t = wave_sum_f(a);
+            if (lane == 0) s_vs[pcl * p.max_cand + pc] = -sqrtf(t);
+          }
         }
       }
     }
@@ -808,7 +864,7 @@ inline size_t rerank_fields_lds_floats(uint32_t n_clauses, uint32_t q_floats, ui
 }
 
 inline size_t rerank_multi_lds_floats(uint32_t n_clauses, uint32_t dim, uint32_t max_cand) {
-  return (size_t)n_clauses * (dim + 4) + (size_t)n_clauses * max_cand + 2 * (size_t)max_cand;
+  return (size_t)n_clauses * (dim + 4) + (size_t)n_clauses * max_cand + 2 * (size_t)max_cand + 8;  // (+ clause norms)
 }
 
 template <typename K, typename P>

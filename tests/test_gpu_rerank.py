@@ -207,6 +207,54 @@ def test_rerank_multi_clause(oracle, n_clauses, metric):
                 TOL = tol_save
 
 
+@pytest.mark.parametrize("n_clauses", [3, 4, 8])
+def test_rerank_l2_on_the_matrix_cores_with_near_duplicates(oracle, n_clauses):
+    """L2 with >= 3 clauses computes |q - x|^2 = |q|^2 + |x|^2 - 2 q.x on the matrix cores; the
+    identity cancels when a candidate is (nearly) the query vector, so such pairs are recomputed as the
+    plain sum of squared differences (vectors/mod.rs:98-105).  Candidates here include exact copies
+    of a clause vector, copies with 1e-4 / 1e-2 noise, scaled copies and ordinary vectors; non-unit
+    norms on both sides."""
+    import searchlite_amd as sa
+    from searchlite_amd import corpus
+    rng = np.random.default_rng(500 + n_clauses)
+    n, dim, ncand, k_out, nq = 3000, 768, 601, 10, 4
+    vals = (corpus.unit_vectors(n, dim, seed=31) * rng.uniform(0.5, 3.0, size=(n, 1))).astype(np.float32)
+    q = (corpus.unit_vectors(nq * n_clauses, dim, seed=32) * 1.7).astype(np.float32).reshape(nq, n_clauses, dim)
+    for i in range(nq):  # plant near-duplicates of the query's clause vectors among the rows
+        for c in range(n_clauses):
+            base = 40 * i + 8 * (c % 5)
+            vals[base] = q[i, c]
+            vals[base + 1] = q[i, c] + rng.normal(0, 1e-4, dim).astype(np.float32)
+            vals[base + 2] = q[i, c] + rng.normal(0, 1e-2, dim).astype(np.float32)
+            vals[base + 3] = q[i, c] * np.float32(1.001)
+    offsets = np.arange(n, dtype=np.uint32)
+    offsets[rng.choice(np.arange(200, n), size=100, replace=False)] = 0xFFFFFFFF
+    cand = np.stack([np.concatenate([np.arange(40 * i, 40 * i + 40), rng.choice(np.arange(200, n), size=ncand - 40,
+                                                                                 replace=False)])
+                     for i in range(nq)]).astype(np.uint32)
+    bm = (rng.random((nq, ncand)) * 5).astype(np.float32)
+    cnt = np.full(nq, ncand, np.uint32)
+    alpha = rng.choice(np.array([0.0, 0.3, 0.7], np.float32), size=(nq, n_clauses))
+    seg = _segment_with_vectors(n, offsets, vals, 1)
+    with sa.GpuIndex([seg]) as ix:
+        got = ix.rerank_multi_batch(q, alpha, cand, np.zeros_like(cand), bm, cnt, k_out)
+    wd, ws, wv = [], [], []
+    for i in range(nq):
+        d_, s_, v_ = oracle.rerank_multi(1, offsets, vals, q[i], alpha[i], cand[i], bm[i], k_out)
+        wd.append(d_)
+        ws.append(s_)
+        wv.append(v_)
+    global TOL
+    tol_save = TOL
+    # per clause: the identity's rounding is ~1e-6 (|q|^2 + |x|^2) / (2 d); d >= 0.22 sqrt(|q|^2 + |x|^2) off
+    # the exact path, norms up to 3: within 1e-5 per clause; the vector score sums the clauses
+    TOL = 1e-5 * n_clauses
+    try:
+        _check(got, wd, ws, wv, f"L2 on MFMA, {n_clauses} clauses, near-duplicates")
+    finally:
+        TOL = tol_save
+
+
 @pytest.mark.parametrize("dim", [16, 48, 100, 400, 1100])
 @pytest.mark.parametrize("metric", [0, 1])
 def test_rerank_multi_clause_dims(oracle, dim, metric):

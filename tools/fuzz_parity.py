@@ -3,7 +3,8 @@ tombstones, doc filters, score plans and strategies, each batch compared bit for
 oracle.  usage: python tools/fuzz_parity.py [iterations] [seed]
 (SLG_MAXSCORE=1 / SLG_UNIFORM_MAX_TERMS=0 in the environment force pruning / the many-term kernel;
 FUZZ_MANY_LISTS=1 draws MaxScore-classified queries of 14..32 lists instead; FUZZ_TREES=1 turns the
-score plans of the standard cases into random two-level trees.)"""
+score plans of the standard cases into random two-level trees; FUZZ_FEW_LISTS=1 keeps every query at
+<= 8 lists without plans, so every batch runs on the few-term kernel.)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -38,10 +39,14 @@ def run_case(seed0, it, tuning=None):
           segs.append(sg)
       nq = int(rng.integers(1, 24))
       k = int(rng.choice([1, 2, 11, 64, 65, 101, 256, 257, 600, 1024, 1025, 3000]))
+      FEW = os.environ.get("FUZZ_FEW_LISTS", "0") != "0"
+      frng = np.random.default_rng(seed0 * 1000033 + it + 5)
       offs, terms, w, leaf, plan, tie, nl = [0], [], [], [], [], [], []
       V = vocab * F
       for q in range(nq):
           T = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 8, 13, 32], p=[.03, .1, .1, .2, .12, .12, .1, .1, .08, .05]))
+          if FEW:  # every batch on the few-term kernel: <= 8 lists, no plans (drawn from a generator of its own)
+              T = int(frng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8], p=[.03, .07, .1, .2, .1, .15, .1, .1, .15]))
           T = min(T, V)
           ids = rng.choice(V, size=T, replace=False)
           lf = np.sort(rng.integers(0, max(1, T // 2 + 1), size=T)) if rng.random() < 0.5 else np.arange(T)
@@ -63,7 +68,7 @@ def run_case(seed0, it, tuning=None):
       offs = np.array(offs, dtype=np.uint32)
       terms = np.array(terms, dtype=np.uint32).reshape(-1, n_segs)
       w = np.array(w, dtype=np.float32)
-      use_plan = rng.random() < 0.6
+      use_plan = rng.random() < 0.6 and not FEW
       kw = dict(q_leaf=np.array(leaf, dtype=np.uint32), q_plan=np.array(plan, dtype=np.int32),
                 q_tie=np.array(tie, dtype=np.float32), q_nleaves=np.array(nl, dtype=np.uint32)) if use_plan else {}
       if use_plan and os.environ.get("FUZZ_TREES", "0") != "0":
