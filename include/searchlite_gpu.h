@@ -183,11 +183,9 @@ typedef struct {
                                     round-2 kernel, <= 4 lists (both kept for A/B timing on one device) */
   uint32_t uniform_sigma_x100;   /* SLG_UNIFORM_SIGMA (0 = 160): the few-term planner keeps a round's
                                     expected lanes (slots) + this many hundredths of a sigma under 64.3 (8.3) */
-  int32_t inline_cuts;           /* SLG_INLINE_CUTS (-1 = auto: 2): how the blocked few-term kernel gets its rounds'
-                                    cut points.  2: its waves cut their slices themselves at aligned blocks of
-                                    8 postings, searching the per-block first doc ids; 1: themselves, at exact
-                                    postings (searches in the posting array); 0: reads what
-                                    partition_rounds_kernel wrote for the whole batch */
+  int32_t inline_cuts;           /* SLG_INLINE_CUTS (-1 = auto: on): the blocked few-term kernel cuts the lists at
+                                    its slice's round boundaries itself instead of reading cut points that
+                                    partition_rounds_kernel wrote for the whole batch; 0 off; 1 on */
 } slg_tuning;
 void slg_tuning_default(slg_tuning *out);
 slg_index *slg_index_create_tuned(const slg_segment_desc *segs, uint32_t n_segs, int device,

@@ -254,7 +254,7 @@ struct SegHost {
   uint64_t null_idx = 0;               // SegDev::null_idx
   std::vector<uint64_t> term_offsets;  // as given (unpadded); device position = + kListPad * term
   std::vector<float> champ;  // host mirror of d_champ [V * kChampions] (query planning)
-  DevBuf d_docs, d_imps, d_deleted, d_champ, d_docs8;
+  DevBuf d_docs, d_imps, d_deleted, d_champ;
   // vectors
   uint32_t vec_dim = 0, vec_rows = 0;
   int32_t vec_metric = 0;
@@ -574,17 +574,6 @@ void stage_segment(slg_index *ix, SegHost &sh, const slg_segment_desc &d) {
       hipLaunchKernelGGL(slg::stage_champions_kernel, dim3(cblocks ? cblocks : 1), dim3(256), 0, st, cp);
       SLG_HIP(hipGetLastError());
     }
-    {  // the first doc id of every aligned block of 8 postings (SegDev::docs8)
-      const uint64_t n8 = P_pad / 8;
-      sh.d_docs8.alloc((n8 ? n8 : 1) * 4);
-      ix->device_bytes += sh.d_docs8.bytes;
-      if (n8) {
-        const uint32_t blocks8 = (uint32_t)std::min<uint64_t>((n8 + 255) / 256, 256ull * 64);
-        hipLaunchKernelGGL(slg::sample_docs_kernel, dim3(blocks8), dim3(256), 0, st, sh.d_docs.as<uint32_t>(),
-                           sh.d_docs8.as<uint32_t>(), n8);
-        SLG_HIP(hipGetLastError());
-      }
-    }
     SLG_HIP(hipStreamSynchronize(st));  // temporaries die here
     if (sh.d_champ.p) {
       sh.champ.resize((size_t)d.n_terms * slg::kChampions);
@@ -701,7 +690,6 @@ slg_index *slg_index_create_tuned(const slg_segment_desc *segs, uint32_t n_segs,
       sd[s].n_docs = ix->segs[s]->n_docs;
       sd[s].pad = 0;
       sd[s].null_idx = ix->segs[s]->null_idx;
-      sd[s].docs8 = ix->segs[s]->d_docs8.as<uint32_t>();
       vd[s].offsets = ix->segs[s]->d_vec_offsets.as<uint32_t>();
       vd[s].values = ix->segs[s]->d_vec_values.as<float>();
       vd[s].n_docs = ix->segs[s]->n_docs;
@@ -1120,7 +1108,6 @@ int slg_batch_run(slg_batch *b) {
       sp.slice_cbeg = b->d_slice_cbeg.as<uint64_t>();
       sp.slice_ccnt = b->d_slice_ccnt.as<uint32_t>();
       sp.segs = ix->d_segs.as<slg::SegDev>();
-      sp.block_cuts = inline_cuts && ix->tune.inline_cuts != 1 ? 1u : 0u;
       sp.bounds = inline_cuts ? nullptr : b->d_bounds.as<uint32_t>();
       sp.rdoc = inline_cuts ? nullptr : b->d_rdoc.as<uint32_t>();
       sp.slice_tk = b->d_slice_tk.as<int32_t>();

@@ -46,9 +46,6 @@ struct SegDev {
   uint32_t n_docs;
   uint32_t pad;
   uint64_t null_idx;        // index of kNullRun sentinel entries
-  const uint32_t *docs8;    // docs8[i] = docs[8 i]: the first doc id of every aligned block of 8 postings
-                            // (the blocked kernel cuts its rounds at block granularity by searching
-                            // this 8x smaller array, slg_score_uni4.hpp)
 };
 
 struct TermRef {  // one scored term of one sub-query

@@ -469,12 +469,6 @@ __global__ void __launch_bounds__(256) merge_topk_kernel(MergeParams p) {
   if (lane == 0) p.out_count[q] = top.count;
 }
 
-// docs8[i] = docs[8 i] (SegDev::docs8), grid-stride
-static __global__ void __launch_bounds__(256) sample_docs_kernel(const uint32_t *docs, uint32_t *docs8, uint64_t n8) {
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (uint64_t)gridDim.x * blockDim.x)
-    docs8[i] = docs[8 * i];
-}
-
 // ---- merge of per-shard results gathered over RCCL (api/reader.rs:2776-2778 across shards) --
 struct ShardMergeParams {
   const uint32_t *doc;    // shard sh's rows start at doc + sh * arr_stride ([nq*k] each)

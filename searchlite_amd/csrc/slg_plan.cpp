@@ -354,10 +354,6 @@ uint32_t uniform_round_target(const slg::RoundQuery &sq, const slg::TermRef *t, 
     dflt = (uint32_t)slg::kUniCap;
     if (!tn.uniform_round_target && n > 1) {
       // lanes a round of R postings is expected to need, plus `sigmas` standard deviations
-      // (block cuts, slg_tuning.inline_cuts = -1 / 2: a list's round is the aligned blocks of 8 its
-      //  postings touch plus the block the next round starts in: c/8 + 1 lanes on average)
-      const bool block_cuts = tn.inline_cuts != 0 && tn.inline_cuts != 1;
-      const double pad = block_cuts ? 1.0 : 7.0 / 16.0;
       auto lanes_needed = [&](const uint32_t R) {
         double mu = 0.0, var = 0.0;
         for (uint32_t j = 0; j < n; j++) {
@@ -365,7 +361,7 @@ uint32_t uniform_round_target(const slg::RoundQuery &sq, const slg::TermRef *t, 
           if (j == sq.longest) {
             mu += std::ceil(c / 8.0);
           } else {
-            mu += c / 8.0 + pad;
+            mu += c / 8.0 + 7.0 / 16.0;
             var += c / 64.0 + 1.0 / 12.0;
           }
         }
@@ -377,7 +373,7 @@ uint32_t uniform_round_target(const slg::RoundQuery &sq, const slg::TermRef *t, 
       // corrected against the exact count (the ceil) in steps of 8 — usually two evaluations (a scan
       // over all 53 candidates cost 70 ms of planning on config 4's 65 536 sub-queries)
       const double f = (double)t[sq.longest].df / Pd;
-      const double b = pad * (n - 1) + 0.5, c = (1.0 - f) / 64.0, d = (n - 1) / 12.0;
+      const double b = 7.0 / 16.0 * (n - 1) + 0.5, c = (1.0 - f) / 64.0, d = (n - 1) / 12.0;
       double x = (64.3 - b) * 8.0;
       if (c > 1e-9) {
         const double qa = 1.0 / (8.0 * c), qc = b - 64.3 - d / (8.0 * c);
@@ -679,9 +675,7 @@ void plan_batch(const std::vector<SegView> &segs, const slg_tuning &tn, const Ba
     for (size_t i = 0; i < out.sqs.size(); i++) {
       out.sqs[i].cand_lo = (uint32_t)out.cand_total;
       out.sqs[i].cand_hi = (uint32_t)(out.cand_total >> 32);
-      // (+ 8 slots per list and round: with block cuts a slice's candidate region starts where its
-      //  first blocks start, slg_score_uni4.hpp)
-      out.cand_total += sq_postings_all[i] + 8ull * out.sqs[i].n_terms * ((uint64_t)out.sqs[i].n_rounds + 2);
+      out.cand_total += sq_postings_all[i];
     }
   out.qrefs.resize(nq);
   for (uint32_t q = 0; q < nq; q++) {

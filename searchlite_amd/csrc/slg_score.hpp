@@ -69,46 +69,6 @@ __device__ __forceinline__ bool lower_bound_window(const DocPtr d, uint32_t df, 
   return true;
 }
 
-// the same over an array with nothing readable behind d[n - 1] (SegDev::docs8 samples of one list):
-// positions >= n count as +inf without being read.  16 NP entries from `a` on.
-template <int NP, typename DocPtr>
-__device__ __forceinline__ bool lower_bound_window_bounded(const DocPtr d, uint32_t n, uint32_t target, uint32_t a,
-                                                           uint32_t &pos) {
-  uint32_t below = 0;
-#pragma unroll
-  for (uint32_t i = 0; i <= (uint32_t)NP; i++) {
-    const uint32_t at = a + 16u * i;
-    const bool rd = at != 0u && at - 1u < n;
-    const uint32_t v = rd ? d[at - 1u] : 0xFFFFFFFFu;
-    below += (at == 0u || v < target) ? 1u : 0u;
-  }
-  if (below < 1u || below > (uint32_t)NP) return false;
-  const uint32_t base = a + 16u * (below - 1u);
-  uint32_t cnt = 0;
-#pragma unroll
-  for (uint32_t i = 0; i < 16; i++) cnt += (base + i < n && d[base + i] < target) ? 1u : 0u;
-  pos = base + cnt;
-  return true;
-}
-// number of entries of d[0, n) below target (d ascending, nothing readable behind it)
-template <typename DocPtr>
-__device__ __forceinline__ uint32_t lower_bound_samples(const DocPtr d, uint32_t n, uint32_t target, uint32_t n_docs) {
-  if (n == 0u) return 0u;
-  uint32_t g = (uint32_t)(((uint64_t)n * target) / (n_docs ? n_docs : 1u));
-  g = g < n ? g : n;
-  uint32_t lo = 0, hi = n;
-  if (lower_bound_window_bounded<4>(d, n, target, g > 32u ? g - 32u : 0u, lo)) return lo;
-  lo = 0;
-  while (lo < hi) {
-    const uint32_t mid = lo + ((hi - lo) >> 1);
-    if (d[mid] < target)
-      lo = mid + 1;
-    else
-      hi = mid;
-  }
-  return lo;
-}
-
 // first index of d[0, df) with d[idx] >= target: the window around the position a uniform doc-id
 // distribution predicts (doc ids are validated < n_docs at staging, so the guess is <= df); if the
 // guess was off by more than 64 postings, a bracket widened until it holds the answer (64-bit
@@ -255,9 +215,6 @@ struct RoundScoreParams {
   uint32_t *slice_ccnt;   // [n_slices] candidates written
   uint32_t n_slices;
   uint32_t k;
-  // blocked few-term kernel cutting its own slices (bounds == nullptr): 1 = rounds are cut at aligned
-  // blocks of 8 postings found in SegDev::docs8 (slg_score_uni4.hpp), 0 = at exact postings
-  uint32_t block_cuts;
   // block skipping (many-term kernel with classified lists): 64-posting slots of non-essential
   // lists whose doc range holds no doc of an essential list are never loaded
   uint32_t block_skip;

@@ -111,7 +111,6 @@ score_uniform4_kernel(RoundScoreParams p) {
   uint32_t *const bflat = reinterpret_cast<uint32_t *>(smem + u4_plan_off(KREGS, FW));
   uint32_t *const off_lo = bflat + BW, *const off_hi = off_lo + ML, *const wts = off_hi + ML, *const dfs = wts + ML;
   const bool inline_cuts = p.bounds == nullptr;
-  uint32_t *const row0_doc = rend + kMaxRoundsPerSlice + 1;  // the doc the slice starts at (inline cuts)
   TermRef tr{};
   if (lane < T) tr = p.terms[sl.term_begin + lane];
   // The wave cuts its own slice (what partition_rounds_kernel does for every boundary of the batch,
@@ -123,21 +122,7 @@ score_uniform4_kernel(RoundScoreParams p) {
   const uint32_t lg = rfl(sl.longest), sq_rounds = rfl(sl.sq_rounds), r0 = rfl(sl.first_round);
   const uint64_t l_off = ((uint64_t)rfl((uint32_t)(sl.l_off >> 32)) << 32) | rfl((uint32_t)sl.l_off);
   const uint32_t l_df = rfl(sl.l_df);
-  // Block cuts (p.block_cuts): rounds are cut at ALIGNED blocks of 8 postings instead of exact
-  // postings.  The splitter list is cut every `stride` blocks; boundary j's doc is the first doc of
-  // its block (SegDev::docs8); another list's round starts at the block holding its first posting
-  // >= that doc, found by counting the list's block-first docs below it — a search in an array 8
-  // times smaller whose lines neighbouring boundaries share — and ends with the block in which the
-  // next round starts: adjacent rounds share that block, and every posting is tested against
-  // [start doc, end doc) where it counts.  No search touches the posting array itself (the exact
-  // cuts' searches were 16 % / 29 % of the HBM traffic on configs 2 / 3), at one more lane per list
-  // and round.
-  const bool blk = inline_cuts && p.block_cuts != 0u;
-  const gu32_t gdocs8 = (gu32_t)sd.docs8;
-  const uint64_t l_b0 = l_off >> 3;                                           // the splitter's first block
-  const uint32_t l_nb = (uint32_t)(((l_off + l_df + 7ull) >> 3) - l_b0);      // blocks it covers
-  const uint32_t l_units = blk ? l_nb : l_df;                                 // what the stride counts
-  const uint32_t stride = inline_cuts ? (l_units + sq_rounds - 1u) / sq_rounds : 0u;
+  const uint32_t stride = inline_cuts ? (l_df + sq_rounds - 1u) / sq_rounds : 0u;
   const float inv_t = 1.0f / (float)T;
   // (the boundary docs are loaded straight off the slice record, beside the TermRef loads)
   constexpr int NTASK = (int)(BW / 64u);
@@ -148,8 +133,8 @@ score_uniform4_kernel(RoundScoreParams p) {
       const uint32_t task = lane + 64u * u;
       const uint32_t i = (uint32_t)(((float)task + 0.5f) * inv_t);  // (exact: task < 128, T <= 8)
       const uint64_t pos_l = (uint64_t)(r0 + i) * stride;
-      const bool mid = task < (n_r + 1u) * T && r0 + i != 0u && r0 + i < sq_rounds && pos_l < l_units;
-      tgt[u] = !mid ? 0u : (blk ? gdocs8[l_b0 + pos_l] : gdocs[l_off + pos_l]);
+      const bool mid = task < (n_r + 1u) * T && r0 + i != 0u && r0 + i < sq_rounds && pos_l < l_df;
+      tgt[u] = mid ? gdocs[l_off + pos_l] : 0u;
     }
   }
   if (lane < T) {
@@ -166,42 +151,30 @@ score_uniform4_kernel(RoundScoreParams p) {
     wave_fence();
     // the boundaries' docs: rend[i - 1] = end doc of round i - 1 (sentinels are 0xFFFFFFFF: never below
     // kDocEnd); rend[kMaxRoundsPerSlice + 1] = the doc the slice starts at
+    uint32_t *const row0_doc = rend + kMaxRoundsPerSlice + 1;
 #pragma unroll
     for (int u = 0; u < NTASK; u++) {
       const uint32_t task = lane + 64u * u;
       const uint32_t i = (uint32_t)(((float)task + 0.5f) * inv_t);
       const uint64_t pos_l = (uint64_t)(r0 + i) * stride;
-      const bool last_b = r0 + i >= sq_rounds || pos_l >= l_units;
+      const bool last_b = r0 + i >= sq_rounds || pos_l >= l_df;
       if (task < (n_r + 1u) * T && task == i * T) {
         if (i >= 1u)
           rend[i - 1u] = last_b ? kDocEnd : tgt[u];
         else
-          *row0_doc = last_b ? kDocEnd : tgt[u];  // (0 for the sub-query's first boundary; a slice of
-                                                  //  rounds past the splitter's end starts at "no doc")
+          *row0_doc = tgt[u];  // (0 for the sub-query's first boundary)
       }
     }
     // one boundary of one list: first posting with doc >= the boundary's doc
     auto cut_one = [&](const uint32_t i, const uint32_t t, const uint32_t target, const bool inner) {
       const uint32_t j = r0 + i;
       const uint64_t pos_l = (uint64_t)j * stride;
-      const bool first_b = j == 0u, last_b = j >= sq_rounds || pos_l >= l_units;
+      const bool first_b = j == 0u, last_b = j >= sq_rounds || pos_l >= l_df;
       const uint32_t df_t = dfs[t];
-      const uint64_t off_t = ((uint64_t)off_hi[t] << 32) | off_lo[t];
-      if (blk) {
-        // relative block in which the round that starts at this boundary starts (the splitter: the
-        // boundary's own block; past the end: its block count, the others': their last block)
-        const uint64_t b0 = off_t >> 3;
-        const uint32_t nb = (uint32_t)(((off_t + df_t + 7ull) >> 3) - b0);
-        if (first_b) return 0u;
-        if (t == lg) return last_b ? nb : (uint32_t)pos_l;
-        if (last_b) return nb - 1u;
-        // block-first docs of the blocks behind the list's first: all real postings, ascending
-        return lower_bound_samples(gdocs8 + (b0 + 1ull), nb - 1u, target, sd.n_docs);
-      }
       if (first_b) return 0u;
       if (last_b) return df_t;
       if (t == lg) return (uint32_t)pos_l;
-      const gu32_t d = gdocs + off_t;
+      const gu32_t d = gdocs + (((uint64_t)off_hi[t] << 32) | off_lo[t]);
       if (!inner) return lower_bound_guess(d, df_t, target, sd.n_docs);
       // between the slice's own first and last cut points the postings are spread evenly enough for a
       // 64-posting window around the interpolated position (half the lines of the global guess's
@@ -223,7 +196,7 @@ score_uniform4_kernel(RoundScoreParams p) {
       }
       return lo;
     };
-    const bool two_phase = !blk && n_r >= (uint32_t)SLG_U4_TWO_PHASE_MIN;
+    const bool two_phase = n_r >= (uint32_t)SLG_U4_TWO_PHASE_MIN;
     if (two_phase) {
       wave_fence();
       if (lane < 2u * T) {  // the slice's first and last boundary, every list
@@ -252,10 +225,7 @@ score_uniform4_kernel(RoundScoreParams p) {
   uint64_t cbeg = 0;
   if (!BUF) {
     uint32_t before = 0;
-    for (uint32_t t = 0; t < T; t++) before += rfl(bflat[t]) * (blk ? 8u : 1u);
-    // (block cuts: a slice's candidates may exceed the postings its start blocks are apart by < 8 per
-    //  list; the planner leaves 8 T slots per round for it)
-    if (blk) before += r0 * 8u * T;
+    for (uint32_t t = 0; t < T; t++) before += rfl(bflat[t]);
     cbeg = (((uint64_t)rfl(sl.cand_hi) << 32) | rfl(sl.cand_lo)) + before;
   }
   uint2 *const creg = BUF ? nullptr : p.cand + cbeg;
@@ -263,11 +233,8 @@ score_uniform4_kernel(RoundScoreParams p) {
     const float th0 = __uint_as_float(rfl(__float_as_uint(sl.theta0)));
     if (th0 > 0.0f) btop.set_floor(th0);
   }
-  // docs scored = postings - queued + owners of the joins: the postings are counted from the exact cut
-  // points, or (block cuts) all of the sub-query's by its first slice
   uint32_t n_scored = 0;
-  for (uint32_t t = 0; t < T; t++)
-    n_scored += blk ? (r0 == 0u ? rfl(dfs[t]) : 0u) : rfl(bflat[n_r * T + t]) - rfl(bflat[t]);
+  for (uint32_t t = 0; t < T; t++) n_scored += rfl(bflat[n_r * T + t]) - rfl(bflat[t]);
 
 #ifdef SLG_STAMPS
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_ins = 0, st_queued = 0;
@@ -310,9 +277,8 @@ score_uniform4_kernel(RoundScoreParams p) {
     const bool rv = ri < n_r && t < T;
     const uint32_t src = (ri * T + t) & (BW - 1u);
     const uint32_t lo_t = bflat[src];
-    const uint32_t c = rv ? bflat[(src + T) & (BW - 1u)] - lo_t : 0u;  // postings (block cuts: blocks) of list t in the round
-    // lanes of the list: its postings padded to 8; block cuts: its blocks + the one the next round starts in
-    const uint32_t m = blk ? (rv ? c + (t != lg ? 1u : 0u) : 0u) : (c + 7u) >> 3;
+    const uint32_t c = rv ? bflat[(src + T) & (BW - 1u)] - lo_t : 0u;  // postings of list t in the round
+    const uint32_t m = (c + 7u) >> 3;
     uint32_t incl = m;  // prefix sum over the round's 8 lanes
 #pragma unroll
     for (int d = 1; d < 8; d <<= 1) {
@@ -323,7 +289,7 @@ score_uniform4_kernel(RoundScoreParams p) {
     const uint32_t total = from_lane(incl, lane | 7u);
     const uint32_t used = total < 64u ? total : 64u;
     if (t < T) {
-      const uint64_t a = (blk ? (list_off(t) & ~7ull) + 8ull * lo_t : list_off(t) + lo_t) - 8ull * first;
+      const uint64_t a = list_off(t) + lo_t - 8ull * first;
       tbl[i * TE + t] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), wts[t], 1u << t);
     }
     if (t == 0u) {
@@ -345,12 +311,12 @@ score_uniform4_kernel(RoundScoreParams p) {
   //      lane t gets its list's lanes [first, first + m) ----
   auto describe_chunk = [&](const uint32_t lo, const uint32_t cnt, uint32_t &first, uint32_t &m) {
     const uint32_t lane = fresh_lane();
-    m = lane < T ? (blk ? cnt : (cnt + 7u) >> 3) : 0u;  // (block cuts: lo and cnt count blocks)
+    m = lane < T ? (cnt + 7u) >> 3 : 0u;
     const uint32_t incl = wave_incl_scan(m);
     first = incl - m;
     const uint32_t total = rl(incl, 63);  // <= 64 (the chunk was sized for it)
     if (lane < T) {
-      const uint64_t a = (blk ? (list_off(lane) & ~7ull) + 8ull * lo : list_off(lane) + lo) - 8ull * first;
+      const uint64_t a = list_off(lane) + lo - 8ull * first;
       tbl[8 * TE + lane] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), wts[lane], 1u << lane);
     }
     if (lane == 0u) {
@@ -435,12 +401,10 @@ score_uniform4_kernel(RoundScoreParams p) {
   };
   refresh_threshold();
 
-  // ---- score the postings of `e`: the postings with start <= doc < end are this round's (or chunk's;
-  //      start = 0 with exact cuts: every loaded posting below `end` is the round's); the others
-  //      (later or — block cuts — earlier postings of the same lists, sentinels) only ever add filter bits.
+  // ---- score the postings of `e`: all postings with doc < end are this round's (or chunk's);
+  //      the others (later postings of the same lists, sentinels) only ever add filter bits.
   //      bnd_*_v: the round's list boundaries (header words, uniform; for the dense join) ----
-  auto accumulate = [&](const BRound &e, const uint32_t start, const uint32_t end, const uint32_t bnd_lo_v,
-                        const uint32_t bnd_hi_v) {
+  auto accumulate = [&](const BRound &e, const uint32_t end, const uint32_t bnd_lo_v, const uint32_t bnd_hi_v) {
     SLG_STAMP(1);
     uint32_t x[NS];
     uint32_t accx = hot_all ? 1u : 0u;
@@ -495,7 +459,7 @@ score_uniform4_kernel(RoundScoreParams p) {
             dc = it == (uint32_t)j ? e.doc[j] : dc;
             xf = it == (uint32_t)j ? x[j] : xf;
           }
-          const bool single = xf == 0u && dc < end && dc >= start;
+          const bool single = xf == 0u && dc < end;
           if (__ballot(single) == 0ull) continue;
           take_checked(single, 0.0f + xs, dc);
         }
@@ -506,10 +470,8 @@ score_uniform4_kernel(RoundScoreParams p) {
       uint32_t qf[NS], cnt = 0;
 #pragma unroll
       for (int jj = 0; jj < NS; jj++) {
-        const uint32_t below = __builtin_elementwise_sub_sat(end, e.doc[jj]);        // != 0: doc < end
-        const uint32_t above = __builtin_elementwise_sub_sat(e.doc[jj] + 1u, start);  // != 0: doc >= start
-        const uint32_t in = below < above ? below : above;
-        const uint32_t both = x[jj] < in ? x[jj] : in;                                // != 0: all three
+        const uint32_t below = __builtin_elementwise_sub_sat(end, e.doc[jj]);  // != 0: doc < end
+        const uint32_t both = x[jj] < below ? x[jj] : below;                    // != 0: both
         qf[jj] = both < 1u ? both : 1u;
         cnt += qf[jj];
       }
@@ -676,46 +638,27 @@ score_uniform4_kernel(RoundScoreParams p) {
     SLG_STAMP(0);
     if (first) continue;
     uint32_t ocur = 0, oend = 0, end = rend_r;
-    // block cuts: the round's postings are those with start <= doc < end among the loaded blocks
-    uint32_t start = blk ? (rr == 0u ? rfl(*row0_doc) : rfl(rend[rr - 1u])) : 0u;
-    if (big) {
-      cuts(rr, ocur, oend);
-      if (blk && lane != lg && lane < T) oend += 1u;  // (one past the block the next round starts in)
-    }
+    if (big) cuts(rr, ocur, oend);
     uint32_t guard = 0;
-    bool more = big;
     do {
       if (big) {
         // next chunk of an over-full round: every list with postings left gets >= 1 lane, the rest
         // in proportion to what it has left; the chunk ends at the smallest "last loaded doc" of
-        // the lists that did not finish, so all postings of a doc are scored in the same chunk.
-        // Exact cuts: ocur / oend / chunk count postings; block cuts: blocks (= lanes).
+        // the lists that did not finish, so all postings of a doc are scored in the same chunk
         const uint32_t lane = fresh_lane();
         const uint32_t rem = oend - ocur;
         const uint32_t nne = (uint32_t)__popcll(__ballot(rem != 0u));
         const uint32_t R = lane_sum_T(rem);
         if (R == 0 || ++guard > (1u << 22)) break;
-        const uint32_t need = lane_sum_T(blk ? rem : (rem + 7u) >> 3);
+        const uint32_t need = lane_sum_T((rem + 7u) >> 3);
         uint32_t chunk = rem;
         if (need > 64u) {
-          if (blk) {
-            // every list first gets up to two blocks (the one it shares with the previous round and the
-            // next: a list cut inside the shared block would end the chunk below the round's start),
-            // the other lanes go in proportion to what is left
-            const uint32_t base = rem < 2u ? rem : 2u;
-            const uint32_t B = lane_sum_T(base), Rx = R - B;
-            chunk = base + (Rx ? (uint32_t)((float)(64u - B) * ((float)(rem - base) / (float)Rx)) : 0u);
-            chunk = chunk < rem ? chunk : rem;
-          } else {
-            const float share = (float)(64u - nne) * ((float)rem / (float)R);
-            const uint32_t mlanes = rem == 0u ? 0u : 1u + (uint32_t)share;
-            chunk = rem < mlanes * 8u ? rem : mlanes * 8u;
-          }
+          const float share = (float)(64u - nne) * ((float)rem / (float)R);
+          const uint32_t mlanes = rem == 0u ? 0u : 1u + (uint32_t)share;
+          chunk = rem < mlanes * 8u ? rem : mlanes * 8u;
         }
-        const uint64_t my_off = list_off(lane < T ? lane : 0u);
         uint32_t lastdoc = kDocEnd;
-        if (chunk < rem)
-          lastdoc = blk ? gdocs[(my_off & ~7ull) + 8ull * (ocur + chunk) - 1ull] : gdocs[my_off + ocur + chunk - 1];
+        if (chunk < rem) lastdoc = gdocs[list_off(lane < T ? lane : 0u) + ocur + chunk - 1];
         uint32_t my_first, my_m;
         wave_fence();
         describe_chunk(ocur, chunk, my_first, my_m);
@@ -730,10 +673,6 @@ score_uniform4_kernel(RoundScoreParams p) {
         }
         // (kDocEnd: nothing was cut, the chunk is the rest of the round)
         end = bound == kDocEnd ? rend_r : (bound + 1u < rend_r ? bound + 1u : rend_r);
-        // (block cuts: a list cut inside the block it shares with the previous round may end below the
-        //  round's start; the chunk is then empty and only moves the lists on)
-        end = end < start ? start : end;
-        more = bound != kDocEnd;
         // what each list consumed: its postings with doc < end (a prefix of its lanes' postings)
         uint32_t below = 0;
 #pragma unroll
@@ -741,14 +680,10 @@ score_uniform4_kernel(RoundScoreParams p) {
         const uint32_t bincl = wave_incl_scan(below);
         const uint32_t hi_v = from_lane(bincl, (my_first + my_m - 1u) & 63u);
         const uint32_t lo_v = from_lane(bincl, (my_first - 1u) & 63u);
-        const uint32_t cnt = my_m == 0u ? 0u : hi_v - (my_first == 0u ? 0u : lo_v);
-        // block cuts: the next chunk starts in the block of the first posting >= end (the list's very
-        // first block may begin with sentinels of the pad before it)
-        ocur += blk ? (cnt + (ocur == 0u ? (uint32_t)my_off & 7u : 0u)) >> 3 : cnt;
+        ocur += my_m == 0u ? 0u : hi_v - (my_first == 0u ? 0u : lo_v);
       }
-      accumulate(ew, start, end, hcur.x, hcur.y);
-      start = blk ? end : 0u;
-    } while (more);
+      accumulate(ew, end, hcur.x, hcur.y);
+    } while (big);
   }
 
   // ---- write this slice's candidates ----
