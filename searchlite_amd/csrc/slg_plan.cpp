@@ -215,9 +215,10 @@ void plan_queries(const Pass1Ctx &c, const uint32_t q_lo, const uint32_t q_hi, P
     const bool groups = pl.leaf_group != nullptr;
     const uint32_t *lgroup = groups ? pl.leaf_group + pl.q_leaf_offsets[q] : nullptr;
     const uint32_t n_groups = groups ? pl.q_group_offsets[q + 1] - pl.q_group_offsets[q] : 0u;
-    uint32_t leaves_in_group[kMaxPlanNodes + 1] = {0};
+    uint32_t leaves_in_group[kMaxPlanNodes + 1];  // (zeroed only for queries with groups: 1 KB per query otherwise)
     bool nested = false;
     if (groups) {
+      std::memset(leaves_in_group, 0, sizeof(leaves_in_group));
       PLAN_REQUIRE(n_leaves == pl.q_nleaves[q], "a term names a leaf beyond q_nleaves in query " + std::to_string(q));
       for (uint32_t l = 0; l < n_leaves; l++) leaves_in_group[lgroup[l]]++;
       for (uint32_t g = 0; g < n_groups; g++)
