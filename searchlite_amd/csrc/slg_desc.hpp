@@ -116,7 +116,10 @@ struct QueryRef {
 // ---- planning constants (the kernels that consume them: slg_score*.hpp) ------------------------
 constexpr int kMaxRoundsPerSlice = 16;  // and (rounds+1)*T <= 64: cut points live in one VGPR
 constexpr int kDefaultRoundsPerSlice = 8;
-constexpr int kUniRoundsPerSlice = 4;     // few-term kernel
+#ifndef SLG_UNI_RPS
+#define SLG_UNI_RPS 4
+#endif
+constexpr int kUniRoundsPerSlice = SLG_UNI_RPS;  // few-term kernel, k <= 64
 constexpr int kSpanWords = 512;           // bitmap words per window (many-term kernel)
 constexpr uint32_t kSpan = kSpanWords * 32;  // docs per window
 constexpr int kUniSlots = 8;                 // 64-posting slots per round
