@@ -254,6 +254,43 @@ def test_kernel_choice_follows_what_block_skipping_can_save(lib):
     off.close()
 
 
+def test_blocked_round_target_is_the_largest_that_fits(lib):
+    """The few-term planner's round target (closed form + correction, slg_plan.cpp) is the largest R in
+    steps of 8 whose expected lanes + 3.2 sigma stay under 64.3 — checked against a plain scan over
+    all candidates, through the rounds the planner reports (rounds = ceil(postings / R))."""
+    import math
+    rng = np.random.default_rng(21)
+    seg = random_segment(rng, 60000, 50, 40, zipf=True)
+    offs, terms, w = random_queries(rng, 200, 5, 50)
+    for T in (2, 3, 5, 8):
+        o = (np.arange(201) * T).astype(np.uint32)
+        t = np.stack([rng.choice(50, size=T, replace=False) for _ in range(200)]).astype(np.uint32).reshape(-1)
+        ww = np.ones(200 * T, np.float32)
+        p = Planned(lib, [seg], o, t, ww, 11, strategy=0)
+        assert p.h, p.err
+        sqs, tr = check_structure(p, 11)
+        assert p.facts.uniform
+        for sq in sqs:
+            tt = tr[int(sq["term_begin"]):int(sq["term_begin"]) + int(sq["n_terms"])]
+            dfs = [int(x) for x in tt["df"]]
+            P, n, lg = sum(dfs), len(dfs), int(sq["longest"])
+            def lanes(R):
+                mu = var = 0.0
+                for j, df in enumerate(dfs):
+                    c = R * df / P
+                    if j == lg:
+                        mu += math.ceil(c / 8.0)
+                    else:
+                        mu += c / 8.0 + 7.0 / 16.0
+                        var += c / 64.0 + 1.0 / 12.0
+                return mu + 3.2 * math.sqrt(var)
+            best = 512 if n == 1 else max([R for R in range(64, 513, 8) if lanes(R) <= 64.3] or [64])
+            best = max(48, min(best, 512))
+            want = max(1, min(-(-P // best), dfs[lg]))
+            assert int(sq["n_rounds"]) == want, (dfs, int(sq["n_rounds"]), want, best)
+        p.close()
+
+
 def test_threshold_seed_never_exceeds_the_true_kth_score(lib, oracle):
     """theta0 = max_t w_t * champ[t][rank(k)] must be a lower bound of the k-th best score of the
     sub-query (RoundQuery::theta0): checked against the exhaustive oracle; and MaxScore's
