@@ -98,8 +98,10 @@ typedef struct {
  * applied to the work the device did:
  *   scored_docs = candidates_examined = distinct docs that got a score.  SLG_STRATEGY_BM25: every
  *     doc holding a query term (tombstoned docs included: accept() runs at top-k insertion) — the
- *     count brute_force reports.  SLG_STRATEGY_WAND / _BMW: docs of the ESSENTIAL lists only (the
- *     MaxScore classification never scores a doc found in non-essential lists alone);
+ *     count brute_force reports.  SLG_STRATEGY_WAND / _BMW: the same when the batch runs unclassified
+ *     (slg_tuning.pruning: the default for queries of <= 8 terms unless block skipping pays); with the
+ *     MaxScore classification kept, docs of the ESSENTIAL lists only (a doc found in non-essential
+ *     lists alone is never scored);
  *   postings_advanced = postings of the query's lists minus those block skipping never loaded.
  * Under Wand / Bmw these are NOT the reference's wand_loop counters (wand.rs:826-835, 883-891 count
  * the pivot sequence of its cursors, which the device does not walk): a caller that derives
