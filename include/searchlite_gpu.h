@@ -32,7 +32,9 @@
 extern "C" {
 #endif
 
-#define SLG_ABI_VERSION 2u  /* 2: slg_tuning grew (pool_cap_mb, uniform_kernel, uniform_sigma_x100, inline_cuts); shard groups; slg_batch_prepare_plans */
+#define SLG_ABI_VERSION 3u  /* 3: slg_tuning grew (updatable); index updates (slg_index_update_deleted / _add_segment /
+                               _remove_segment / _generation); request coalescer; slg_batch_device_candidates.
+                               2: pool_cap_mb, uniform_kernel, uniform_sigma_x100, inline_cuts; shard groups; slg_batch_prepare_plans */
 #define SLG_NO_TERM 0xFFFFFFFFu      /* term absent from a segment (api/reader.rs:2989) */
 #define SLG_NO_VECTOR 0xFFFFFFFFu    /* vectors/mod.rs:65-67 (u32::MAX offset) */
 #define SLG_MAX_QUERY_TERMS 32u      /* scored terms per query per segment */
@@ -188,6 +190,10 @@ typedef struct {
   int32_t inline_cuts;           /* SLG_INLINE_CUTS (-1 = auto: on): the blocked few-term kernel cuts the lists at
                                     its slice's round boundaries itself instead of reading cut points that
                                     partition_rounds_kernel wrote for the whole batch; 0 off; 1 on */
+  int32_t updatable;             /* !SLG_NOT_UPDATABLE (1): keep term frequencies and doc lengths resident
+                                    (4 B per posting + 4 B per doc and field) so that slg_index_update_deleted
+                                    can re-derive a segment's impacts on the device when live_docs changes;
+                                    0: that call fails with SLG_ERR_UNSUPPORTED (add / remove segment still work) */
 } slg_tuning;
 void slg_tuning_default(slg_tuning *out);
 slg_index *slg_index_create_tuned(const slg_segment_desc *segs, uint32_t n_segs, int device,
@@ -202,6 +208,44 @@ int slg_index_trim_pool(slg_index *index, uint64_t *freed_bytes_or_null);
 /* Bytes of HBM held by the index; total postings; segments. */
 int slg_index_info(const slg_index *index, uint32_t *n_segs, uint64_t *n_postings,
                    uint64_t *device_bytes);
+
+/* ---- index updates (the reference's commit: api/writer.rs:106-240) -------------------------------
+ * searchlite opens a fresh IndexReader per request (searchlite-http/src/lib.rs:640-643 ->
+ * index/mod.rs:98-100 -> api/reader.rs:1887-1913), so a staged index must outlive readers and follow
+ * the manifest: a commit merges new tombstones into segments' deleted_docs (api/writer.rs:150-158:
+ * the set only grows), appends at most one new segment (:160-192, at the END of manifest.segments, so
+ * existing segment ordinals keep their meaning) and compaction replaces segments (index/mod.rs:102+).
+ *
+ * The index is a sequence of immutable states.  Every call below builds the next state (unchanged
+ * segments are shared, not copied), publishes it atomically and bumps the generation.  A batch is
+ * bound to the state that was current when it was PREPARED: batches prepared or in flight during an
+ * update run to completion against their own state — same segments, same tombstones, same filters —
+ * and the device memory of a retired state is released when its last batch is destroyed.  Updates are
+ * serialised among themselves and never wait for running batches.
+ *
+ * The caller builds q_term_ids rows for the segment count it knows: it must not race
+ * slg_index_add_segment / _remove_segment with building query arrays for the same index (the Rust
+ * shim holds these calls under the index's write lock; slg_index_generation tells a reader whether
+ * the staged index still matches its manifest snapshot). */
+
+/* New tombstones for segment `seg`: `deleted` is the segment's COMPLETE bitmap (bit d&7 of byte d>>3;
+ * a superset of the previous one — the reference never resurrects a doc), `live_docs` =
+ * seg.live_docs() = doc_count - |deleted| (index/segment.rs:1365-1370).  live_docs is the `docs` of
+ * every ScoredTerm (api/reader.rs:2985), so every idf — and with it every posting's impact, every
+ * champion bound and threshold seed — changes: they are re-derived on the device from the resident
+ * term frequencies and doc lengths by the same kernels as at creation, i.e. bit-identical to a fresh
+ * slg_index_create on the updated descriptor.  Registered filters follow (their reject bitmaps of
+ * this segment take the new tombstones).  Needs slg_tuning.updatable. */
+int slg_index_update_deleted(slg_index *index, uint32_t seg, const uint8_t *deleted, float live_docs);
+/* Stage one more segment; it takes the next ordinal (returned, >= 0; negative error code otherwise).
+ * Filters registered before the call have no bitmap for it: a batch that names one of them fails with
+ * SLG_ERR_INVALID until the filter is removed and registered again.  Extra vector fields
+ * (slg_index_add_vector_field) hold no vectors for the new segment. */
+int slg_index_add_segment(slg_index *index, const slg_segment_desc *seg);
+/* Drop segment `seg` (compaction, index/mod.rs:102+); the ordinals above it move down by one. */
+int slg_index_remove_segment(slg_index *index, uint32_t seg);
+/* Number of updates applied since creation (0 for a fresh index). */
+uint64_t slg_index_generation(const slg_index *index);
 
 /* Use an external HIP stream (hipStream_t) for all work of this index, e.g. the current
  * PyTorch stream so RCCL collectives order after the kernels.  NULL is a valid handle (the
@@ -225,7 +269,8 @@ int slg_index_add_filter_range_i64(slg_index *index, const int64_t *const *seg_c
                                    int64_t hi);
 int slg_index_add_filter_range_f64(slg_index *index, const double *const *seg_columns, double lo,
                                    double hi);
-/* Frees the bitmaps; the id is not reused.  No batch prepared with this filter may run after. */
+/* Unregisters the filter.  Batches already prepared with it keep their bitmaps (they belong to the
+ * batch's index state) and may still run; the id may be handed out again by a later add. */
 int slg_index_remove_filter(slg_index *index, int filter_id);
 
 /* ---- one-shot search (what a searchlite `gpu` shim calls) -------------------------- */

@@ -28,6 +28,7 @@ pub struct slg_tuning {
     pub probe_target: u32, pub rounds_per_slice: u32, pub max_rounds_per_slice: u32,
     pub slices_per_subquery: u32, pub cand_mode: i32, pub slice_order: i32, pub block_max: i32,
     pub pool_cap_mb: u32, pub uniform_kernel: u32, pub uniform_sigma_x100: u32, pub inline_cuts: i32,
+    pub updatable: i32,
 }
 #[repr(C)] pub struct slg_vector_field_desc {
     pub vec_dim: u32, pub vec_metric: i32, pub vec_offsets: *const u32, pub vec_values: *const c_float, pub vec_rows: u32,
@@ -53,6 +54,11 @@ extern "C" {
     pub fn slg_index_create(segs: *const slg_segment_desc, n_segs: u32, device: c_int) -> *mut slg_index;
     pub fn slg_index_destroy(index: *mut slg_index);
     pub fn slg_index_info(index: *const slg_index, n_segs: *mut u32, n_postings: *mut u64, device_bytes: *mut u64) -> c_int;
+    // index updates: the staged index follows the manifest (api/writer.rs:106-240)
+    pub fn slg_index_update_deleted(index: *mut slg_index, seg: u32, deleted: *const u8, live_docs: c_float) -> c_int;
+    pub fn slg_index_add_segment(index: *mut slg_index, seg: *const slg_segment_desc) -> c_int;
+    pub fn slg_index_remove_segment(index: *mut slg_index, seg: u32) -> c_int;
+    pub fn slg_index_generation(index: *const slg_index) -> u64;
     // index sharding over RCCL (api/reader.rs:2670-2778 across GPUs)
     pub fn slg_shard_unique_id(out: *mut c_void, out_bytes: usize) -> c_int;
     pub fn slg_shard_group_create(index: *mut slg_index, rank: c_int, world: c_int, unique_id: *const c_void,

@@ -29,7 +29,6 @@
 #include "slg_plan.hpp"
 #include "slg_rerank.hpp"
 #include "slg_score.hpp"
-#include "slg_score_uni.hpp"
 #include "slg_score_multi.hpp"
 
 namespace {
@@ -248,31 +247,99 @@ struct DevBuf {
   }
 };
 
-struct SegHost {
-  uint32_t n_docs = 0, n_terms = 0;
+// What a staged segment keeps for as long as any version of it lives: the posting arrays in the
+// padded device layout, and (slg_tuning.updatable) everything stage_impacts_kernel needs to derive the
+// impacts again when live_docs changes (slg_index_update_deleted).  Immutable after staging.
+struct PostingStore {
+  uint32_t n_docs = 0, n_terms = 0, n_fields = 0;
   uint64_t n_postings = 0;
   uint64_t null_idx = 0;               // SegDev::null_idx
   std::vector<uint64_t> term_offsets;  // as given (unpadded); device position = + kListPad * term
-  std::vector<float> champ;  // host mirror of d_champ [V * kChampions] (query planning)
-  DevBuf d_docs, d_imps, d_deleted, d_champ;
-  // vectors
+  std::vector<float> avgdl;            // [n_fields]
+  float k1 = 0.0f, b = 0.0f;
+  bool has_term_field = false;
+  bool updatable = false;
+  DevBuf d_docs;                                        // padded doc ids
+  DevBuf d_offs, d_tfs, d_tfield, d_avgdl, d_lenptrs;   // updatable only (else freed after staging)
+  std::vector<DevBuf> d_lens;                           // updatable only: per-field doc lengths
+  // vectors (field 0)
   uint32_t vec_dim = 0, vec_rows = 0;
   int32_t vec_metric = 0;
   DevBuf d_vec_offsets, d_vec_values;
+  size_t device_bytes() const {
+    size_t n = d_docs.bytes + d_offs.bytes + d_tfs.bytes + d_tfield.bytes + d_avgdl.bytes + d_lenptrs.bytes +
+               d_vec_offsets.bytes + d_vec_values.bytes;
+    for (auto &l : d_lens) n += l.bytes;
+    return n;
+  }
 };
 
-// a vector field beyond the one in the segment descriptors (slg_index_add_vector_field)
+// One VERSION of a staged segment: what depends on live_docs and the tombstones (impacts, champion
+// bounds, the bitmap).  Versions of one segment share its PostingStore.
+struct SegHost {
+  std::shared_ptr<PostingStore> store;
+  uint32_t n_docs = 0, n_terms = 0;
+  uint64_t n_postings = 0;
+  uint64_t null_idx = 0;
+  float docs = 0.0f;         // live_docs this version's idf values were computed with
+  std::vector<float> champ;  // host mirror of d_champ [V * kChampions] (query planning)
+  DevBuf d_imps, d_deleted, d_champ;
+  size_t device_bytes() const { return d_imps.bytes + d_deleted.bytes + d_champ.bytes; }
+};
+
+// a vector field beyond the one in the segment descriptors (slg_index_add_vector_field): per segment
+// shared stores (null: the segment has no vectors in the field)
+struct VecSegStore {
+  DevBuf offsets, values;
+  uint32_t dim = 0;
+};
 struct VecFieldHost {
   uint32_t dim = 0;
   int32_t metric = 0;
-  std::vector<DevBuf> offsets, values;  // per segment (empty buffers: no vectors there)
-  DevBuf d_vsegs;                       // slg::VecSegDev[n_segs]
+  std::vector<std::shared_ptr<VecSegStore>> per_seg;
+  DevBuf d_vsegs;  // slg::VecSegDev[n_segs] of the state this object belongs to
+};
+
+// a registered doc filter: per segment a reject bitmap (deleted | ~filter); null = the filter predates
+// the segment (slg_index_add_segment) and cannot be used until it is registered again
+struct FilterData {
+  std::vector<std::shared_ptr<DevBuf>> per_seg;
+  bool complete() const {
+    for (auto &b : per_seg)
+      if (!b) return false;
+    return true;
+  }
+};
+
+// One immutable state of the index (see "index updates" in searchlite_gpu.h).  Batches hold the state
+// they were prepared on; the index holds the current one.
+struct IndexState {
+  uint64_t generation = 0;
+  int device = 0;
+  std::vector<std::shared_ptr<SegHost>> segs;
+  DevBuf d_segs;   // slg::SegDev[n_segs]
+  DevBuf d_vsegs;  // slg::VecSegDev[n_segs]
+  std::vector<std::shared_ptr<VecFieldHost>> vfields;  // field id f >= 1 is vfields[f - 1]
+  std::vector<std::shared_ptr<FilterData>> filters;    // slot = filter id; null = free
+  std::vector<const uint32_t *> reject_host;           // flattened [filter * n_segs + seg] device pointers
+  DevBuf d_reject_table;                               // the same table on the device
+  ~IndexState() {
+    // kernels of already-destroyed batches, or rerank calls on the index stream, may still read the
+    // tables: retiring a state is rare (one per update), so wait for the device once
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
 };
 
 }  // namespace
 
 struct slg_index {
-  BufPool pool;  // work buffers of finished batches (declared first: destroyed last)
+  // work buffers of finished batches.  Shared with the batches (a batch that outlives the index
+  // still returns its buffers somewhere valid); declared first: destroyed last
+  BufPool pool;
   slg_tuning tune{};
   std::vector<slg_batch *> live;  // batches prepared on this index and not yet destroyed (under mu)
   int device = 0;
@@ -284,24 +351,24 @@ struct slg_index {
   static constexpr int kUploadStreams = 8;
   hipStream_t upload_streams[kUploadStreams] = {};
   hipStream_t stream = nullptr;
-  std::vector<std::unique_ptr<SegHost>> segs;
-  DevBuf d_segs;  // slg::SegDev[n_segs]
-  DevBuf d_vsegs; // slg::VecSegDev[n_segs]
-  std::vector<std::unique_ptr<VecFieldHost>> vfields;  // field id f >= 1 is vfields[f - 1] (under mu)
-  uint64_t device_bytes = 0;
+  std::shared_ptr<const IndexState> state;  // the current state (under mu)
   std::mutex mu;
-  // doc filters (slg_index_add_filter*): per filter and segment a reject bitmap (deleted | ~filter)
-  std::vector<std::vector<DevBuf>> filters;  // [filter][seg]; a removed filter keeps empty bufs
-  std::vector<const uint32_t *> reject_host;  // flattened [filter * n_segs + seg] device pointers
-  DevBuf d_reject_table;                      // the same table on the device
+  std::mutex update_mu;  // serialises slg_index_update_* / add_filter / add_vector_field (taken before mu)
   // profiling of the scoring kernel
   bool profile = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   size_t prof_used = 0;
+  // set by a scoring wave that had to give up on a round (chunk-loop guard): checked at fetch
+  DevBuf d_error_flag;
+  std::shared_ptr<const IndexState> snapshot() {
+    std::lock_guard<std::mutex> lk(mu);
+    return state;
+  }
 };
 
 struct slg_batch {
   slg_index *idx = nullptr;
+  std::shared_ptr<const IndexState> snap;  // the index state the batch was prepared on
   uint32_t nq = 0, k = 0;
   int strategy = 0;
   uint32_t n_sq = 0, n_slices = 0, n_terms = 0, n_boundaries = 0, max_terms = 0;
@@ -477,124 +544,252 @@ static inline hipStream_t batch_stream(const slg_batch *b) {
   return b->own_stream_set ? b->stream : b->idx->stream;
 }
 
-void stage_segment(slg_index *ix, SegHost &sh, const slg_segment_desc &d) {
+// The version of a staged segment for (deleted bitmap, live_docs): impacts (stage_impacts_kernel:
+// query/bm25.rs:1-6 with idf from the host's logf), champion bounds, host mirror.  At creation the
+// kernel also scatters the uploaded doc ids into the padded layout (docs_in != nullptr); for an
+// update it reads them back from there.  Temporaries of a non-updatable store are passed in `tmp`.
+struct StageTemps {
+  const uint32_t *docs_in = nullptr;   // [P] unpadded doc ids as uploaded (creation only)
+};
+void derive_version(slg_index *ix, const std::shared_ptr<PostingStore> &ps, SegHost &sh, const uint8_t *deleted,
+                    float docs, const StageTemps &tmp) {
   hipStream_t st = ix->stream;
-  sh.n_docs = d.n_docs;
-  sh.n_terms = d.n_terms;
-  sh.term_offsets.assign(d.term_offsets, d.term_offsets + d.n_terms + 1);
-  const uint64_t P = sh.term_offsets[d.n_terms];
-  sh.n_postings = P;
+  sh.store = ps;
+  sh.n_docs = ps->n_docs;
+  sh.n_terms = ps->n_terms;
+  sh.n_postings = ps->n_postings;
+  sh.null_idx = ps->null_idx;
+  sh.docs = docs;
+  const uint64_t P = ps->n_postings;
+  const uint64_t P_pad = P + (uint64_t)slg::kListPad * (uint64_t)ps->n_terms + (uint64_t)slg::kNullRun;
+  sh.d_imps.alloc(P_pad * 4, &ix->pool);
+  SLG_HIP(hipMemsetAsync(sh.d_imps.p, 0, P_pad * 4, st));
+  if (deleted) {
+    const size_t words = ((size_t)ps->n_docs + 31) / 32;
+    std::vector<uint32_t> w(words ? words : 1, 0u);
+    std::memcpy(w.data(), deleted, ((size_t)ps->n_docs + 7) / 8);
+    sh.d_deleted.alloc(w.size() * 4, &ix->pool);
+    SLG_HIP(hipMemcpy(sh.d_deleted.p, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+  }
+  if (P == 0) return;
+  // idf per term: query/bm25.rs:2 with df = postings.len() as f32 (wand.rs:108,471)
+  std::vector<float> idf(ps->n_terms);
+  for (uint32_t t = 0; t < ps->n_terms; t++) {
+    const float df = (float)(uint32_t)(ps->term_offsets[t + 1] - ps->term_offsets[t]);
+    idf[t] = fmaxf(logf((docs - df + 0.5f) / (df + 0.5f)), 0.0f) + 1.0f;
+  }
+  DevBuf d_idf;
+  d_idf.alloc((size_t)ps->n_terms * 4, &ix->pool);
+  SLG_HIP(hipMemcpyAsync(d_idf.p, idf.data(), (size_t)ps->n_terms * 4, hipMemcpyHostToDevice, st));
+  slg::StageParams sp{};
+  sp.n_postings = P;
+  sp.n_terms = ps->n_terms;
+  sp.n_docs = ps->n_docs;
+  sp.term_offsets = ps->d_offs.as<uint64_t>();
+  sp.docs = tmp.docs_in;
+  sp.docs_out = ps->d_docs.as<uint32_t>();
+  sp.tfs = ps->d_tfs.as<uint32_t>();
+  sp.term_idf = d_idf.as<float>();
+  sp.term_field = ps->has_term_field ? ps->d_tfield.as<uint16_t>() : nullptr;
+  sp.field_doc_len = ps->d_lenptrs.as<const float *>();
+  sp.field_avgdl = ps->d_avgdl.as<float>();
+  sp.k1 = ps->k1;
+  sp.b = ps->b;
+  sp.imps = sh.d_imps.as<float>();
+  const uint64_t want = (P + 255) / 256;
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>(want, 256ull * 32);
+  hipLaunchKernelGGL(slg::stage_impacts_kernel, dim3(blocks), dim3(256), 0, st, sp);
+  SLG_HIP(hipGetLastError());
+  if (ix->tune.champions) {
+    sh.d_champ.alloc((size_t)ps->n_terms * slg::kChampions * 4, &ix->pool);
+    slg::ChampParams cp{};
+    cp.term_offsets = ps->d_offs.as<uint64_t>();
+    cp.imps = sh.d_imps.as<float>();
+    cp.docs = ps->d_docs.as<uint32_t>();
+    cp.deleted = sh.d_deleted.as<uint32_t>();
+    cp.champ = sh.d_champ.as<float>();
+    cp.n_terms = ps->n_terms;
+    const uint32_t cblocks = std::min<uint32_t>((ps->n_terms + 3) / 4, 256u * 16);
+    hipLaunchKernelGGL(slg::stage_champions_kernel, dim3(cblocks ? cblocks : 1), dim3(256), 0, st, cp);
+    SLG_HIP(hipGetLastError());
+  }
+  SLG_HIP(hipStreamSynchronize(st));  // d_idf dies here
+  if (sh.d_champ.p) {
+    sh.champ.resize((size_t)ps->n_terms * slg::kChampions);
+    SLG_HIP(hipMemcpy(sh.champ.data(), sh.d_champ.p, sh.champ.size() * 4, hipMemcpyDeviceToHost));
+  }
+}
+
+std::shared_ptr<SegHost> stage_segment(slg_index *ix, const slg_segment_desc &d) {
+  hipStream_t st = ix->stream;
+  auto ps = std::make_shared<PostingStore>();
+  ps->n_docs = d.n_docs;
+  ps->n_terms = d.n_terms;
+  ps->n_fields = d.n_fields;
+  ps->term_offsets.assign(d.term_offsets, d.term_offsets + d.n_terms + 1);
+  ps->avgdl.assign(d.field_avgdl, d.field_avgdl + d.n_fields);
+  ps->k1 = d.k1;
+  ps->b = d.b;
+  ps->has_term_field = d.term_field != nullptr;
+  ps->updatable = ix->tune.updatable != 0;
+  const uint64_t P = ps->term_offsets[d.n_terms];
+  ps->n_postings = P;
 
   // padded layout (SegDev): every list is followed by kListPad sentinel entries, + a run of kNullRun
   // at the end (null_idx): the scoring kernels load whole 64-lane slots starting at any posting
   const uint64_t P_pad = P + (uint64_t)slg::kListPad * (uint64_t)d.n_terms + (uint64_t)slg::kNullRun;
-  sh.null_idx = P + (uint64_t)slg::kListPad * d.n_terms;
-  sh.d_docs.alloc(P_pad * 4, &ix->pool);
-  sh.d_imps.alloc(P_pad * 4, &ix->pool);
-  SLG_HIP(hipMemsetAsync(sh.d_docs.p, 0xFF, P_pad * 4, st));
-  SLG_HIP(hipMemsetAsync(sh.d_imps.p, 0, P_pad * 4, st));
-  ix->device_bytes += sh.d_docs.bytes + sh.d_imps.bytes;
-  if (d.deleted) {
-    const size_t words = ((size_t)d.n_docs + 31) / 32;
-    std::vector<uint32_t> w(words ? words : 1, 0u);
-    std::memcpy(w.data(), d.deleted, ((size_t)d.n_docs + 7) / 8);
-    sh.d_deleted.alloc(w.size() * 4);
-    SLG_HIP(hipMemcpy(sh.d_deleted.p, w.data(), w.size() * 4, hipMemcpyHostToDevice));
-    ix->device_bytes += sh.d_deleted.bytes;
-  }
+  ps->null_idx = P + (uint64_t)slg::kListPad * d.n_terms;
+  ps->d_docs.alloc(P_pad * 4, &ix->pool);
+  SLG_HIP(hipMemsetAsync(ps->d_docs.p, 0xFF, P_pad * 4, st));
+  DevBuf d_docs_in;  // the uploaded (unpadded) doc ids: staging only
   if (P > 0) {
-    // temporaries used only by the staging kernel
-    DevBuf d_docs_in, d_tfs, d_offs, d_idf, d_tfield, d_avgdl, d_lenptrs;
-    std::vector<DevBuf> d_lens(d.n_fields);
-    d_docs_in.alloc(P * 4);
-    d_tfs.alloc(P * 4);
+    d_docs_in.alloc(P * 4, &ix->pool);
+    ps->d_tfs.alloc(P * 4, &ix->pool);
     SLG_HIP(hipMemcpyAsync(d_docs_in.p, d.doc_ids, P * 4, hipMemcpyHostToDevice, st));
-    SLG_HIP(hipMemcpyAsync(d_tfs.p, d.tfs, P * 4, hipMemcpyHostToDevice, st));
-    d_offs.alloc(((size_t)d.n_terms + 1) * 8);
-    SLG_HIP(hipMemcpyAsync(d_offs.p, sh.term_offsets.data(), ((size_t)d.n_terms + 1) * 8,
+    SLG_HIP(hipMemcpyAsync(ps->d_tfs.p, d.tfs, P * 4, hipMemcpyHostToDevice, st));
+    ps->d_offs.alloc(((size_t)d.n_terms + 1) * 8, &ix->pool);
+    SLG_HIP(hipMemcpyAsync(ps->d_offs.p, ps->term_offsets.data(), ((size_t)d.n_terms + 1) * 8,
                            hipMemcpyHostToDevice, st));
-    // idf per term: query/bm25.rs:2 with df = postings.len() as f32 (wand.rs:108,471)
-    std::vector<float> idf(d.n_terms);
-    for (uint32_t t = 0; t < d.n_terms; t++) {
-      const float df = (float)(uint32_t)(sh.term_offsets[t + 1] - sh.term_offsets[t]);
-      idf[t] = fmaxf(logf((d.docs - df + 0.5f) / (df + 0.5f)), 0.0f) + 1.0f;
-    }
-    d_idf.alloc((size_t)d.n_terms * 4);
-    SLG_HIP(hipMemcpyAsync(d_idf.p, idf.data(), (size_t)d.n_terms * 4, hipMemcpyHostToDevice, st));
     if (d.term_field) {
-      d_tfield.alloc((size_t)d.n_terms * 2);
-      SLG_HIP(hipMemcpyAsync(d_tfield.p, d.term_field, (size_t)d.n_terms * 2,
-                             hipMemcpyHostToDevice, st));
+      ps->d_tfield.alloc((size_t)d.n_terms * 2, &ix->pool);
+      SLG_HIP(hipMemcpyAsync(ps->d_tfield.p, d.term_field, (size_t)d.n_terms * 2, hipMemcpyHostToDevice, st));
     }
-    d_avgdl.alloc((size_t)d.n_fields * 4);
-    SLG_HIP(hipMemcpyAsync(d_avgdl.p, d.field_avgdl, (size_t)d.n_fields * 4,
-                           hipMemcpyHostToDevice, st));
+    ps->d_avgdl.alloc((size_t)d.n_fields * 4, &ix->pool);
+    SLG_HIP(hipMemcpyAsync(ps->d_avgdl.p, d.field_avgdl, (size_t)d.n_fields * 4, hipMemcpyHostToDevice, st));
+    ps->d_lens.resize(d.n_fields);
     std::vector<const float *> lenptrs(d.n_fields, nullptr);
     for (uint32_t f = 0; f < d.n_fields; f++) {
       if (d.field_doc_len[f] && d.n_docs) {
-        d_lens[f].alloc((size_t)d.n_docs * 4);
-        SLG_HIP(hipMemcpyAsync(d_lens[f].p, d.field_doc_len[f], (size_t)d.n_docs * 4,
-                               hipMemcpyHostToDevice, st));
-        lenptrs[f] = d_lens[f].as<float>();
+        ps->d_lens[f].alloc((size_t)d.n_docs * 4, &ix->pool);
+        SLG_HIP(hipMemcpyAsync(ps->d_lens[f].p, d.field_doc_len[f], (size_t)d.n_docs * 4, hipMemcpyHostToDevice, st));
+        lenptrs[f] = ps->d_lens[f].as<float>();
       }
     }
-    d_lenptrs.alloc((size_t)d.n_fields * sizeof(float *));
-    SLG_HIP(hipMemcpyAsync(d_lenptrs.p, lenptrs.data(), (size_t)d.n_fields * sizeof(float *),
-                           hipMemcpyHostToDevice, st));
-    slg::StageParams sp{};
-    sp.n_postings = P;
-    sp.n_terms = d.n_terms;
-    sp.n_docs = d.n_docs;
-    sp.term_offsets = d_offs.as<uint64_t>();
-    sp.docs = d_docs_in.as<uint32_t>();
-    sp.docs_out = sh.d_docs.as<uint32_t>();
-    sp.tfs = d_tfs.as<uint32_t>();
-    sp.term_idf = d_idf.as<float>();
-    sp.term_field = d.term_field ? d_tfield.as<uint16_t>() : nullptr;
-    sp.field_doc_len = d_lenptrs.as<const float *>();
-    sp.field_avgdl = d_avgdl.as<float>();
-    sp.k1 = d.k1;
-    sp.b = d.b;
-    sp.imps = sh.d_imps.as<float>();
-    const uint64_t want = (P + 255) / 256;
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>(want, 256ull * 32);
-    hipLaunchKernelGGL(slg::stage_impacts_kernel, dim3(blocks), dim3(256), 0, st, sp);
-    SLG_HIP(hipGetLastError());
-    if (ix->tune.champions) {
-      sh.d_champ.alloc((size_t)d.n_terms * slg::kChampions * 4);
-      ix->device_bytes += sh.d_champ.bytes;
-      slg::ChampParams cp{};
-      cp.term_offsets = d_offs.as<uint64_t>();
-      cp.imps = sh.d_imps.as<float>();
-      cp.docs = sh.d_docs.as<uint32_t>();
-      cp.deleted = sh.d_deleted.as<uint32_t>();
-      cp.champ = sh.d_champ.as<float>();
-      cp.n_terms = d.n_terms;
-      const uint32_t cblocks = std::min<uint32_t>((d.n_terms + 3) / 4, 256u * 16);
-      hipLaunchKernelGGL(slg::stage_champions_kernel, dim3(cblocks ? cblocks : 1), dim3(256), 0, st, cp);
-      SLG_HIP(hipGetLastError());
-    }
-    SLG_HIP(hipStreamSynchronize(st));  // temporaries die here
-    if (sh.d_champ.p) {
-      sh.champ.resize((size_t)d.n_terms * slg::kChampions);
-      SLG_HIP(hipMemcpy(sh.champ.data(), sh.d_champ.p, sh.champ.size() * 4, hipMemcpyDeviceToHost));
-    }
+    ps->d_lenptrs.alloc((size_t)d.n_fields * sizeof(float *), &ix->pool);
+    SLG_HIP(hipMemcpy(ps->d_lenptrs.p, lenptrs.data(), (size_t)d.n_fields * sizeof(float *), hipMemcpyHostToDevice));
+  }
+  auto sh = std::make_shared<SegHost>();
+  StageTemps tmp;
+  tmp.docs_in = d_docs_in.as<uint32_t>();
+  derive_version(ix, ps, *sh, d.deleted, d.docs, tmp);  // (synchronises the stream when P > 0)
+  if (!ps->updatable) {  // what only an update would read again
+    ps->d_tfs.release();
+    ps->d_offs.release();
+    ps->d_tfield.release();
+    ps->d_avgdl.release();
+    ps->d_lenptrs.release();
+    ps->d_lens.clear();
   }
   if (d.vec_dim) {
-    sh.vec_dim = d.vec_dim;
-    sh.vec_rows = d.vec_rows;
-    sh.vec_metric = d.vec_metric;
-    sh.d_vec_offsets.alloc((size_t)d.n_docs * 4);
+    ps->vec_dim = d.vec_dim;
+    ps->vec_rows = d.vec_rows;
+    ps->vec_metric = d.vec_metric;
+    ps->d_vec_offsets.alloc((size_t)d.n_docs * 4, &ix->pool);
     if (d.n_docs)
-      SLG_HIP(hipMemcpy(sh.d_vec_offsets.p, d.vec_offsets, (size_t)d.n_docs * 4,
-                        hipMemcpyHostToDevice));
+      SLG_HIP(hipMemcpy(ps->d_vec_offsets.p, d.vec_offsets, (size_t)d.n_docs * 4, hipMemcpyHostToDevice));
     const size_t vb = (size_t)d.vec_rows * d.vec_dim * 4;
-    sh.d_vec_values.alloc(vb);
-    if (vb) SLG_HIP(hipMemcpy(sh.d_vec_values.p, d.vec_values, vb, hipMemcpyHostToDevice));
-    ix->device_bytes += sh.d_vec_offsets.bytes + sh.d_vec_values.bytes;
+    ps->d_vec_values.alloc(vb, &ix->pool);
+    if (vb) SLG_HIP(hipMemcpy(ps->d_vec_values.p, d.vec_values, vb, hipMemcpyHostToDevice));
+  }
+  SLG_HIP(hipStreamSynchronize(st));
+  return sh;
+}
+
+// the device tables of a state (segment descriptors, vector stores, reject-bitmap pointers): small,
+// rebuilt for every state
+void finish_state(slg_index *ix, IndexState &s) {
+  const size_t n_segs = s.segs.size();
+  s.device = ix->device;
+  std::vector<slg::SegDev> sd(n_segs);
+  std::vector<slg::VecSegDev> vd(n_segs);
+  for (size_t i = 0; i < n_segs; i++) {
+    const SegHost &sh = *s.segs[i];
+    sd[i].docs = sh.store->d_docs.as<uint32_t>();
+    sd[i].imps = sh.d_imps.as<float>();
+    sd[i].deleted = sh.d_deleted.as<uint32_t>();
+    sd[i].champ = sh.d_champ.as<float>();
+    sd[i].n_docs = sh.n_docs;
+    sd[i].pad = 0;
+    sd[i].null_idx = sh.null_idx;
+    vd[i].offsets = sh.store->d_vec_offsets.as<uint32_t>();
+    vd[i].values = sh.store->d_vec_values.as<float>();
+    vd[i].n_docs = sh.n_docs;
+    vd[i].dim = sh.store->vec_dim;
+    vd[i].metric = sh.store->vec_metric;
+    vd[i].pad = 0;
+  }
+  s.d_segs.alloc(std::max<size_t>(n_segs, 1) * sizeof(slg::SegDev), &ix->pool);
+  s.d_vsegs.alloc(std::max<size_t>(n_segs, 1) * sizeof(slg::VecSegDev), &ix->pool);
+  if (n_segs) {
+    SLG_HIP(hipMemcpy(s.d_segs.p, sd.data(), n_segs * sizeof(slg::SegDev), hipMemcpyHostToDevice));
+    SLG_HIP(hipMemcpy(s.d_vsegs.p, vd.data(), n_segs * sizeof(slg::VecSegDev), hipMemcpyHostToDevice));
+  }
+  for (auto &vfp : s.vfields) {  // (the field objects of a new state are fresh copies: see copy_state)
+    VecFieldHost &vf = *vfp;
+    std::vector<slg::VecSegDev> fv(n_segs);
+    for (size_t i = 0; i < n_segs; i++) {
+      fv[i] = slg::VecSegDev{nullptr, nullptr, s.segs[i]->n_docs, 0u, vf.metric, 0u};
+      if (i < vf.per_seg.size() && vf.per_seg[i]) {
+        fv[i].offsets = vf.per_seg[i]->offsets.as<uint32_t>();
+        fv[i].values = vf.per_seg[i]->values.as<float>();
+        fv[i].dim = vf.per_seg[i]->dim;
+      }
+    }
+    vf.d_vsegs.alloc(std::max<size_t>(n_segs, 1) * sizeof(slg::VecSegDev), &ix->pool);
+    if (n_segs) SLG_HIP(hipMemcpy(vf.d_vsegs.p, fv.data(), n_segs * sizeof(slg::VecSegDev), hipMemcpyHostToDevice));
+  }
+  s.reject_host.assign(s.filters.size() * n_segs, nullptr);
+  for (size_t f = 0; f < s.filters.size(); f++)
+    if (s.filters[f])
+      for (size_t i = 0; i < n_segs && i < s.filters[f]->per_seg.size(); i++)
+        if (s.filters[f]->per_seg[i]) s.reject_host[f * n_segs + i] = s.filters[f]->per_seg[i]->as<uint32_t>();
+  s.d_reject_table.alloc(std::max<size_t>(s.reject_host.size(), 1) * sizeof(void *), &ix->pool);
+  if (!s.reject_host.empty())
+    SLG_HIP(hipMemcpy(s.d_reject_table.p, s.reject_host.data(), s.reject_host.size() * sizeof(void *),
+                      hipMemcpyHostToDevice));
+}
+
+// the next state: the current one's segments / fields / filters (shared), the device tables not yet built
+std::unique_ptr<IndexState> copy_state(const IndexState &cur) {
+  auto n = std::make_unique<IndexState>();
+  n->generation = cur.generation + 1;
+  n->device = cur.device;
+  n->segs = cur.segs;
+  n->filters = cur.filters;
+  for (auto &vf : cur.vfields) {  // the per-state table d_vsegs is rebuilt: own object, shared stores
+    auto c = std::make_shared<VecFieldHost>();
+    c->dim = vf->dim;
+    c->metric = vf->metric;
+    c->per_seg = vf->per_seg;
+    n->vfields.push_back(std::move(c));
+  }
+  return n;
+}
+
+void publish(slg_index *ix, std::unique_ptr<IndexState> ns) {
+  std::shared_ptr<const IndexState> keep;  // (the old state may die here: outside the lock)
+  std::shared_ptr<const IndexState> fresh(std::move(ns));
+  {
+    std::lock_guard<std::mutex> lk(ix->mu);
+    keep.swap(ix->state);
+    ix->state = fresh;
   }
 }
 
+size_t state_device_bytes(const IndexState &s) {
+  size_t n = s.d_segs.bytes + s.d_vsegs.bytes + s.d_reject_table.bytes;
+  for (auto &sh : s.segs) n += sh->device_bytes() + sh->store->device_bytes();
+  for (auto &f : s.filters)
+    if (f)
+      for (auto &b : f->per_seg)
+        if (b) n += b->bytes;
+  for (auto &vf : s.vfields) {
+    n += vf->d_vsegs.bytes;
+    for (auto &v : vf->per_seg)
+      if (v) n += v->offsets.bytes + v->values.bytes;
+  }
+  return n;
+}
 
 }  // namespace
 
@@ -637,6 +832,7 @@ void slg_tuning_default(slg_tuning *t) {
   t->uniform_kernel = env_u32("SLG_UNIFORM_KERNEL", 4);
   t->uniform_sigma_x100 = env_u32("SLG_UNIFORM_SIGMA", 0);
   t->inline_cuts = env_i32("SLG_INLINE_CUTS", -1);
+  t->updatable = env_i32("SLG_NOT_UPDATABLE", 0) == 0;
 }
 
 slg_index *slg_index_create(const slg_segment_desc *segs, uint32_t n_segs, int device) {
@@ -655,6 +851,12 @@ slg_index *slg_index_create_tuned(const slg_segment_desc *segs, uint32_t n_segs,
     } else {
       slg_tuning_default(&tune);
     }
+    // (a zero-initialised struct from a C or Rust caller must not plan for one kernel and launch another)
+    SLG_REQUIRE(tune.uniform_kernel >= 2 && tune.uniform_kernel <= 4, "slg_tuning.uniform_kernel must be 2, 3 or 4");
+#ifndef SLG_LEGACY_KERNELS
+    if (tune.uniform_kernel != 4)
+      throw SlgError(SLG_ERR_UNSUPPORTED, "slg_tuning.uniform_kernel 2 / 3 need a library built with -DSLG_LEGACY_KERNELS");
+#endif
     tune.uniform_max_terms = std::min<uint32_t>(
         tune.uniform_max_terms, tune.uniform_kernel == 2 ? slg::kUniMaxLists : slg::kU3MaxLists);
     tune.max_rounds_per_slice = std::min<uint32_t>(tune.max_rounds_per_slice, slg::kMaxRoundsPerSlice);
@@ -676,27 +878,10 @@ slg_index *slg_index_create_tuned(const slg_segment_desc *segs, uint32_t n_segs,
     SLG_HIP(hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking));
     ix->stream = ix->own_stream;
     for (auto &us : ix->upload_streams) SLG_HIP(hipStreamCreateWithFlags(&us, hipStreamNonBlocking));
-    for (uint32_t s = 0; s < n_segs; s++) {
-      ix->segs.emplace_back(new SegHost());
-      stage_segment(ix, *ix->segs[s], segs[s]);
-    }
-    std::vector<slg::SegDev> sd(n_segs);
-    std::vector<slg::VecSegDev> vd(n_segs);
-    for (uint32_t s = 0; s < n_segs; s++) {
-      sd[s].docs = ix->segs[s]->d_docs.as<uint32_t>();
-      sd[s].imps = ix->segs[s]->d_imps.as<float>();
-      sd[s].deleted = ix->segs[s]->d_deleted.as<uint32_t>();
-      sd[s].champ = ix->segs[s]->d_champ.as<float>();
-      sd[s].n_docs = ix->segs[s]->n_docs;
-      sd[s].pad = 0;
-      sd[s].null_idx = ix->segs[s]->null_idx;
-      vd[s].offsets = ix->segs[s]->d_vec_offsets.as<uint32_t>();
-      vd[s].values = ix->segs[s]->d_vec_values.as<float>();
-      vd[s].n_docs = ix->segs[s]->n_docs;
-      vd[s].dim = ix->segs[s]->vec_dim;
-      vd[s].metric = ix->segs[s]->vec_metric;
-      vd[s].pad = 0;
-    }
+    auto st0 = std::make_unique<IndexState>();
+    st0->generation = 0;
+    st0->device = device;
+    for (uint32_t s = 0; s < n_segs; s++) st0->segs.push_back(stage_segment(ix, segs[s]));
     {  // bound of the work-buffer pool (BufPool): a quarter of what staging left free
       size_t cap = (size_t)tune.pool_cap_mb << 20;
       if (tune.pool_cap_mb == 0) {
@@ -707,11 +892,10 @@ slg_index *slg_index_create_tuned(const slg_segment_desc *segs, uint32_t n_segs,
       }
       ix->pool.cap = cap;
     }
-    ix->d_segs.alloc(n_segs * sizeof(slg::SegDev));
-    SLG_HIP(hipMemcpy(ix->d_segs.p, sd.data(), n_segs * sizeof(slg::SegDev), hipMemcpyHostToDevice));
-    ix->d_vsegs.alloc(n_segs * sizeof(slg::VecSegDev));
-    SLG_HIP(hipMemcpy(ix->d_vsegs.p, vd.data(), n_segs * sizeof(slg::VecSegDev),
-                      hipMemcpyHostToDevice));
+    ix->d_error_flag.alloc(16, &ix->pool);
+    SLG_HIP(hipMemset(ix->d_error_flag.p, 0, 16));
+    finish_state(ix, *st0);
+    publish(ix, std::move(st0));
   });
   if (rc != SLG_OK) {
     const std::string keep = g_last_error;
@@ -749,6 +933,7 @@ void slg_index_destroy(slg_index *ix) {
     std::lock_guard<std::mutex> lk(ix->mu);
     for (slg_batch *b : ix->live) {
       release_batch_buffers(b, false);
+      b->snap.reset();
       b->idx = nullptr;
     }
     ix->live.clear();
@@ -757,10 +942,12 @@ void slg_index_destroy(slg_index *ix) {
     (void)hipEventDestroy(pr.first);
     (void)hipEventDestroy(pr.second);
   }
-  ix->segs.clear();
-  ix->vfields.clear();
-  ix->d_segs.release();
-  ix->d_vsegs.release();
+  {
+    std::shared_ptr<const IndexState> last;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    last.swap(ix->state);
+  }  // (the state's device memory goes here unless a detached batch handle still holds a snapshot)
+  ix->d_error_flag.release();
   if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
   for (auto us : ix->upload_streams)
     if (us) (void)hipStreamDestroy(us);
@@ -788,11 +975,12 @@ int slg_index_info(const slg_index *ix, uint32_t *n_segs, uint64_t *n_postings,
                    uint64_t *device_bytes) {
   return guarded([&] {
     SLG_REQUIRE(ix != nullptr, "index is NULL");
+    const auto st = const_cast<slg_index *>(ix)->snapshot();
     uint64_t P = 0;
-    for (auto &s : ix->segs) P += s->n_postings;
-    if (n_segs) *n_segs = (uint32_t)ix->segs.size();
+    for (auto &s : st->segs) P += s->n_postings;
+    if (n_segs) *n_segs = (uint32_t)st->segs.size();
     if (n_postings) *n_postings = P;
-    if (device_bytes) *device_bytes = ix->device_bytes;
+    if (device_bytes) *device_bytes = state_device_bytes(*st);
   });
 }
 
@@ -814,20 +1002,23 @@ int add_filter_impl(slg_index *ix, const uint8_t *const *seg_bitmaps, const void
   int id = -1;
   int rc = guarded([&] {
     SLG_REQUIRE(ix != nullptr, "index is NULL");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    std::lock_guard<std::mutex> ulk(ix->update_mu);
+    const auto cur = ix->snapshot();
     DeviceGuard g(ix->device);
     hipStream_t st = ix->stream;
-    const size_t n_segs = ix->segs.size();
-    std::vector<DevBuf> bufs(n_segs);
+    const size_t n_segs = cur->segs.size();
+    auto fd = std::make_shared<FilterData>();
+    fd->per_seg.resize(n_segs);
     std::vector<DevBuf> tmp(n_segs);  // uploaded pass bitmaps / columns (freed on return)
     for (size_t s = 0; s < n_segs; s++) {
-      const SegHost &sh = *ix->segs[s];
+      const SegHost &sh = *cur->segs[s];
       const size_t words = ((size_t)sh.n_docs + 31) / 32;
-      bufs[s].alloc((words ? words : 1) * 4, &ix->pool);
+      fd->per_seg[s] = std::make_shared<DevBuf>();
+      fd->per_seg[s]->alloc((words ? words : 1) * 4, &ix->pool);
       slg::FilterBuildParams fp{};
       fp.deleted = sh.d_deleted.as<uint32_t>();
       fp.n_docs = sh.n_docs;
-      fp.reject = bufs[s].as<uint32_t>();
+      fp.reject = fd->per_seg[s]->as<uint32_t>();
       fp.column_kind = 0;
       if (column_kind) {
         SLG_REQUIRE(seg_columns && seg_columns[s], "filter column of a segment is NULL");
@@ -852,20 +1043,18 @@ int add_filter_impl(slg_index *ix, const uint8_t *const *seg_bitmaps, const void
       }
     }
     SLG_HIP(hipStreamSynchronize(st));
-    for (size_t s = 0; s < n_segs; s++) ix->device_bytes += bufs[s].bytes;
-    id = (int)ix->filters.size();
-    ix->filters.push_back(std::move(bufs));
-    // rebuild the device pointer table (batches read it at run time; ids are stable)
-    ix->reject_host.assign(ix->filters.size() * n_segs, nullptr);
-    for (size_t f = 0; f < ix->filters.size(); f++)
-      for (size_t s = 0; s < ix->filters[f].size(); s++)
-        ix->reject_host[f * n_segs + s] = ix->filters[f][s].as<uint32_t>();
-    DevBuf nt;
-    nt.alloc(std::max<size_t>(ix->reject_host.size(), 1) * sizeof(void *), &ix->pool);
-    SLG_HIP(hipMemcpy(nt.p, ix->reject_host.data(), ix->reject_host.size() * sizeof(void *),
-                      hipMemcpyHostToDevice));
-    SLG_HIP(hipDeviceSynchronize());  // no kernel may still read the old table
-    ix->d_reject_table = std::move(nt);
+    // the next state: the filter takes the lowest free id (ids of removed filters are reused, so the
+    // pointer table stays as small as the number of filters alive at once).  Batches prepared on
+    // earlier states keep their own table: nobody waits for the device here
+    auto ns = copy_state(*cur);
+    ns->generation = cur->generation;  // (filters do not change what a manifest snapshot sees)
+    size_t slot = 0;
+    while (slot < ns->filters.size() && ns->filters[slot]) slot++;
+    if (slot == ns->filters.size()) ns->filters.emplace_back();
+    ns->filters[slot] = std::move(fd);
+    finish_state(ix, *ns);
+    publish(ix, std::move(ns));
+    id = (int)slot;
   });
   return rc == SLG_OK ? id : rc;
 }
@@ -883,14 +1072,112 @@ int slg_index_add_filter_range_f64(slg_index *ix, const double *const *seg_colum
 int slg_index_remove_filter(slg_index *ix, int filter_id) {
   return guarded([&] {
     SLG_REQUIRE(ix != nullptr, "index is NULL");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    std::lock_guard<std::mutex> ulk(ix->update_mu);
+    const auto cur = ix->snapshot();
     DeviceGuard g(ix->device);
-    SLG_REQUIRE(filter_id >= 0 && (size_t)filter_id < ix->filters.size() && !ix->filters[filter_id].empty(),
+    SLG_REQUIRE(filter_id >= 0 && (size_t)filter_id < cur->filters.size() && cur->filters[filter_id],
                 "unknown filter id");
-    SLG_HIP(hipDeviceSynchronize());
-    for (auto &bf : ix->filters[filter_id]) ix->device_bytes -= bf.bytes;
-    ix->filters[filter_id].clear();  // the id is never reused
+    // batches prepared with the filter hold the state that owns its bitmaps and its table row: they
+    // may still run.  The slot is free for the next add
+    auto ns = copy_state(*cur);
+    ns->generation = cur->generation;
+    ns->filters[filter_id].reset();
+    while (!ns->filters.empty() && !ns->filters.back()) ns->filters.pop_back();
+    finish_state(ix, *ns);
+    publish(ix, std::move(ns));
   });
+}
+
+// ---- index updates (api/writer.rs:106-240) ---------------------------------------------------
+int slg_index_update_deleted(slg_index *ix, uint32_t seg, const uint8_t *deleted, float live_docs) {
+  return guarded([&] {
+    SLG_REQUIRE(ix != nullptr, "index is NULL");
+    std::lock_guard<std::mutex> ulk(ix->update_mu);
+    const auto cur = ix->snapshot();
+    SLG_REQUIRE(seg < cur->segs.size(), "no such segment");
+    SLG_REQUIRE(live_docs >= 0.0f && live_docs <= (float)cur->segs[seg]->n_docs, "live_docs outside [0, n_docs]");
+    const std::shared_ptr<PostingStore> &ps = cur->segs[seg]->store;
+    if (!ps->updatable)
+      throw SlgError(SLG_ERR_UNSUPPORTED, "index was created with slg_tuning.updatable = 0");
+    DeviceGuard g(ix->device);
+    auto sh = std::make_shared<SegHost>();
+    derive_version(ix, ps, *sh, deleted, live_docs, StageTemps{});
+    auto ns = copy_state(*cur);
+    ns->segs[seg] = sh;
+    // registered filters: reject = deleted | ~filter, so this segment's bitmaps take the new tombstones
+    const size_t words = std::max<size_t>(((size_t)ps->n_docs + 31) / 32, 1);
+    for (auto &f : ns->filters) {
+      if (!f || seg >= f->per_seg.size() || !f->per_seg[seg]) continue;
+      auto nf = std::make_shared<FilterData>(*f);
+      auto nb = std::make_shared<DevBuf>();
+      nb->alloc(words * 4, &ix->pool);
+      slg::BitmapOrParams bp{};
+      bp.a = f->per_seg[seg]->as<uint32_t>();
+      bp.b = sh->d_deleted.as<uint32_t>();
+      bp.out = nb->as<uint32_t>();
+      bp.n_words = (uint32_t)words;
+      hipLaunchKernelGGL(slg::bitmap_or_kernel, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, ix->stream, bp);
+      SLG_HIP(hipGetLastError());
+      nf->per_seg[seg] = std::move(nb);
+      f = std::move(nf);
+    }
+    SLG_HIP(hipStreamSynchronize(ix->stream));
+    finish_state(ix, *ns);
+    publish(ix, std::move(ns));
+  });
+}
+
+int slg_index_add_segment(slg_index *ix, const slg_segment_desc *seg) {
+  int ord = -1;
+  const int rc = guarded([&] {
+    SLG_REQUIRE(ix != nullptr && seg != nullptr, "index or segment descriptor is NULL");
+    validate_segment(*seg, 0, ix->tune.validate != 0);
+    std::lock_guard<std::mutex> ulk(ix->update_mu);
+    const auto cur = ix->snapshot();
+    DeviceGuard g(ix->device);
+    auto sh = stage_segment(ix, *seg);
+    auto ns = copy_state(*cur);
+    ns->segs.push_back(std::move(sh));
+    for (auto &f : ns->filters)  // no bitmap for the new segment: unusable until registered again
+      if (f) {
+        auto nf = std::make_shared<FilterData>(*f);
+        nf->per_seg.resize(ns->segs.size());
+        f = std::move(nf);
+      }
+    for (auto &vf : ns->vfields) vf->per_seg.resize(ns->segs.size());
+    finish_state(ix, *ns);
+    ord = (int)ns->segs.size() - 1;
+    publish(ix, std::move(ns));
+  });
+  return rc == SLG_OK ? ord : rc;
+}
+
+int slg_index_remove_segment(slg_index *ix, uint32_t seg) {
+  return guarded([&] {
+    SLG_REQUIRE(ix != nullptr, "index is NULL");
+    std::lock_guard<std::mutex> ulk(ix->update_mu);
+    const auto cur = ix->snapshot();
+    SLG_REQUIRE(seg < cur->segs.size(), "no such segment");
+    SLG_REQUIRE(cur->segs.size() > 1, "the last segment of an index cannot be removed (add the replacement first)");
+    DeviceGuard g(ix->device);
+    auto ns = copy_state(*cur);
+    ns->segs.erase(ns->segs.begin() + seg);
+    for (auto &f : ns->filters)
+      if (f) {
+        auto nf = std::make_shared<FilterData>(*f);
+        if (seg < nf->per_seg.size()) nf->per_seg.erase(nf->per_seg.begin() + seg);
+        f = std::move(nf);
+      }
+    for (auto &vf : ns->vfields)
+      if (seg < vf->per_seg.size()) vf->per_seg.erase(vf->per_seg.begin() + seg);
+    finish_state(ix, *ns);
+    publish(ix, std::move(ns));
+  });
+}
+
+uint64_t slg_index_generation(const slg_index *ix) {
+  if (!ix) return 0;
+  return const_cast<slg_index *>(ix)->snapshot()->generation;
 }
 
 slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offsets,
@@ -926,21 +1213,20 @@ slg_batch *slg_batch_prepare_plans(slg_index *ix, uint32_t nq, const uint32_t *q
   slg_batch *b = nullptr;
   int rc = guarded([&] {
     SLG_REQUIRE(ix != nullptr, "index is NULL");
-    // Planning (slg_plan.cpp: a pure host function) reads only immutable index data — segments are
-    // fixed at create — so host threads may prepare batches for one index concurrently; the index
-    // mutex is held just to look at the filter table.
-    std::vector<char> filter_live;
-    {
-      std::lock_guard<std::mutex> lk(ix->mu);
-      filter_live.resize(ix->filters.size());
-      for (size_t f = 0; f < ix->filters.size(); f++) filter_live[f] = !ix->filters[f].empty();
-    }
-    std::vector<slgplan::SegView> views(ix->segs.size());
-    for (size_t s = 0; s < ix->segs.size(); s++) {
-      const SegHost &sh = *ix->segs[s];
+    // Planning (slg_plan.cpp: a pure host function) reads only the immutable state the batch binds
+    // to, so host threads may prepare batches for one index concurrently, also while an update builds
+    // the next state; the index mutex is held just to take the snapshot.
+    const std::shared_ptr<const IndexState> snap = ix->snapshot();
+    std::vector<char> filter_live(snap->filters.size());
+    for (size_t f = 0; f < snap->filters.size(); f++)
+      filter_live[f] = snap->filters[f] && snap->filters[f]->complete() &&
+                       snap->filters[f]->per_seg.size() == snap->segs.size();
+    std::vector<slgplan::SegView> views(snap->segs.size());
+    for (size_t s = 0; s < snap->segs.size(); s++) {
+      const SegHost &sh = *snap->segs[s];
       views[s].n_docs = sh.n_docs;
       views[s].n_terms = sh.n_terms;
-      views[s].term_offsets = sh.term_offsets.data();
+      views[s].term_offsets = sh.store->term_offsets.data();
       views[s].champ = sh.champ.empty() ? nullptr : sh.champ.data();
     }
     slgplan::BatchIn in;
@@ -960,6 +1246,7 @@ slg_batch *slg_batch_prepare_plans(slg_index *ix, uint32_t nq, const uint32_t *q
     DeviceGuard g(ix->device);
     b = new slg_batch();
     b->idx = ix;
+    b->snap = snap;
     b->nq = nq;
     b->k = k;
     b->strategy = strategy;
@@ -1061,6 +1348,7 @@ int slg_batch_run(slg_batch *b) {
   return guarded([&] {
     SLG_REQUIRE_LIVE(b);
     slg_index *ix = b->idx;
+    const IndexState &S = *b->snap;  // the state the batch was prepared on (not the index's current one)
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
     hipStream_t st = batch_stream(b);
@@ -1073,7 +1361,7 @@ int slg_batch_run(slg_batch *b) {
       pp.terms = b->d_terms;
       pp.n_sq = b->n_sq;
       pp.bnd_coarse = b->d_bnd_coarse;
-      pp.segs = ix->d_segs.as<slg::SegDev>();
+      pp.segs = S.d_segs.as<slg::SegDev>();
       pp.bounds = b->d_bounds.as<uint32_t>();
       pp.rdoc = b->d_rdoc.as<uint32_t>();
       pp.q_scored = b->d_q_scored.as<uint32_t>();
@@ -1101,13 +1389,13 @@ int slg_batch_run(slg_batch *b) {
       sp.slice_sq = b->d_slice_sq;
       sp.slice_order = b->d_slice_order;
       sp.slice_desc = b->d_slice_desc.as<slg::SliceDesc>();
-      sp.reject_table = ix->d_reject_table.as<const uint32_t *>();
-      sp.n_segs = (uint32_t)ix->segs.size();
+      sp.reject_table = S.d_reject_table.as<const uint32_t *>();
+      sp.n_segs = (uint32_t)S.segs.size();
       sp.plan_batch = b->plan_batch ? (b->nested ? 2u : 1u) : 0u;
       sp.cand = b->d_cand.as<uint2>();
       sp.slice_cbeg = b->d_slice_cbeg.as<uint64_t>();
       sp.slice_ccnt = b->d_slice_ccnt.as<uint32_t>();
-      sp.segs = ix->d_segs.as<slg::SegDev>();
+      sp.segs = S.d_segs.as<slg::SegDev>();
       sp.bounds = inline_cuts ? nullptr : b->d_bounds.as<uint32_t>();
       sp.rdoc = inline_cuts ? nullptr : b->d_rdoc.as<uint32_t>();
       sp.slice_tk = b->d_slice_tk.as<int32_t>();
@@ -1146,10 +1434,10 @@ int slg_batch_run(slg_batch *b) {
       sp.slice_cbeg = b->d_slice_cbeg.as<uint64_t>();
       sp.slice_ccnt = b->d_slice_ccnt.as<uint32_t>();
       sp.cand = b->d_cand.as<uint2>();
-      sp.segs = ix->d_segs.as<slg::SegDev>();
+      sp.segs = S.d_segs.as<slg::SegDev>();
       sp.q_filter = b->d_q_filter.as<uint32_t>();
-      sp.reject_table = ix->d_reject_table.as<const uint32_t *>();
-      sp.n_segs = (uint32_t)ix->segs.size();
+      sp.reject_table = S.d_reject_table.as<const uint32_t *>();
+      sp.n_segs = (uint32_t)S.segs.size();
       sp.out_doc = b->d_out_doc;
       sp.out_seg = b->d_out_seg;
       sp.out_score = b->d_out_score;
@@ -1342,7 +1630,7 @@ int slg_search_batch_filtered(slg_index *ix, const slg_query *queries, uint32_t 
   std::vector<uint32_t> offs(nq + 1, 0), tids;
   std::vector<float> ws;
   rc = guarded([&] {
-    const size_t n_segs = ix->segs.size();
+    const size_t n_segs = ix->snapshot()->segs.size();
     for (uint32_t q = 0; q < nq; q++) {
       const slg_query &qq = queries[q];
       SLG_REQUIRE(qq.n_terms == 0 || (qq.term_ids && qq.weights), "query arrays are NULL");
@@ -1434,7 +1722,8 @@ RcclApi &rccl() {
     for (const char *n : {"librccl.so.1", "librccl.so"})
       if (!a.handle) a.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     if (!a.handle) {
-      a.error = std::string("librccl not found: ") + (dlerror() ? dlerror() : "");
+      const char *e = dlerror();  // (one call: dlerror() clears the state it reports)
+      a.error = std::string("librccl not found: ") + (e ? e : "");
       return a;
     }
     a.get_uid = (nccl_get_uid_fn)dlsym(a.handle, "ncclGetUniqueId");
@@ -1477,7 +1766,7 @@ slg_shard_group *slg_shard_group_create(slg_index *ix, int rank, int world, cons
   const int rc = guarded([&] {
     SLG_REQUIRE(ix != nullptr && unique_id != nullptr, "index or unique id is NULL");
     SLG_REQUIRE(world >= 1 && rank >= 0 && rank < world, "rank outside [0, world)");
-    SLG_REQUIRE(segs_per_rank >= ix->segs.size(), "segs_per_rank is smaller than this shard's segment count");
+    SLG_REQUIRE(segs_per_rank >= ix->snapshot()->segs.size(), "segs_per_rank is smaller than this shard's segment count");
     DeviceGuard dg(ix->device);
     NcclUid id;
     std::memcpy(id.internal, unique_id, sizeof(id.internal));
@@ -1519,6 +1808,7 @@ int slg_batch_run_sharded(slg_batch *b, slg_shard_group *g, uint32_t *out_doc, u
   int rc = guarded([&] {
     SLG_REQUIRE_LIVE(b);
     SLG_REQUIRE(g != nullptr && g->idx == b->idx, "shard group is NULL or belongs to another index");
+    SLG_REQUIRE(g->segs_per_rank >= b->snap->segs.size(), "the shard grew beyond the group's segs_per_rank");
   });
   if (rc != SLG_OK) return rc;
   rc = slg_batch_run(b);  // this rank's segments: partition + score + merge, on the batch's stream
@@ -1645,11 +1935,12 @@ int slg_rerank_batch_device(slg_index *ix, uint32_t nq, const float *d_qvecs, co
     SLG_REQUIRE(d_qvecs && d_alpha && d_cand_count && d_out_count, "device arrays are NULL");
     SLG_REQUIRE(max_cand == 0 || (d_cand_doc && d_cand_seg && d_cand_bm25), "candidate arrays are NULL");
     SLG_REQUIRE(k_out == 0 || (d_out_doc && d_out_seg && d_out_score), "output arrays are NULL");
+    const auto S = ix->snapshot();  // (a retired state waits for the device before its tables go)
     uint32_t dim = 0;
-    for (auto &s : ix->segs)
-      if (s->vec_dim) {
-        SLG_REQUIRE(dim == 0 || dim == s->vec_dim, "segments disagree on vec_dim");
-        dim = s->vec_dim;
+    for (auto &s : S->segs)
+      if (s->store->vec_dim) {
+        SLG_REQUIRE(dim == 0 || dim == s->store->vec_dim, "segments disagree on vec_dim");
+        dim = s->store->vec_dim;
       }
     if (dim == 0) throw SlgError(SLG_ERR_UNSUPPORTED, "index has no vector field");
     if (max_cand > slg::kRerankMaxCand)
@@ -1657,8 +1948,8 @@ int slg_rerank_batch_device(slg_index *ix, uint32_t nq, const float *d_qvecs, co
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
     slg::RerankParams rp{};
-    rp.vsegs = ix->d_vsegs.as<slg::VecSegDev>();
-    rp.n_segs = (uint32_t)ix->segs.size();
+    rp.vsegs = S->d_vsegs.as<slg::VecSegDev>();
+    rp.n_segs = (uint32_t)S->segs.size();
     rp.dim = dim;
     rp.qvecs = d_qvecs;
     rp.alpha = d_alpha;
@@ -1697,26 +1988,27 @@ int slg_rerank_multi_batch_device(slg_index *ix, uint32_t nq, uint32_t n_clauses
     SLG_REQUIRE(d_qvecs && d_alpha && d_cand_count && d_out_count, "device arrays are NULL");
     SLG_REQUIRE(max_cand == 0 || (d_cand_doc && d_cand_seg && d_cand_bm25), "candidate arrays are NULL");
     SLG_REQUIRE(k_out == 0 || (d_out_doc && d_out_seg && d_out_score), "output arrays are NULL");
+    const auto S = ix->snapshot();
     uint32_t dim = 0;
     int32_t metric = -1;
-    for (auto &s : ix->segs) {
-      if (!s->vec_dim) continue;
-      SLG_REQUIRE(dim == 0 || dim == s->vec_dim, "segments disagree on vec_dim");
-      SLG_REQUIRE(metric < 0 || metric == s->vec_metric, "segments disagree on the vector metric");
-      dim = s->vec_dim;
-      metric = s->vec_metric;
+    for (auto &s : S->segs) {
+      if (!s->store->vec_dim) continue;
+      SLG_REQUIRE(dim == 0 || dim == s->store->vec_dim, "segments disagree on vec_dim");
+      SLG_REQUIRE(metric < 0 || metric == s->store->vec_metric, "segments disagree on the vector metric");
+      dim = s->store->vec_dim;
+      metric = s->store->vec_metric;
     }
     if (dim == 0) throw SlgError(SLG_ERR_UNSUPPORTED, "index has no vector field");
-    for (auto &s : ix->segs)
-      if (!s->vec_dim) throw SlgError(SLG_ERR_UNSUPPORTED, "multi-clause rerank needs the vector field in every segment");
+    for (auto &s : S->segs)
+      if (!s->store->vec_dim) throw SlgError(SLG_ERR_UNSUPPORTED, "multi-clause rerank needs the vector field in every segment");
     if (slg::rerank_multi_lds_floats(n_clauses, dim, max_cand) > slg::kRerankMultiLdsFloats)
       throw SlgError(SLG_ERR_UNSUPPORTED, "n_clauses * (dim + max_cand) exceeds the LDS budget of the multi-clause rerank");
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
     slg::RerankMultiParams mp{};
     slg::RerankParams &rp = mp.base;
-    rp.vsegs = ix->d_vsegs.as<slg::VecSegDev>();
-    rp.n_segs = (uint32_t)ix->segs.size();
+    rp.vsegs = S->d_vsegs.as<slg::VecSegDev>();
+    rp.n_segs = (uint32_t)S->segs.size();
     rp.dim = dim;
     rp.qvecs = d_qvecs;
     rp.alpha = d_alpha;
@@ -1743,8 +2035,10 @@ int slg_index_add_vector_field(slg_index *ix, const slg_vector_field_desc *per_s
   int id = 0;
   const int rc = guarded([&] {
     SLG_REQUIRE(ix != nullptr && per_segment != nullptr, "index or descriptors are NULL");
-    SLG_REQUIRE(n_segs == ix->segs.size(), "one descriptor per segment of the index is required");
-    auto vf = std::make_unique<VecFieldHost>();
+    std::lock_guard<std::mutex> ulk(ix->update_mu);
+    const auto cur = ix->snapshot();
+    SLG_REQUIRE(n_segs == cur->segs.size(), "one descriptor per segment of the index is required");
+    auto vf = std::make_shared<VecFieldHost>();
     for (uint32_t s = 0; s < n_segs; s++) {
       const slg_vector_field_desc &d = per_segment[s];
       if (!d.vec_dim) continue;
@@ -1754,59 +2048,56 @@ int slg_index_add_vector_field(slg_index *ix, const slg_vector_field_desc *per_s
                   "segments disagree on the field's dimension or metric");
       vf->dim = d.vec_dim;
       vf->metric = d.vec_metric;
-      const uint32_t nd = ix->segs[s]->n_docs;
+      const uint32_t nd = cur->segs[s]->n_docs;
       for (uint32_t i = 0; i < nd; i++)
         SLG_REQUIRE(d.vec_offsets[i] == SLG_NO_VECTOR || d.vec_offsets[i] < d.vec_rows, "vector offset past vec_rows");
     }
     SLG_REQUIRE(vf->dim != 0, "no segment has vectors in this field");
-    std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
-    vf->offsets.resize(n_segs);
-    vf->values.resize(n_segs);
-    std::vector<slg::VecSegDev> vd(n_segs);
+    vf->per_seg.resize(n_segs);
     for (uint32_t s = 0; s < n_segs; s++) {
       const slg_vector_field_desc &d = per_segment[s];
-      vd[s] = slg::VecSegDev{nullptr, nullptr, ix->segs[s]->n_docs, 0u, vf->metric, 0u};
       if (!d.vec_dim) continue;
-      const size_t ob = (size_t)ix->segs[s]->n_docs * 4, vb = (size_t)d.vec_rows * d.vec_dim * 4;
-      vf->offsets[s].alloc(ob, &ix->pool);
-      if (ob) SLG_HIP(hipMemcpy(vf->offsets[s].p, d.vec_offsets, ob, hipMemcpyHostToDevice));
-      vf->values[s].alloc(vb, &ix->pool);
-      if (vb) SLG_HIP(hipMemcpy(vf->values[s].p, d.vec_values, vb, hipMemcpyHostToDevice));
-      ix->device_bytes += vf->offsets[s].bytes + vf->values[s].bytes;
-      vd[s].offsets = vf->offsets[s].as<uint32_t>();
-      vd[s].values = vf->values[s].as<float>();
-      vd[s].dim = d.vec_dim;
+      auto vs = std::make_shared<VecSegStore>();
+      const size_t ob = (size_t)cur->segs[s]->n_docs * 4, vb = (size_t)d.vec_rows * d.vec_dim * 4;
+      vs->offsets.alloc(ob, &ix->pool);
+      if (ob) SLG_HIP(hipMemcpy(vs->offsets.p, d.vec_offsets, ob, hipMemcpyHostToDevice));
+      vs->values.alloc(vb, &ix->pool);
+      if (vb) SLG_HIP(hipMemcpy(vs->values.p, d.vec_values, vb, hipMemcpyHostToDevice));
+      vs->dim = d.vec_dim;
+      vf->per_seg[s] = std::move(vs);
     }
-    vf->d_vsegs.alloc(n_segs * sizeof(slg::VecSegDev), &ix->pool);
-    SLG_HIP(hipMemcpy(vf->d_vsegs.p, vd.data(), n_segs * sizeof(slg::VecSegDev), hipMemcpyHostToDevice));
-    ix->vfields.push_back(std::move(vf));
-    id = (int)ix->vfields.size();
+    auto ns = copy_state(*cur);
+    ns->generation = cur->generation;
+    ns->vfields.push_back(std::move(vf));
+    finish_state(ix, *ns);
+    id = (int)ns->vfields.size();
+    publish(ix, std::move(ns));
   });
   return rc == SLG_OK ? id : rc;
 }
 
 namespace {
 // dimension / metric / device stores of vector field f (0: the field of the segment descriptors)
-void field_facts(slg_index *ix, uint32_t f, uint32_t *dim, int32_t *metric, const slg::VecSegDev **vsegs) {
+void field_facts(const IndexState &S, uint32_t f, uint32_t *dim, int32_t *metric, const slg::VecSegDev **vsegs) {
   if (f == 0) {
     uint32_t d = 0;
     int32_t m = -1;
-    for (auto &s : ix->segs) {
-      if (!s->vec_dim) continue;
-      SLG_REQUIRE(d == 0 || d == s->vec_dim, "segments disagree on vec_dim");
-      SLG_REQUIRE(m < 0 || m == s->vec_metric, "segments disagree on the vector metric");
-      d = s->vec_dim;
-      m = s->vec_metric;
+    for (auto &s : S.segs) {
+      if (!s->store->vec_dim) continue;
+      SLG_REQUIRE(d == 0 || d == s->store->vec_dim, "segments disagree on vec_dim");
+      SLG_REQUIRE(m < 0 || m == s->store->vec_metric, "segments disagree on the vector metric");
+      d = s->store->vec_dim;
+      m = s->store->vec_metric;
     }
     if (d == 0) throw SlgError(SLG_ERR_UNSUPPORTED, "index has no vector field 0");
     *dim = d;
     *metric = m;
-    *vsegs = ix->d_vsegs.as<slg::VecSegDev>();
+    *vsegs = S.d_vsegs.as<slg::VecSegDev>();
     return;
   }
-  SLG_REQUIRE(f <= ix->vfields.size(), "unknown vector field id");
-  const VecFieldHost &vf = *ix->vfields[f - 1];
+  SLG_REQUIRE(f <= S.vfields.size(), "unknown vector field id");
+  const VecFieldHost &vf = *S.vfields[f - 1];
   *dim = vf.dim;
   *metric = vf.metric;
   *vsegs = vf.d_vsegs.as<slg::VecSegDev>();
@@ -1828,12 +2119,13 @@ int slg_rerank_fields_batch_device(slg_index *ix, uint32_t nq, uint32_t n_clause
     SLG_REQUIRE(d_qvecs && d_alpha && d_cand_count && d_out_count, "device arrays are NULL");
     SLG_REQUIRE(max_cand == 0 || (d_cand_doc && d_cand_seg && d_cand_bm25), "candidate arrays are NULL");
     SLG_REQUIRE(k_out == 0 || (d_out_doc && d_out_seg && d_out_score), "output arrays are NULL");
+    const auto S = ix->snapshot();
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
     slg::RerankFieldsParams fp{};
     uint32_t qf = 0;
     for (uint32_t c = 0; c < n_clauses; c++) {
-      field_facts(ix, clause_field[c], &fp.cdim[c], &fp.cmetric[c], &fp.cvsegs[c]);
+      field_facts(*S, clause_field[c], &fp.cdim[c], &fp.cmetric[c], &fp.cvsegs[c]);
       fp.coff[c] = qf;
       qf += fp.cdim[c];
     }
@@ -1841,7 +2133,7 @@ int slg_rerank_fields_batch_device(slg_index *ix, uint32_t nq, uint32_t n_clause
       throw SlgError(SLG_ERR_UNSUPPORTED, "clause vectors + n_clauses * max_cand exceed the LDS budget of the rerank");
     slg::RerankParams &rp = fp.base;
     rp.vsegs = nullptr;
-    rp.n_segs = (uint32_t)ix->segs.size();
+    rp.n_segs = (uint32_t)S->segs.size();
     rp.dim = 0;
     rp.qvecs = d_qvecs;
     rp.alpha = d_alpha;
@@ -1878,12 +2170,12 @@ int slg_rerank_fields_batch(slg_index *ix, uint32_t nq, uint32_t n_clauses, cons
     SLG_REQUIRE(qvecs && alpha && cand_count && out_count, "host arrays are NULL");
     SLG_REQUIRE(max_cand == 0 || (cand_doc && cand_seg && cand_bm25), "candidate arrays are NULL");
     SLG_REQUIRE(k_out == 0 || (out_doc && out_seg && out_score), "output arrays are NULL");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    const auto S = ix->snapshot();
     for (uint32_t c = 0; c < n_clauses; c++) {
       uint32_t d;
       int32_t m;
       const slg::VecSegDev *v;
-      field_facts(ix, clause_field[c], &d, &m, &v);
+      field_facts(*S, clause_field[c], &d, &m, &v);
       qf += d;
     }
   });
@@ -1951,8 +2243,8 @@ int slg_rerank_multi_batch(slg_index *ix, uint32_t nq, uint32_t n_clauses, const
   });
   if (rc != SLG_OK || nq == 0) return rc;
   uint32_t dim = 0;
-  for (auto &s : ix->segs)
-    if (s->vec_dim) dim = s->vec_dim;
+  for (auto &s : ix->snapshot()->segs)
+    if (s->store->vec_dim) dim = s->store->vec_dim;
   if (dim == 0) {
     g_last_error = "index has no vector field";
     g_last_code = SLG_ERR_UNSUPPORTED;
@@ -2019,8 +2311,8 @@ int slg_rerank_batch(slg_index *ix, uint32_t nq, const float *qvecs, const float
   });
   if (rc != SLG_OK || nq == 0) return rc;
   uint32_t dim = 0;
-  for (auto &s : ix->segs)
-    if (s->vec_dim) dim = s->vec_dim;
+  for (auto &s : ix->snapshot()->segs)
+    if (s->store->vec_dim) dim = s->store->vec_dim;
   if (dim == 0) {
     g_last_error = "index has no vector field";
     return SLG_ERR_UNSUPPORTED;

@@ -297,7 +297,7 @@ struct StageParams {
   uint32_t n_terms;
   uint32_t n_docs;
   const uint64_t *term_offsets;  // [V+1] (unpadded: positions in docs / tfs)
-  const uint32_t *docs;          // [P] as uploaded
+  const uint32_t *docs;          // [P] as uploaded; nullptr: docs_out already holds them (re-derivation)
   const uint32_t *tfs;           // [P]
   const float *term_idf;         // [V]
   const uint16_t *term_field;    // [V] or nullptr
@@ -327,7 +327,10 @@ static __global__ void __launch_bounds__(256) stage_impacts_kernel(StageParams p
     uint32_t f = p.term_field ? p.term_field[t] : 0;
     float avgdl = p.field_avgdl[f];
     const float *lens = p.field_doc_len[f];
-    uint32_t doc = p.docs[i];
+    const uint64_t at = i + (uint64_t)kListPad * t;
+    // creation: the uploaded doc id, scattered into the padded layout below; re-derivation after a
+    // tombstone update (slg_index_update_deleted): the doc id is read back from there
+    uint32_t doc = p.docs ? p.docs[i] : p.docs_out[at];
     float tf = (float)p.tfs[i];
     // ScoredTerm::doc_len  query/wand.rs:77-84
     float dl = fmaxf(avgdl, 1.0f);
@@ -341,8 +344,7 @@ static __global__ void __launch_bounds__(256) stage_impacts_kernel(StageParams p
     float idf = p.term_idf[t];
     float norm_dl = avgdl > 0.0f ? norm_len / avgdl : 1.0f;
     float denom = tf + p.k1 * (1.0f - p.b + p.b * norm_dl);
-    const uint64_t at = i + (uint64_t)kListPad * t;
-    p.docs_out[at] = doc;
+    if (p.docs) p.docs_out[at] = doc;
     p.imps[at] = idf * (tf * (p.k1 + 1.0f)) / fmaxf(denom, 1e-6f);
   }
 }
@@ -615,6 +617,17 @@ static __global__ void __launch_bounds__(256) filter_build_kernel(FilterBuildPar
   const uint32_t w = d >> 5;
   if ((lane & 31u) == 0 && (d < p.n_docs))
     p.reject[w] = lane == 0 ? (uint32_t)rej : (uint32_t)(rej >> 32);
+}
+
+// reject bitmap of a filter after new tombstones: out = a | b (b may be null: no tombstones)
+struct BitmapOrParams {
+  const uint32_t *a, *b;
+  uint32_t *out;
+  uint32_t n_words;
+};
+static __global__ void __launch_bounds__(256) bitmap_or_kernel(BitmapOrParams p) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < p.n_words) p.out[i] = p.a[i] | (p.b ? p.b[i] : 0u);
 }
 
 // ---- large k (k > 256): per-query radix select over the candidates the scoring kernel kept ----

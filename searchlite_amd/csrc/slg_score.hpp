@@ -1,7 +1,8 @@
 // slg_score.hpp — shared definitions of the round-scoring kernels: the planning kernel
 // partition_rounds_kernel, RoundScoreParams, wave scans, in-kernel stamps (diagnostic builds).
-// The scoring kernels themselves: slg_score_uni.hpp (<= 4 lists), slg_score_multi.hpp (5..32
-// lists, score plans, MaxScore / block-max pruning).
+// The scoring kernels themselves: slg_score_uni4.hpp (<= 8 lists), slg_score_multi.hpp (9..32
+// lists, score plans beyond the few-term kernel's, MaxScore / block-max pruning); the superseded
+// few-term forms slg_score_uni.hpp / slg_score_uni3.hpp build only with -DSLG_LEGACY_KERNELS.
 //
 // Restates query/wand.rs:459-566 (brute_force: every posting of every term is scored and
 // summed per doc, in ScorePlan leaf order planner.rs:122-135) and push_top_k
@@ -252,6 +253,13 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
   do {               \
   } while (0)
 #endif
+
+// shared by the scoring kernels
+constexpr int kJoinWords = 1024;  // filter words of the few-term kernels = 8192 doc fields; also the join queue
+static_assert(kJoinWords * 4 >= kUniCap * 8, "the join queue ({doc, score} per posting) overlays the filter");
+// k <= 256 (KREGS <= 4): buffered top-k in LDS (BufTopK); larger k: every doc above the seed
+// threshold goes to the slice's candidate region and select_topk_kernel picks the k best
+constexpr bool uni_buffered(int kregs) { return kregs <= 4; }
 
 typedef const __attribute__((address_space(1))) uint32_t *gu32_t;
 typedef const __attribute__((address_space(1))) float *gf32_t;

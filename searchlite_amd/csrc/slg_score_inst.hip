@@ -4,8 +4,10 @@
 #include <hip/hip_runtime.h>
 
 #include "slg_score.hpp"
+#ifdef SLG_LEGACY_KERNELS  // the superseded few-term forms, for A/B timing on one device (tools/ab_uniform.sh)
 #include "slg_score_uni.hpp"
 #include "slg_score_uni3.hpp"
+#endif
 #include "slg_score_uni4.hpp"
 #include "slg_score_multi.hpp"
 
@@ -22,6 +24,7 @@ void launch_score_kregs(const RoundScoreParams &sp, int kind, hipStream_t st);
 // wave: a finished wave frees its wave slot and its LDS at once.
 template <>
 void launch_score_kregs<SLG_INST_KREGS>(const RoundScoreParams &sp, int kind, hipStream_t st) {
+#ifdef SLG_LEGACY_KERNELS
   if (kind == 1) {  // <= 4 lists (slg_score_uni3.hpp)
     hipLaunchKernelGGL((score_uniform3_kernel<SLG_INST_KREGS, 4>), dim3(sp.n_slices), dim3(64),
                        u3_wave_lds(SLG_INST_KREGS, 4), st, sp);
@@ -32,6 +35,12 @@ void launch_score_kregs<SLG_INST_KREGS>(const RoundScoreParams &sp, int kind, hi
                        u3_wave_lds(SLG_INST_KREGS, 8), st, sp);
     return;
   }
+  if (kind == 4) {  // the round-2 form of the same kernel (slg_tuning.uniform_kernel = 2: A/B timing)
+    hipLaunchKernelGGL((score_uniform_kernel<SLG_INST_KREGS>), dim3(sp.n_slices), dim3(64),
+                       uni_wave_lds(SLG_INST_KREGS), st, sp);
+    return;
+  }
+#endif
   if (kind == 6 || kind == 7) {  // <= 4 / 5..8 lists, blocked layout (slg_score_uni4.hpp)
     if (kind == 6)
       hipLaunchKernelGGL((score_uniform4_kernel<SLG_INST_KREGS, 4>), dim3(sp.n_slices), dim3(64),
@@ -39,11 +48,6 @@ void launch_score_kregs<SLG_INST_KREGS>(const RoundScoreParams &sp, int kind, hi
     else
       hipLaunchKernelGGL((score_uniform4_kernel<SLG_INST_KREGS, 8>), dim3(sp.n_slices), dim3(64),
                          u4_wave_lds(SLG_INST_KREGS, 8, u4_filter_words(8)), st, sp);
-    return;
-  }
-  if (kind == 4) {  // the round-2 form of the same kernel (slg_tuning.uniform_kernel = 2: A/B timing)
-    hipLaunchKernelGGL((score_uniform_kernel<SLG_INST_KREGS>), dim3(sp.n_slices), dim3(64),
-                       uni_wave_lds(SLG_INST_KREGS), st, sp);
     return;
   }
   // many lists: slots of one list each, 8 at a time (slg_score_multi.hpp)

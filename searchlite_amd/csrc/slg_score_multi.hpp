@@ -40,7 +40,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "slg_score_uni.hpp"
+#include "slg_score.hpp"
 
 namespace slg {
 

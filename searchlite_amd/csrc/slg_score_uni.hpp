@@ -41,13 +41,9 @@
 namespace slg {
 
 // (kUniSlots = 8 slots per round, kUniCap, kUniMaxLists = 4 lists: slg_desc.hpp)
-constexpr int kJoinWords = 1024;             // filter words = 8192 doc fields; also the join queue
+// (kJoinWords, uni_buffered: slg_score.hpp)
 constexpr int kJoinPairs = 24;               // queue sizes up to this are joined all-pairs in registers
                                              // (16 / 40 / 64 measured: no better)
-static_assert(kJoinWords * 4 >= kUniCap * 8, "the join queue ({doc, score} per posting) overlays the filter");
-// k <= 256 (KREGS <= 4): buffered top-k in LDS (BufTopK); larger k: every doc above the seed
-// threshold goes to the slice's candidate region and select_topk_kernel picks the k best
-constexpr bool uni_buffered(int kregs) { return kregs <= 4; }
 // per-wave LDS: filter / join queue, top-k buffer, then the slice's cut points (64 words) and the
 // lists' posting offsets (2 x 4 words) — values needed once per 8 rounds, kept out of the VGPRs
 constexpr int kUniPlanLds = 64 * 4 + 2 * kUniMaxLists * 4;

@@ -44,15 +44,7 @@ class GpuIndex:
         descs = (N.SegmentDesc * len(self.segments))()
         keep = []
         for i, s in enumerate(self.segments):
-            nf = len(s.field_doc_len)
-            ptrs = (C.c_void_p * nf)(*[_ptr(a) for a in s.field_doc_len])
-            keep.append(ptrs)
-            vec_rows = 0 if s.vec_values is None else int(s.vec_values.shape[0])
-            descs[i] = N.SegmentDesc(
-                s.n_docs, s.n_terms, _ptr(s.term_offsets), _ptr(s.doc_ids), _ptr(s.tfs),
-                _ptr(s.term_field), nf, C.addressof(ptrs), _ptr(s.field_avgdl),
-                s.docs, s.k1, s.b, _ptr(s.deleted),
-                s.vec_dim, s.vec_metric, _ptr(s.vec_offsets), _ptr(s.vec_values), vec_rows)
+            descs[i] = self._desc(s, keep)
         tune = N.default_tuning()
         for name, val in (tuning or {}).items():
             if not hasattr(tune, name):
@@ -61,6 +53,46 @@ class GpuIndex:
         self._h = self._lib.slg_index_create_tuned(descs, len(self.segments), device, C.addressof(tune))
         if not self._h:
             raise N.SlgError(N.last_error_code() or N.ERR_INVALID, N.last_error())
+
+    @staticmethod
+    def _desc(s: Segment, keep: list) -> "N.SegmentDesc":
+        nf = len(s.field_doc_len)
+        ptrs = (C.c_void_p * nf)(*[_ptr(a) for a in s.field_doc_len])
+        keep.append(ptrs)
+        vec_rows = 0 if s.vec_values is None else int(s.vec_values.shape[0])
+        return N.SegmentDesc(
+            s.n_docs, s.n_terms, _ptr(s.term_offsets), _ptr(s.doc_ids), _ptr(s.tfs),
+            _ptr(s.term_field), nf, C.addressof(ptrs), _ptr(s.field_avgdl),
+            s.docs, s.k1, s.b, _ptr(s.deleted),
+            s.vec_dim, s.vec_metric, _ptr(s.vec_offsets), _ptr(s.vec_values), vec_rows)
+
+    # -- index updates (the reference's commit, api/writer.rs:106-240) ------------------------
+    def update_deleted(self, seg: int, deleted: Optional[np.ndarray], live_docs: float) -> None:
+        """New tombstones of segment `seg` (complete bitmap, bit d&7 of byte d>>3) and its new
+        live_docs (slg_index_update_deleted); the mirrored Segment object follows."""
+        bm = None if deleted is None else np.ascontiguousarray(deleted, dtype=np.uint8)
+        N.check(self._lib.slg_index_update_deleted(self._h, seg, _ptr(bm), float(live_docs)))
+        s = self.segments[seg]
+        s.deleted = bm
+        s.docs = float(live_docs)
+
+    def add_segment(self, segment: Segment) -> int:
+        """Stage one more segment at the next ordinal (slg_index_add_segment) -> the ordinal."""
+        keep: list = []
+        d = self._desc(segment, keep)
+        ord_ = self._lib.slg_index_add_segment(self._h, C.addressof(d))
+        if ord_ < 0:
+            raise N.SlgError(ord_, N.last_error())
+        self.segments.append(segment)
+        return ord_
+
+    def remove_segment(self, seg: int) -> None:
+        N.check(self._lib.slg_index_remove_segment(self._h, seg))
+        del self.segments[seg]
+
+    @property
+    def generation(self) -> int:
+        return int(self._lib.slg_index_generation(self._h))
 
     def tuning(self) -> "N.Tuning":
         t = N.Tuning()

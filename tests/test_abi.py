@@ -59,7 +59,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_abi_version_and_error_string(lib):
-    assert lib.slg_abi_version() == 2
+    assert lib.slg_abi_version() == 3
     assert isinstance(lib.slg_last_error(), bytes)
 
 

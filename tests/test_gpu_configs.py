@@ -43,7 +43,8 @@ def _properties(d, s, sc, c, k, n_docs):
 # ---- config 3: 10M docs, 5-term OR with pruning, batch 4096, top-100 --------------------------------
 def test_config3_full_size_properties(gpu, oracle):
     """BASELINE config 3 exactly as bench.py --config c3 builds it (zipf seed 43, V = 2^20, query
-    seed 7, k = 101, strategy Wand => many-term kernel with pruning-classified lists): determinism,
+    seed 7, k = 101, strategy Wand => the blocked few-term kernel score_uniform4_kernel<2, 8>, the planner
+    having dropped the MaxScore classification that block skipping cannot use here): determinism,
     sortedness, distinctness, and a 32-query sample bit-exact against the exhaustive oracle."""
     from searchlite_amd import corpus
     n_docs, vocab, nq, T, k = 10_000_000, 1 << 20, 4096, 5, 101
@@ -68,15 +69,15 @@ def test_config3_full_size_properties(gpu, oracle):
 
 
 @pytest.mark.parametrize("tuning", [None, {"pruning": 1}, {"pruning": 1, "block_max": 0}, {"pruning": 0},
-                                    {"uniform_max_terms": 4}, {"uniform_kernel": 3}, {"inline_cuts": 0}])
+                                    {"uniform_max_terms": 4}, {"inline_cuts": 0}])
 def test_five_terms_top100_pruned_kernel_small(gpu, oracle, tuning):
     """T = 5, k = 101 (two registers per lane) on a corpus small enough for the oracle to check
     every query: the kernel config 3 selects (None: score_uniform4_kernel<2, 8>, the planner drops the
     classification because block skipping has nothing to gain), the classified many-term kernel
     score_multi_kernel<2, 1> (pruning: 1), the unclassified one (uniform_max_terms: 4 -> <2, 0> is
-    not reached: classification stays on; pruning: 0 with 8 lists -> few-term kernel), and the slot
-    form of the few-term kernel with 8-bit filter fields (uniform_kernel: 3); inline_cuts: 0 = cut points
-    from partition_rounds_kernel instead of the scoring waves' own."""
+    not reached: classification stays on; pruning: 0 with 8 lists -> few-term kernel); inline_cuts: 0 =
+    cut points from partition_rounds_kernel instead of the scoring waves' own.  (The slot forms of the
+    few-term kernel are no longer in the product library: -DSLG_LEGACY_KERNELS, tools/ab_uniform.sh.)"""
     from searchlite_amd import corpus
     seg = corpus.zipf_segment(300_000, 1 << 16, seed=43)
     offs, terms, w = corpus.zipf_queries(192, 5, rank_lo=8, rank_hi=4096, seed=7, vocab=1 << 16)
