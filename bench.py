@@ -52,7 +52,13 @@ CONFIGS = {
     "c4": (1_250_000, 1 << 20, 43, 8192, 5, 100),
     # config 5: BM25 top-1000 (k = 1001) -> cosine rerank over 768-d f32 vectors -> top-10
     "c5": (1_000_000, 1 << 18, 42, 1024, 3, 1000),
+    # multi-field query strings (the reference's default `fields: None` = all text fields,
+    # api/reader.rs:2576-2586): config 2's corpus split over 4 fields (4 x ~64 tokens per doc, seeds
+    # 42..45), 2-word query strings = 8 scored lists in 2 ScorePlan leaves (Sum of leaves,
+    # query/planner.rs:354-360).  `terms` = words per query
+    "mf": (1_000_000, 1 << 18, 42, 1024, 2, 10),
 }
+MF_FIELDS = 4
 C4_SEGMENTS = 8
 
 
@@ -81,6 +87,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=0, help="queries in the CPU sample")
     ap.add_argument("--check", type=int, default=64, help="queries parity-checked vs the oracle")
+    ap.add_argument("--coalesce-threads", type=int, default=256,
+                    help="caller threads of the request-coalescer leg (config c2, N = 1; 0: skip the leg)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even for one rank")
     return ap.parse_args()
@@ -301,7 +309,9 @@ def main():
     # replica workload (configs 2 / 3 / 5 / small)
     # ------------------------------------------------------------------------------------------
     t0 = time.time()
-    seg = corpus.zipf_segment(n_docs, vocab, seed=cseed, n_threads=gen_threads)
+    plans = args.config == "mf"  # score plans: every query carries q_leaf (a leaf per word)
+    seg = corpus.zipf_multifield_segment(n_docs, vocab, MF_FIELDS, seed=cseed, n_threads=gen_threads) if plans \
+        else corpus.zipf_segment(n_docs, vocab, seed=cseed, n_threads=gen_threads)
     t_corpus = time.time() - t0
     rerank = args.config == "c5"
     if rerank:
@@ -312,6 +322,11 @@ def main():
     index.set_stream(stream.cuda_stream)
     n_sets = max(1, args.rotate)
     qs = query_sets(nq, T, vocab, 1, 7 + rank * n_sets, n_sets)  # seeds 7.. (rank 0), distinct per rank
+    q_leaves = None
+    if plans:
+        mq = [corpus.multifield_queries(nq, T, MF_FIELDS, vocab, seed=7 + rank * n_sets + j) for j in range(n_sets)]
+        qs = [(o, t.reshape(-1, 1), w_) for o, t, w_, _ in mq]
+        q_leaves = [l for _, _, _, l in mq]
 
     # ---- leg 1 (`value`): host arrays in -> prepare -> run -> fetch -> host arrays out ----
     n_thr = max(1, args.host_threads)
@@ -341,6 +356,7 @@ def main():
             L.slh_first_result.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
             L.slh_destroy.argtypes = [C.c_void_p]
             L.slh_stats.argtypes = [C.c_void_p, C.c_void_p]
+            L.slh_reset_stats.argtypes = [C.c_void_p]
             self.L, self.C = L, C
             self.keep = [(np.ascontiguousarray(o, np.uint32), np.ascontiguousarray(t, np.uint32),
                           np.ascontiguousarray(w_, np.float32)) for o, t, w_ in qs]
@@ -364,20 +380,23 @@ def main():
             out = (C.c_double * 4)()
             self.L.slh_stats(self.h, out)
             return {"prepare_ms": round(out[0], 4), "run_ms": round(out[1], 4), "fetch_ms": round(out[2], 4),
+                    "batches": int(out[3]),
                     "is": "mean time per batch a caller thread spends inside slg_batch_prepare / set_stream + run / "
-                          "fetch + destroy (warm-up included)"}
+                          "fetch + destroy, over the timed regions (warm-up excluded); a thread keeps two batches "
+                          "going, so fetch mostly waits for the batch's kernels behind the other threads' batches"}
 
         def close(self):
             self.L.slh_destroy(self.h)
             self.h = None
 
     value = ms_per_step = value_spread = host_ms = None
-    if not rerank and not args.kernel_leg_only:
+    if not rerank and not plans and not args.kernel_leg_only:
         pool = HostPool()
         # untimed: --warmup steps, and at least three batches per caller thread so that every
         # thread has run and the library's buffer pool holds a set of work buffers per batch in flight
         host_warm = max(args.warmup, 3 * n_thr)
         pool.run(host_warm, 0)
+        pool.L.slh_reset_stats(pool.h)
         # the timed region = EXACTLY --steps steps between two fences; it is repeated --regions times
         # (a 20-step region is 2.5 ms: 2.5 steps per caller thread with the pipeline's fill and drain
         # inside) and `value` is the MEDIAN region; the spread is reported beside it
@@ -403,7 +422,8 @@ def main():
 
     # ---- leg 2: device-resident pre-planned batches, rotating, `inflight` streams ----
     inflight = max(1, args.inflight) if not rerank else 1
-    batches = [index.prepare(*q, k, strategy) for q in qs]
+    batches = [index.prepare(*q, k, strategy, q_leaf=None if q_leaves is None else q_leaves[j])
+               for j, q in enumerate(qs)]
     infos = [b.info() for b in batches]
     streams = [torch.cuda.Stream() for _ in range(inflight)] if inflight > 1 else [stream]
     if inflight > 1:
@@ -449,7 +469,7 @@ def main():
     fence()
     res_elapsed = max_over_ranks(time.perf_counter() - t1) * (args.steps if args.kernel_leg_only else 1)
     resident_qps = nq * world / (res_elapsed / args.steps)
-    if rerank:
+    if rerank or plans:
         value, ms_per_step = resident_qps, res_elapsed / args.steps * 1e3
 
     # ---- leg 3: the scoring kernel alone (HIP events on its launch stream), batches rotating ----
@@ -470,6 +490,8 @@ def main():
         value = nq * world / (kern_ms / max(n_launch, 1) * 1e-3)
         ms_per_step = kern_ms / max(n_launch, 1)
     total_postings = sum_over_ranks(float(np.mean([i["n_postings"] for i in infos])))
+    touched = np.unique(np.concatenate([np.asarray(q[1]).reshape(-1) for q in qs]))
+    working_set_postings = int((seg.term_offsets[touched.astype(np.int64) + 1] - seg.term_offsets[touched.astype(np.int64)]).sum())
 
     if rank == 0:
         kern_avg_ms = kern_ms / max(n_launch, 1)
@@ -493,21 +515,29 @@ def main():
             "value_spread": value_spread,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{n_docs} synthetic Zipf docs (avg 256 tokens, V={vocab}, "
-                                   f"s=1.0, seed {cseed}), {T}-term OR, batch={nq} per GPU, "
-                                   f"top-{limit} (k={k}), strategy={args.strategy}, "
-                                   f"query-sharded replicas",
+            "config": {"workload": (f"{n_docs} synthetic Zipf docs (avg 256 tokens, V={vocab}, "
+                                    f"s=1.0, seed {cseed}), {T}-term OR, batch={nq} per GPU, "
+                                    f"top-{limit} (k={k}), strategy={args.strategy}, "
+                                    f"query-sharded replicas") if not plans else
+                                   (f"{n_docs} synthetic Zipf docs x {MF_FIELDS} text fields (avg 64 tokens each, V={vocab} "
+                                    f"per field, s=1.0, seeds {cseed}..{cseed + MF_FIELDS - 1}), {T}-word query strings "
+                                    f"over all fields = {T * MF_FIELDS} scored lists in {T} ScorePlan leaves (Sum of "
+                                    f"leaves, planner.rs:354-360), batch={nq} per GPU, top-{limit} (k={k}), "
+                                    f"strategy={args.strategy}"),
                        "value_is": ("--kernel-leg-only: rate of the scoring kernel alone (profiling run)"
                                     if args.kernel_leg_only else
                                     "device-resident index; every step a fresh host query batch through the "
                                     "C ABI: slg_batch_prepare (plan + H2D) -> run -> fetch (D2H) -> destroy"
-                                    if not rerank else
+                                    if not (rerank or plans) else
+                                    "device-resident pre-planned batches with score plans, rotating" if plans else
                                     "device-resident pipeline BM25 top-1000 -> rerank -> top-10 of pre-planned batches"),
                        "host_threads": None if rerank else n_thr,
                        "host_call_ms": host_ms,
                        "host_warmup_steps": None if (rerank or args.kernel_leg_only) else host_warm,
                        "rotating_query_sets": n_sets,
-                       "posting_working_set_bytes": int(8 * sum(i["n_postings"] for i in infos)),
+                       # 8 B x postings of the DISTINCT lists the rotating query sets touch (the resident
+                       # doc-id + impact streams a pass over all sets reads at least once)
+                       "posting_working_set_bytes": int(8 * working_set_postings),
                        "kernel_only_qps": round(resident_qps, 1),
                        "kernel_only_ms_per_step": round(res_elapsed / args.steps * 1e3, 4),
                        "kernel_only_is": f"pre-planned device-resident batches, {inflight} in flight",
@@ -519,9 +549,11 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_measured_in_run": False,
-                         "kernel": {"2": "score_uniform_kernel", "3": "score_uniform3_kernel"}.get(
-                             os.environ.get("SLG_UNIFORM_KERNEL", "4"), "score_uniform4_kernel")
-                         if T <= int(os.environ.get("SLG_UNIFORM_MAX_TERMS", "8")) else "score_multi_kernel",
+                         "kernel": (("score_uniform4_kernel<.., PLAN>" if os.environ.get("SLG_NO_UNIFORM_PLANS", "0") == "0"
+                                     else "score_multi_kernel<.., 2>") if plans else
+                                    {"2": "score_uniform_kernel", "3": "score_uniform3_kernel"}.get(
+                                        os.environ.get("SLG_UNIFORM_KERNEL", "4"), "score_uniform4_kernel")
+                                    if T <= int(os.environ.get("SLG_UNIFORM_MAX_TERMS", "8")) else "score_multi_kernel"),
                          "kernel_ms": round(kern_avg_ms, 4), "launches": n_launch,
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "exhaustive_bytes_per_launch": int(exhaustive_bytes),
@@ -575,6 +607,9 @@ def main():
         from oracle import oracle as O
         offs, terms, w = qs[0]
         terms = terms.reshape(-1)
+        TQ = T * MF_FIELDS if plans else T  # scored terms per query
+        leaf0 = q_leaves[0] if plans else None
+        lk = (lambda n: {"q_leaf": leaf0[:n * TQ]}) if plans else (lambda n: {})
         got = batches[0].fetch() if rerank else None
         if not rerank:
             batches[0].run()
@@ -585,8 +620,8 @@ def main():
                 raise SystemExit("bench.py: host-inclusive and device-resident results disagree")
         nchk = min(args.check, nq)
         if nchk:
-            want = O.search_batch([seg], offs[:nchk + 1], terms[:nchk * T], w[:nchk * T], k,
-                                  strategy=O.BM25, n_threads=gen_threads)
+            want = O.search_batch([seg], offs[:nchk + 1], terms[:nchk * TQ], w[:nchk * TQ], k,
+                                  strategy=O.BM25, n_threads=gen_threads, **lk(nchk))
             ok = True
             for q in range(nchk):
                 n = int(want[3][q])
@@ -619,27 +654,35 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cores = host_cores
             ncpu = min(args.cpu_queries or nq, nq)
-            co, ct, cw = offs[:ncpu + 1], terms[:ncpu * T], w[:ncpu * T]
+            co, ct, cw = offs[:ncpu + 1], terms[:ncpu * TQ], w[:ncpu * TQ]
             ostrat = {"bm25": O.BM25, "wand": O.WAND, "bmw": O.BMW}[args.strategy]
             # strict baseline: scorer only, min_doc_len cached (a cache the reference lacks)
             reps_c, t_cpu = 0, 0.0
             while t_cpu < 10.0 and reps_c < 50:
                 tc = time.perf_counter()
-                O.search_batch([seg], co, ct, cw, k, strategy=ostrat, n_threads=cores, cache_min_len=True)
+                O.search_batch([seg], co, ct, cw, k, strategy=ostrat, n_threads=cores, cache_min_len=True, **lk(ncpu))
                 t_cpu += time.perf_counter() - tc
                 reps_c += 1
             strict = ncpu * reps_c / t_cpu
             # faithful: TermState::new rescans all doc lengths per term per query (wand.rs:111-125)
-            nf = min(ncpu, 256)
-            tc = time.perf_counter()
-            O.search_batch([seg], offs[:nf + 1], terms[:nf * T], w[:nf * T], k, strategy=ostrat,
-                           n_threads=cores, cache_min_len=False)
-            faithful = nf / (time.perf_counter() - tc)
+            # (the whole CPU sample, repeated until >= 2 s have passed: 256 queries on 256 threads once was a
+            #  single wave of work whose time was mostly thread start-up)
+            nf = min(ncpu, 1024)
+            reps_f, t_f = 0, 0.0
+            while t_f < 2.0 and reps_f < 20:
+                tc = time.perf_counter()
+                O.search_batch([seg], offs[:nf + 1], terms[:nf * TQ], w[:nf * TQ], k, strategy=ostrat,
+                               n_threads=cores, cache_min_len=False, **lk(nf))
+                t_f += time.perf_counter() - tc
+                reps_f += 1
+            faithful = nf * reps_f / t_f
             # BASELINE.md "Baseline A" (context): + per-query varint decode of every list (twice) and
             # the O(N) doc-length rebuild IndexReader::search does around the scorer
             na = min(ncpu, 4 * cores)
-            _, secs_a = O.search_batch_faithful([seg], offs[:na + 1], terms[:na * T], w[:na * T], k,
-                                                strategy=ostrat, n_threads=cores)
+            secs_a = None
+            if not plans:  # (the Baseline A restatement takes flat queries)
+                _, secs_a = O.search_batch_faithful([seg], offs[:na + 1], terms[:na * T], w[:na * T], k,
+                                                    strategy=ostrat, n_threads=cores)
             # Baseline B is `wand` for config 2 and `bmw` (block 128, postings.rs:11) for
             # config 3; the other pruned strategy is timed beside it on the same sample
             other = O.BMW if ostrat != O.BMW else O.WAND
@@ -647,7 +690,7 @@ def main():
             while t_o < 4.0 and reps_o < 20:
                 tc = time.perf_counter()
                 O.search_batch([seg], co, ct, cw, k, strategy=other, block_size=128, n_threads=cores,
-                               cache_min_len=True)
+                               cache_min_len=True, **lk(ncpu))
                 t_o += time.perf_counter() - tc
                 reps_o += 1
             other_rate = ncpu * reps_o / t_o
@@ -660,12 +703,50 @@ def main():
                           f"{cores} threads, one query per thread",
                 "faithful_value": round(faithful, 1),
                 "faithful_note": "same, but with the reference's per-term O(N) min_doc_len scan "
-                                 f"(wand.rs:111-125) on {nf} queries",
-                "baseline_a_value": round(na / secs_a, 1),
+                                 f"(wand.rs:111-125) on {nf} queries x {reps_f} reps",
+                "baseline_a_value": None if secs_a is None else round(na / secs_a, 1),
                 "baseline_a_note": "BASELINE.md Baseline A on the same cores: per query every term's list is "
                                    "varint-decoded twice from its serialized form and the dense doc-length "
                                    f"vector is rebuilt (api/reader.rs:1732-1735, 3604-3621), then wand; {na} queries",
                 "gpu_over_cpu": round(value / strict, 1)}
+
+    # ---- request coalescer (N = 1, config 2): single-query callers, one blocking thread each ----
+    if rank == 0 and world == 1 and args.config == "c2" and args.coalesce_threads > 0 and not args.kernel_leg_only:
+        import ctypes as C
+        from searchlite_amd import build as sbuild
+        Lh = C.CDLL(sbuild.build_harness())
+        Lh.slh_coalesce_bench.restype = C.c_double
+        Lh.slh_coalesce_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        offs, terms, w = (np.ascontiguousarray(x) for x in qs[0])
+        batches[0].run()
+        exp = batches[0].fetch()
+        e_doc, e_score, e_cnt = (np.ascontiguousarray(exp[0], np.uint32), np.ascontiguousarray(exp[2], np.float32),
+                                 np.ascontiguousarray(exp[3], np.uint32))
+        legs = []
+        for thr, wait_us in ((args.coalesce_threads, 30), (4 * args.coalesce_threads, 30)):
+            bad, nb = C.c_int64(0), C.c_uint64(0)
+            total = 64 * nq
+            Lh.slh_coalesce_bench(index._h, local_rank, thr, 8 * nq, offs.ctypes.data, terms.ctypes.data, w.ctypes.data,
+                                  nq, 1, k, strategy, 1024, wait_us, None, None, None, None, None)  # warm-up
+            secs = Lh.slh_coalesce_bench(index._h, local_rank, thr, total, offs.ctypes.data, terms.ctypes.data,
+                                         w.ctypes.data, nq, 1, k, strategy, 1024, wait_us, e_doc.ctypes.data,
+                                         e_score.ctypes.data, e_cnt.ctypes.data, C.addressof(bad), C.addressof(nb))
+            if secs <= 0:
+                raise SystemExit("bench.py: the coalescer leg failed")
+            legs.append({"caller_threads": thr, "max_wait_us": wait_us, "queries": total,
+                         "queries_per_s": round(total / secs, 1), "batches": int(nb.value),
+                         "mean_batch": round(total / max(1, nb.value), 1),
+                         "rows_differing_from_the_batch_api": int(bad.value)})
+            if bad.value:
+                print(json.dumps(legs))
+                raise SystemExit("bench.py: coalescer results differ from the batch API")
+        out["config"]["coalescer"] = {
+            "is": "slg_coalescer_search: every caller thread blocks with ONE query (the reference serves a request "
+                  "per blocking thread, searchlite-http/src/lib.rs:628-652); concurrent callers are collected into "
+                  "batches behind the C ABI; every row compared bit for bit with the batch API's",
+            "legs": legs}
 
     for b in batches:
         b.close()

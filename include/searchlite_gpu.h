@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SLG_ABI_VERSION 3u  /* 3: slg_tuning grew (updatable); index updates (slg_index_update_deleted / _add_segment /
+#define SLG_ABI_VERSION 3u  /* 3: slg_tuning grew (updatable, uniform_plans); index updates (slg_index_update_deleted / _add_segment /
                                _remove_segment / _generation); request coalescer; slg_batch_device_candidates.
                                2: pool_cap_mb, uniform_kernel, uniform_sigma_x100, inline_cuts; shard groups; slg_batch_prepare_plans */
 #define SLG_NO_TERM 0xFFFFFFFFu      /* term absent from a segment (api/reader.rs:2989) */
@@ -194,6 +194,10 @@ typedef struct {
                                     (4 B per posting + 4 B per doc and field) so that slg_index_update_deleted
                                     can re-derive a segment's impacts on the device when live_docs changes;
                                     0: that call fails with SLG_ERR_UNSUPPORTED (add / remove segment still work) */
+  int32_t uniform_plans;         /* !SLG_NO_UNIFORM_PLANS (1): batches with flat score plans (Sum / DisMax over leaves
+                                    of one or more terms) and <= uniform_max_terms lists per sub-query run on the
+                                    few-term kernel's plan instantiation; 0: on the many-term kernel, as two-level
+                                    plans do (A/B timing) */
 } slg_tuning;
 void slg_tuning_default(slg_tuning *out);
 slg_index *slg_index_create_tuned(const slg_segment_desc *segs, uint32_t n_segs, int device,
@@ -384,6 +388,28 @@ int slg_batch_info(const slg_batch *batch, uint64_t *n_postings, uint32_t *n_sli
  * slg_tuning.block_max is off.  Waits for the batch. */
 int slg_batch_skip_counts(slg_batch *batch, uint64_t *probed_postings, uint64_t *skipped_postings);
 void slg_batch_destroy(slg_batch *batch);
+
+/* ---- request coalescer ------------------------------------------------------------------------------
+ * searchlite has no batch API: IndexReader::search takes one request (api/reader.rs:2539) and the HTTP
+ * server gives every request its own blocking thread (searchlite-http/src/lib.rs:628-652).  The
+ * coalescer turns concurrent single-query callers into batches: slg_coalescer_search blocks its caller
+ * thread, the query joins the batch that is collecting (same k, strategy and segment count), one of
+ * the callers plans / runs / fetches the batch on a HIP stream of its own while the next batch already
+ * collects, and every caller returns with its own row — bit-identical to the same query in
+ * slg_search_batch.  A batch closes when it holds max_batch queries, or max_wait_us after its first
+ * query arrived; a query that finds the coalescer idle (nothing in flight) does not wait at all.
+ * Thread-safe; out_doc / out_seg / out_score hold k entries, out_count one. */
+typedef struct slg_coalescer slg_coalescer;
+slg_coalescer *slg_coalescer_create(slg_index *index, uint32_t max_batch, uint32_t max_wait_us);
+/* No caller may be inside slg_coalescer_search any more. */
+void slg_coalescer_destroy(slg_coalescer *coalescer);
+int slg_coalescer_search(slg_coalescer *coalescer, const slg_query *query, uint32_t k, int strategy,
+                         uint32_t *out_doc, uint32_t *out_seg, float *out_score, uint32_t *out_count,
+                         slg_stats *stats_or_null);
+/* Thread-local text of the last failure of slg_coalescer_search on this thread. */
+const char *slg_coalescer_last_error(void);
+/* Batches run and queries served so far (their ratio = the mean batch size reached). */
+int slg_coalescer_stats(const slg_coalescer *coalescer, uint64_t *n_batches, uint64_t *n_queries);
 
 /* ---- index sharding over RCCL ------------------------------------------------------
  * The reference scores every segment independently and merges by (score desc, segment_ord asc,

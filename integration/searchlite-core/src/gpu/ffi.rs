@@ -9,6 +9,7 @@ use std::os::raw::{c_char, c_float, c_int, c_void};
 #[repr(C)] pub struct slg_index { _p: [u8; 0] }
 #[repr(C)] pub struct slg_batch { _p: [u8; 0] }
 #[repr(C)] pub struct slg_shard_group { _p: [u8; 0] }
+#[repr(C)] pub struct slg_coalescer { _p: [u8; 0] }
 
 #[repr(C)]
 pub struct slg_segment_desc {
@@ -28,7 +29,7 @@ pub struct slg_tuning {
     pub probe_target: u32, pub rounds_per_slice: u32, pub max_rounds_per_slice: u32,
     pub slices_per_subquery: u32, pub cand_mode: i32, pub slice_order: i32, pub block_max: i32,
     pub pool_cap_mb: u32, pub uniform_kernel: u32, pub uniform_sigma_x100: u32, pub inline_cuts: i32,
-    pub updatable: i32,
+    pub updatable: i32, pub uniform_plans: i32,
 }
 #[repr(C)] pub struct slg_vector_field_desc {
     pub vec_dim: u32, pub vec_metric: i32, pub vec_offsets: *const u32, pub vec_values: *const c_float, pub vec_rows: u32,
@@ -59,6 +60,14 @@ extern "C" {
     pub fn slg_index_add_segment(index: *mut slg_index, seg: *const slg_segment_desc) -> c_int;
     pub fn slg_index_remove_segment(index: *mut slg_index, seg: u32) -> c_int;
     pub fn slg_index_generation(index: *const slg_index) -> u64;
+    // request coalescer: concurrent single-query callers -> batches (searchlite-http/src/lib.rs:628-652)
+    pub fn slg_coalescer_create(index: *mut slg_index, max_batch: u32, max_wait_us: u32) -> *mut slg_coalescer;
+    pub fn slg_coalescer_destroy(coalescer: *mut slg_coalescer);
+    pub fn slg_coalescer_search(coalescer: *mut slg_coalescer, query: *const slg_query, k: u32, strategy: c_int,
+        out_doc: *mut u32, out_seg: *mut u32, out_score: *mut c_float, out_count: *mut u32,
+        stats_or_null: *mut slg_stats) -> c_int;
+    pub fn slg_coalescer_last_error() -> *const c_char;
+    pub fn slg_coalescer_stats(coalescer: *const slg_coalescer, n_batches: *mut u64, n_queries: *mut u64) -> c_int;
     // index sharding over RCCL (api/reader.rs:2670-2778 across GPUs)
     pub fn slg_shard_unique_id(out: *mut c_void, out_bytes: usize) -> c_int;
     pub fn slg_shard_group_create(index: *mut slg_index, rank: c_int, world: c_int, unique_id: *const c_void,

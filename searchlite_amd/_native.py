@@ -63,7 +63,8 @@ class Tuning(C.Structure):
                 ("slices_per_subquery", C.c_uint32), ("cand_mode", C.c_int32),
                 ("slice_order", C.c_int32), ("block_max", C.c_int32), ("pool_cap_mb", C.c_uint32),
                 ("uniform_kernel", C.c_uint32), ("uniform_sigma_x100", C.c_uint32),
-                ("inline_cuts", C.c_int32), ("updatable", C.c_int32)]
+                ("inline_cuts", C.c_int32), ("updatable", C.c_int32),
+                ("uniform_plans", C.c_int32)]
 
 
 class ScorePlans(C.Structure):
@@ -128,6 +129,11 @@ def load():
         "slg_index_add_segment": (i32, [vp, vp]),
         "slg_index_remove_segment": (i32, [vp, u32]),
         "slg_index_generation": (C.c_uint64, [vp]),
+        "slg_coalescer_create": (vp, [vp, u32, u32]),
+        "slg_coalescer_destroy": (None, [vp]),
+        "slg_coalescer_search": (i32, [vp, vp, u32, i32, vp, vp, vp, vp, vp]),
+        "slg_coalescer_last_error": (C.c_char_p, []),
+        "slg_coalescer_stats": (i32, [vp, vp, vp]),
         "slg_search_batch": (i32, [vp, vp, u32, u32, i32, vp, vp, vp, vp, vp]),
         "slg_index_add_filter": (i32, [vp, vp]),
         "slg_index_add_filter_range_i64": (i32, [vp, vp, C.c_int64, C.c_int64]),

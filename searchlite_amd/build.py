@@ -61,6 +61,8 @@ def build_gpu(force: bool = False, verbose: bool = False, stamps: bool = False, 
         + [f"-D{d}" for d in defines]
     kregs = (1,) if stamps else SCORE_KREGS
     jobs = [(os.path.join(CSRC, "slg_api.hip"), os.path.join(objdir, "slg_api.o"), []),
+            # the request coalescer: host code over the public ABI
+            (os.path.join(CSRC, "slg_coalesce.hip"), os.path.join(objdir, "slg_coalesce.o"), []),
             # the host planner: plain C++ (the same source builds with g++ for the CPU unit tests)
             (os.path.join(CSRC, "slg_plan.cpp"), os.path.join(objdir, "slg_plan.o"), ["-x", "c++"])]
     for kr in kregs:

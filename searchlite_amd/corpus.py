@@ -79,6 +79,42 @@ def zipf_queries(nq: int, n_terms: int, rank_lo: int = 64, rank_hi: int = 8192, 
     return offs, terms.reshape(-1), np.ones(nq * n_terms, dtype=np.float32)
 
 
+def zipf_multifield_segment(n_docs: int, vocab: int, n_fields: int = 4, len_min: int = 32, len_span: int = 64,
+                            seed: int = 42, k1: float = 0.9, b: float = 0.4, n_threads: int | None = None) -> Segment:
+    """`n_fields` text fields over one vocabulary, each an independent zipf_segment draw (seed + f) with
+    doc lengths uniform in [len_min, len_min + len_span]: term id = f * vocab + (rank - 1) (the
+    "field:term" keys of index/postings.rs), per-field doc lengths and avgdl (index/segment.rs:848).
+    The defaults make config 2's corpus split over 4 fields (4 x ~64 tokens per doc)."""
+    parts = [zipf_segment(n_docs, vocab, len_min=len_min, len_span=len_span, seed=seed + f, k1=k1, b=b,
+                          n_threads=n_threads) for f in range(n_fields)]
+    offs = np.zeros(n_fields * vocab + 1, dtype=np.uint64)
+    base = 0
+    for f, sg in enumerate(parts):
+        offs[f * vocab + 1:(f + 1) * vocab + 1] = sg.term_offsets[1:] + np.uint64(base)
+        base += int(sg.term_offsets[-1])
+    return Segment(n_docs=n_docs, term_offsets=offs, doc_ids=np.concatenate([sg.doc_ids for sg in parts]),
+                   tfs=np.concatenate([sg.tfs for sg in parts]),
+                   field_doc_len=[sg.field_doc_len[0] for sg in parts],
+                   field_avgdl=np.array([sg.field_avgdl[0] for sg in parts], dtype=np.float32),
+                   docs=float(n_docs), k1=k1, b=b, term_field=np.repeat(np.arange(n_fields, dtype=np.uint16), vocab),
+                   fields=[f"f{f}" for f in range(n_fields)])
+
+
+def multifield_queries(nq: int, n_words: int, n_fields: int, vocab: int, rank_lo: int = 64, rank_hi: int = 8192,
+                       seed: int = 7):
+    """Query strings of `n_words` distinct words over all `n_fields` fields (the default `fields: None`,
+    api/reader.rs:2576-2586): every word is one ScorePlan leaf, its per-field terms add into it, the
+    leaves are summed (query/planner.rs:354-360).  -> (q_offsets, q_terms, q_weights, q_leaf), terms in
+    the reference's order (word-major, field-minor)."""
+    offs, words, _ = zipf_queries(nq, n_words, rank_lo, rank_hi, seed, vocab)
+    words = words.reshape(nq, n_words)
+    terms = (words[:, :, None] + (np.arange(n_fields, dtype=np.uint32) * np.uint32(vocab))[None, None, :]).astype(np.uint32)
+    leaf = np.broadcast_to(np.arange(n_words, dtype=np.uint32)[None, :, None], terms.shape)
+    per_q = n_words * n_fields
+    return ((np.arange(nq + 1, dtype=np.uint32) * per_q).astype(np.uint32), np.ascontiguousarray(terms.reshape(-1)),
+            np.ones(nq * per_q, dtype=np.float32), np.ascontiguousarray(leaf.reshape(-1)))
+
+
 def unit_vectors(n: int, dim: int, seed: int = 11) -> np.ndarray:
     """iid N(0,1) rows, L2-normalized in f32 (ingest normalizes cosine vectors,
     index/segment.rs:508-510)."""

@@ -29,6 +29,7 @@
 #include "slg_plan.hpp"
 #include "slg_rerank.hpp"
 #include "slg_score.hpp"
+#include "slg_score_uni4.hpp"
 #include "slg_score_multi.hpp"
 
 namespace {
@@ -343,6 +344,7 @@ struct slg_index {
   slg_tuning tune{};
   std::vector<slg_batch *> live;  // batches prepared on this index and not yet destroyed (under mu)
   int device = 0;
+  uint32_t n_cu = 256;  // compute units of the device (persistent launches fill its wave slots)
   hipStream_t own_stream = nullptr;
   // descriptor uploads of slg_batch_prepare*: non-blocking streams picked by caller thread.  A plain
   // hipMemcpy runs on the legacy default stream and waits for whatever the application has queued
@@ -391,6 +393,7 @@ struct slg_batch {
   const slg::QueryRef *d_queries = nullptr;
   const uint32_t *d_bnd_coarse = nullptr;
   DevBuf d_bounds, d_rdoc, d_slice_tk, d_slice_doc, d_q_scored, d_slice_desc;
+  DevBuf d_work_ctr;       // work counter of the persistent scoring waves (zeroed by partition_rounds_kernel)
   DevBuf d_q_filter;       // [nq] 0 = none, f + 1 (select_topk_kernel); empty when unfiltered
   bool cand_mode = false;  // uniform kernel, k > 256: candidates + select_topk_kernel
   DevBuf d_cand, d_slice_cbeg, d_slice_ccnt;
@@ -441,11 +444,13 @@ namespace {
 
 // kind: 1 few-term kernel (slg_score_uni3.hpp; 5: its 5..8-list form), 2 many-term kernel (slg_score_multi.hpp),
 // 3 many-term kernel with pruning-classified lists, 4 the round-2 few-term kernel (slg_score_uni.hpp)
-// 6 / 7: the few-term kernel in its blocked form (slg_score_uni4.hpp), <= 4 / 5..8 lists
-int uniform_kind(uint32_t form, uint32_t max_terms) {
+// 6 / 7: the few-term kernel in its blocked form (slg_score_uni4.hpp), <= 4 / 5..8 lists; 8 / 9: the same
+// with score plans (flat Sum / DisMax over leaves)
+int uniform_kind(uint32_t form, uint32_t max_terms, bool plans) {
   const bool few = max_terms <= (uint32_t)slg::kUniMaxLists;
   if (form == 2) return 4;
   if (form == 3) return few ? 1 : 5;
+  if (plans) return few ? 8 : 9;
   return few ? 6 : 7;
 }
 void launch_score(const slg::RoundScoreParams &sp, int kind, hipStream_t st) {
@@ -833,6 +838,7 @@ void slg_tuning_default(slg_tuning *t) {
   t->uniform_sigma_x100 = env_u32("SLG_UNIFORM_SIGMA", 0);
   t->inline_cuts = env_i32("SLG_INLINE_CUTS", -1);
   t->updatable = env_i32("SLG_NOT_UPDATABLE", 0) == 0;
+  t->uniform_plans = env_i32("SLG_NO_UNIFORM_PLANS", 0) == 0;
 }
 
 slg_index *slg_index_create(const slg_segment_desc *segs, uint32_t n_segs, int device) {
@@ -875,6 +881,7 @@ slg_index *slg_index_create_tuned(const slg_segment_desc *segs, uint32_t n_segs,
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !tune.allow_any_arch)
       throw SlgError(SLG_ERR_DEVICE,
                      std::string("device is ") + prop.gcnArchName + ", this library targets gfx950");
+    ix->n_cu = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     SLG_HIP(hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking));
     ix->stream = ix->own_stream;
     for (auto &us : ix->upload_streams) SLG_HIP(hipStreamCreateWithFlags(&us, hipStreamNonBlocking));
@@ -912,7 +919,7 @@ namespace {
 // to the runtime (the index and its pool are going away)
 void release_batch_buffers(slg_batch *b, bool to_pool) {
   DevBuf *bufs[] = {&b->d_desc, &b->d_bounds, &b->d_rdoc, &b->d_slice_desc, &b->d_slice_tk, &b->d_slice_doc,
-                    &b->d_q_scored, &b->d_q_filter, &b->d_cand, &b->d_slice_cbeg, &b->d_slice_ccnt,
+                    &b->d_q_scored, &b->d_work_ctr, &b->d_q_filter, &b->d_cand, &b->d_slice_cbeg, &b->d_slice_ccnt,
                     &b->d_out, &b->d_stamps, &b->d_blk_skip, &b->d_gather, &b->d_merged};
   for (DevBuf *d : bufs) {
     if (!to_pool) d->pool = nullptr;
@@ -1313,6 +1320,7 @@ slg_batch *slg_batch_prepare_plans(slg_index *ix, uint32_t nq, const uint32_t *q
       b->d_slice_doc.alloc_pooled(&ix->pool, (size_t)b->n_slices * k * 4);
     }
     b->d_q_scored.alloc_pooled(&ix->pool, (size_t)nq * 4);
+    b->d_work_ctr.alloc_pooled(&ix->pool, (size_t)slg::kWorkQueues * slg::kWorkCtrStride * 4);
     // (from the pool like every per-batch buffer: a raw hipMalloc / hipFree per batch synchronises
     // the device and cost config 4's two-in-flight pipeline 60 %)
     if (b->pruned && !b->uniform && ix->tune.block_max) b->d_blk_skip.alloc_pooled(&ix->pool, ((size_t)nq + 1) * 8);
@@ -1377,6 +1385,15 @@ int slg_batch_run(slg_batch *b) {
       pp.n_boundaries = inline_cuts ? 0u : b->n_boundaries;
       pp.n_slices = b->n_slices;
       pp.tpb_shift = b->max_terms <= 4 ? 2u : 3u;
+      // few-term kernel: persistent waves, one per wave slot of the device (slg_score_uni4.hpp)
+      const int score_kind =
+          b->uniform ? uniform_kind(ix->tune.uniform_kernel, b->max_terms, b->plan_batch) : (b->pruned ? 3 : 2);
+      uint32_t n_waves = b->n_slices;
+      if (score_kind >= 6 && score_kind <= 9)
+        n_waves = slg::u4_launch_blocks(kregs_for(b->k), (score_kind & 1) ? 8 : 4, score_kind >= 8, b->n_slices, ix->n_cu) *
+                  (uint32_t)slg::kU4WavesPerBlock;
+      pp.work_ctr = b->d_work_ctr.as<uint32_t>();
+      pp.n_waves = n_waves;
       const uint64_t pthreads = std::max<uint64_t>(
           std::max<uint64_t>((uint64_t)pp.n_boundaries << pp.tpb_shift, (uint64_t)b->nq + 1), b->n_slices);
       hipLaunchKernelGGL(slg::partition_rounds_kernel, dim3((uint32_t)((pthreads + 255) / 256)),
@@ -1406,6 +1423,8 @@ int slg_batch_run(slg_batch *b) {
       sp.block_skip = skipping ? 1u : 0u;
       sp.skip_counts = pp.skip_counts;
       sp.stamps = nullptr;
+      sp.work_ctr = pp.work_ctr;
+      sp.n_waves = n_waves;
 #ifdef SLG_STAMPS
       b->d_stamps.alloc((size_t)b->n_slices * 96);
       sp.stamps = b->d_stamps.as<unsigned long long>();
@@ -1421,10 +1440,7 @@ int slg_batch_run(slg_batch *b) {
         ev = &ix->prof_events[ix->prof_used++];
         SLG_HIP(hipEventRecord(ev->first, st));
       }
-      launch_score(sp,
-                   b->uniform ? uniform_kind(ix->tune.uniform_kernel, b->max_terms)
-                              : (b->pruned ? 3 : 2),
-                   st);
+      launch_score(sp, score_kind, st);
       if (ev) SLG_HIP(hipEventRecord(ev->second, st));
     }
     if (b->k > 0 && b->cand_mode && b->n_slices > 0) {

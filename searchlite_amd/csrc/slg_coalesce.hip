@@ -1,0 +1,308 @@
+// slg_coalesce.hip — request coalescer behind the C ABI (include/searchlite_gpu.h: slg_coalescer_*).
+//
+// searchlite has no batch API: IndexReader::search takes ONE request (api/reader.rs:2539) and the HTTP
+// server runs every request on its own blocking thread (searchlite-http/src/lib.rs:628-652,
+// spawn_blocking -> index.reader() -> reader.search(&req)).  A `gpu` shim that forwards one query per
+// call pays a whole launch chain per query (~80 us: ~12K queries/s per stream) where the device
+// scores 1024 queries in the same time.  The coalescer is what sits between the two: every caller
+// thread blocks in slg_coalescer_search with ITS query; concurrent callers are collected into one
+// slg_batch_prepare / run / fetch and each gets its own row back.
+//
+// Mechanism: leader / followers.  The first caller to find no open batch opens one and becomes its
+// leader; callers that arrive while it is open append their query (same k and strategy; otherwise
+// they open a batch of their own kind).  The leader closes the batch when it is full (max_batch) or
+// max_wait_us after opening it — right away if the device is idle, i.e. no other batch of this
+// coalescer is in flight (a lone request never waits) — then plans, runs and fetches it on a HIP
+// stream of its own while the NEXT batch is already collecting behind a new leader: several batches
+// are in flight at once, which is what keeps the device fed.  Followers sleep on the batch's
+// condition variable and copy their row out after the leader's fetch.
+//
+// Host code on top of the public ABI (no kernels here; HIP only for the leaders' streams); part of
+// libsearchlite_gpu.so.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/searchlite_gpu.h"
+
+namespace {
+
+// One collecting / running batch.  A caller reserves a row under the coalescer's mutex (a counter
+// increment) and writes its query into the row's fixed-size slot OUTSIDE the lock; `ready` counts the
+// rows written.  Batch objects are recycled (the slot arrays are a megabyte for an 8-segment index).
+struct CoBatch {
+  uint32_t k = 0;
+  int strategy = 0;
+  uint32_t n_segs = 0, slot_terms = 0;  // slot: SLG_MAX_QUERY_TERMS x n_segs term ids
+  uint32_t nq = 0;                      // rows reserved (under slg_coalescer::mu)
+  bool closed = false;                  // no more rows (under slg_coalescer::mu)
+  std::atomic<uint32_t> ready{0};       // rows written
+  std::atomic<uint32_t> leaving{0};     // callers that have copied their result out
+  std::vector<uint32_t> slot_ids, slot_nt;
+  std::vector<float> slot_w;
+  std::atomic<bool> want_stats{false};
+  // the closed batch as CSR (built by the leader), and its results
+  std::vector<uint32_t> offs, term_ids;
+  std::vector<float> weights;
+  std::vector<uint32_t> doc, seg, count;
+  std::vector<float> score;
+  std::vector<slg_stats> stats;
+  int rc = SLG_OK;
+  std::string error;
+  std::mutex mu;
+  std::condition_variable cv;
+  bool done = false;
+  bool full = false;  // the leader's wake-up: max_batch reached
+};
+
+}  // namespace
+
+struct slg_coalescer {
+  slg_index *index = nullptr;
+  uint32_t max_batch = 1024, max_wait_us = 50;
+  std::mutex mu;
+  std::vector<CoBatch *> open;        // at most one per (k, strategy, segment count) kind
+  std::vector<CoBatch *> spare;       // recycled batch objects
+  std::atomic<uint32_t> in_flight{0};  // batches closed and not yet fetched
+  // HIP streams for the leaders' batches (a leader takes one for the life of its batch)
+  std::vector<void *> free_streams;
+  // accounting (slg_coalescer_stats)
+  std::atomic<uint64_t> n_batches{0}, n_queries{0};
+};
+
+namespace {
+
+thread_local std::string g_co_error;
+
+void *take_stream(slg_coalescer *c) {
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->free_streams.empty()) {
+      void *s = c->free_streams.back();
+      c->free_streams.pop_back();
+      return s;
+    }
+  }
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  return (void *)s;
+}
+
+void give_stream(slg_coalescer *c, void *s) {
+  if (!s) return;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->free_streams.push_back(s);
+}
+
+// (under c->mu) take `b` off the open list
+void unlist(slg_coalescer *c, CoBatch *b) {
+  for (size_t i = 0; i < c->open.size(); i++)
+    if (c->open[i] == b) {
+      c->open[i] = c->open.back();
+      c->open.pop_back();
+      return;
+    }
+}
+
+// the leader's part: plan + run + fetch the closed batch, publish the results
+void run_batch(slg_coalescer *c, CoBatch &b) {
+  // every reserved row has been written?  (writers are a few stores behind their reservation)
+  while (b.ready.load(std::memory_order_acquire) < b.nq) std::this_thread::yield();
+  const uint32_t nq = b.nq, ns = b.n_segs;
+  b.offs.resize((size_t)nq + 1);
+  b.offs[0] = 0;
+  for (uint32_t q = 0; q < nq; q++) b.offs[q + 1] = b.offs[q] + b.slot_nt[q];
+  b.term_ids.resize((size_t)b.offs[nq] * ns);
+  b.weights.resize(b.offs[nq]);
+  for (uint32_t q = 0; q < nq; q++) {
+    const uint32_t nt = b.slot_nt[q];
+    if (!nt) continue;
+    std::memcpy(b.term_ids.data() + (size_t)b.offs[q] * ns, b.slot_ids.data() + (size_t)q * b.slot_terms, (size_t)nt * ns * 4);
+    std::memcpy(b.weights.data() + b.offs[q], b.slot_w.data() + (size_t)q * SLG_MAX_QUERY_TERMS, (size_t)nt * 4);
+  }
+  const size_t n = (size_t)nq * b.k;
+  b.doc.resize(n ? n : 1);
+  b.seg.resize(n ? n : 1);
+  b.score.resize(n ? n : 1);
+  b.count.resize(nq);
+  const bool want_stats = b.want_stats.load();
+  if (want_stats) b.stats.assign(nq, slg_stats{});
+  void *stream = take_stream(c);
+  slg_batch *sb = slg_batch_prepare(c->index, nq, b.offs.data(), b.term_ids.data(), b.weights.data(), b.k, b.strategy);
+  int rc = sb ? SLG_OK : slg_last_error_code();
+  if (sb && stream) rc = slg_batch_set_stream(sb, stream);
+  if (sb && rc == SLG_OK) rc = slg_batch_run(sb);
+  if (sb && rc == SLG_OK)
+    rc = slg_batch_fetch(sb, b.doc.data(), b.seg.data(), b.score.data(), b.count.data(),
+                         want_stats ? b.stats.data() : nullptr);
+  if (rc != SLG_OK) b.error = slg_last_error();
+  if (sb) slg_batch_destroy(sb);
+  give_stream(c, stream);
+  c->in_flight.fetch_sub(1);
+  c->n_batches.fetch_add(1);
+  c->n_queries.fetch_add(nq);
+  {
+    std::lock_guard<std::mutex> lk(b.mu);
+    b.rc = rc;
+    b.done = true;
+  }
+  b.cv.notify_all();
+}
+
+}  // namespace
+
+extern "C" {
+
+slg_coalescer *slg_coalescer_create(slg_index *index, uint32_t max_batch, uint32_t max_wait_us) {
+  if (!index) return nullptr;
+  auto *c = new slg_coalescer();
+  c->index = index;
+  c->max_batch = max_batch ? max_batch : 1024u;
+  c->max_wait_us = max_wait_us;
+  return c;
+}
+
+// (no caller may be inside slg_coalescer_search)
+void slg_coalescer_destroy(slg_coalescer *c) {
+  if (!c) return;
+  for (void *s : c->free_streams) (void)hipStreamDestroy((hipStream_t)s);
+  for (CoBatch *b : c->spare) delete b;
+  for (CoBatch *b : c->open) delete b;
+  delete c;
+}
+
+const char *slg_coalescer_last_error(void) { return g_co_error.c_str(); }
+
+int slg_coalescer_stats(const slg_coalescer *c, uint64_t *n_batches, uint64_t *n_queries) {
+  if (!c) return SLG_ERR_INVALID;
+  if (n_batches) *n_batches = c->n_batches.load();
+  if (n_queries) *n_queries = c->n_queries.load();
+  return SLG_OK;
+}
+
+int slg_coalescer_search(slg_coalescer *c, const slg_query *query, uint32_t k, int strategy, uint32_t *out_doc,
+                         uint32_t *out_seg, float *out_score, uint32_t *out_count, slg_stats *stats_or_null) {
+  g_co_error.clear();
+  if (!c || !query || !out_count || (k && (!out_doc || !out_seg || !out_score)) ||
+      (query->n_terms && (!query->term_ids || !query->weights))) {
+    g_co_error = "coalescer, query or output array is NULL";
+    return SLG_ERR_INVALID;
+  }
+  if (query->n_terms > SLG_MAX_QUERY_TERMS) {
+    g_co_error = "query has more than SLG_MAX_QUERY_TERMS terms";
+    return SLG_ERR_UNSUPPORTED;
+  }
+  uint32_t n_segs = 0;
+  if (slg_index_info(c->index, &n_segs, nullptr, nullptr) != SLG_OK) {
+    g_co_error = slg_last_error();
+    return SLG_ERR_INVALID;
+  }
+  CoBatch *b = nullptr;
+  uint32_t row = 0;
+  bool leader = false, filled = false;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    for (CoBatch *ob : c->open)
+      if (ob->k == k && ob->strategy == strategy && ob->n_segs == n_segs) {
+        b = ob;
+        break;
+      }
+    if (!b) {
+      if (!c->spare.empty()) {
+        b = c->spare.back();
+        c->spare.pop_back();
+      } else {
+        b = new CoBatch();
+      }
+      b->k = k;
+      b->strategy = strategy;
+      b->n_segs = n_segs;
+      b->nq = 0;
+      b->closed = false;
+      b->ready.store(0);
+      b->leaving.store(0);
+      b->want_stats.store(false);
+      b->done = false;
+      b->full = false;
+      b->rc = SLG_OK;
+      b->error.clear();
+      if (b->slot_terms != SLG_MAX_QUERY_TERMS * n_segs || b->slot_nt.size() != c->max_batch) {
+        b->slot_terms = SLG_MAX_QUERY_TERMS * n_segs;
+        b->slot_ids.resize((size_t)c->max_batch * b->slot_terms);
+        b->slot_w.resize((size_t)c->max_batch * SLG_MAX_QUERY_TERMS);
+        b->slot_nt.resize(c->max_batch);
+      }
+      c->open.push_back(b);
+      leader = true;
+    }
+    row = b->nq++;
+    if (b->nq >= c->max_batch) {  // full: no more rows; the leader goes
+      b->closed = true;
+      unlist(c, b);
+      filled = true;
+    }
+  }
+  // my row (outside the lock)
+  b->slot_nt[row] = query->n_terms;
+  if (query->n_terms) {
+    std::memcpy(b->slot_ids.data() + (size_t)row * b->slot_terms, query->term_ids, (size_t)query->n_terms * n_segs * 4);
+    std::memcpy(b->slot_w.data() + (size_t)row * SLG_MAX_QUERY_TERMS, query->weights, (size_t)query->n_terms * 4);
+  }
+  if (stats_or_null) b->want_stats.store(true);
+  b->ready.fetch_add(1, std::memory_order_release);
+  if (filled && !leader) {  // the row that filled the batch wakes its leader
+    {
+      std::lock_guard<std::mutex> bl(b->mu);
+      b->full = true;
+    }
+    b->cv.notify_all();
+  }
+  if (leader) {
+    // collect: until full, or max_wait_us — unless nothing else is in flight (an idle device: waiting
+    // would only add latency; under load the batches in flight give the next one time to fill)
+    if (!filled && c->max_wait_us != 0 && c->in_flight.load() != 0) {
+      std::unique_lock<std::mutex> bl(b->mu);
+      b->cv.wait_for(bl, std::chrono::microseconds(c->max_wait_us), [&] { return b->full; });
+    }
+    {
+      std::lock_guard<std::mutex> lk(c->mu);
+      if (!b->closed) {
+        b->closed = true;
+        unlist(c, b);
+      }
+      c->in_flight.fetch_add(1);
+    }
+    run_batch(c, *b);
+  } else {
+    std::unique_lock<std::mutex> bl(b->mu);
+    b->cv.wait(bl, [&] { return b->done; });
+  }
+  int rc = b->rc;
+  if (rc != SLG_OK) {
+    g_co_error = b->error;
+  } else {
+    *out_count = b->count[row];
+    if (k) {
+      std::memcpy(out_doc, b->doc.data() + (size_t)row * k, (size_t)k * 4);
+      std::memcpy(out_seg, b->seg.data() + (size_t)row * k, (size_t)k * 4);
+      std::memcpy(out_score, b->score.data() + (size_t)row * k, (size_t)k * 4);
+    }
+    if (stats_or_null) *stats_or_null = b->stats[row];
+  }
+  // the last caller to leave hands the batch object back
+  if (b->leaving.fetch_add(1) + 1 == b->nq) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->spare.push_back(b);
+  }
+  return rc;
+}
+
+}  // extern "C"

@@ -106,12 +106,29 @@ struct SliceDesc {
   uint32_t first_round, sq_rounds, longest;
   uint32_t l_df;   // the splitter list's length and posting offset: its stride positions are read
   uint64_t l_off;  // straight off this record, beside the TermRef loads instead of behind them
+  // score plan of the sub-query (RoundQuery::plan / tie / max_init / n_leaves), for the few-term
+  // kernel's plan instantiation (flat plans: Sum or DisMax over leaves of one or more terms)
+  uint32_t plan;
+  float tie, max_init;
+  uint32_t n_leaves;
 };
 
 struct QueryRef {
   uint32_t slice_begin, slice_end;  // all slices of all sub-queries of this query
 };
 
+
+// ---- work queues of the persistent scoring waves (slg_score_uni4.hpp) ---------------------------
+// One returning atomic per slice on ONE counter does not scale: MI355X hands out a ticket of a single
+// address every ~11-16 ns whatever the number of waves asking (tools/micro/atomic_queue.hip: 6144 waves,
+// 195 us for 12 288 tickets; 8 counters 1.8 ns per ticket, 64 counters 0.43 ns) — config 2's 13.4K
+// slices would take longer to hand out than to score.  So the launch order is dealt round-robin over
+// kWorkQueues queues (position p: queue p % kWorkQueues, index p / kWorkQueues — every queue gets the
+// same mix of long and short slices), each with its own counter on its own 256-byte line; wave w starts
+// with position w, pulls from queue w % kWorkQueues, and when that is empty looks at all counters at
+// once (one coherent load, lane l = queue l) and moves to a queue that still has work.
+constexpr uint32_t kWorkQueues = 64;
+constexpr uint32_t kWorkCtrStride = 64;  // words between two counters (256 bytes)
 
 // ---- planning constants (the kernels that consume them: slg_score*.hpp) ------------------------
 constexpr int kMaxRoundsPerSlice = 16;  // and (rounds+1)*T <= 64: cut points live in one VGPR

@@ -656,9 +656,13 @@ void plan_batch(const std::vector<SegView> &segs, const slg_tuning &tn, const Ba
     out.n_postings_essential = out.n_postings;
     out.n_postings_nonessential = 0;
   }
-  // which kernel: the few-term kernel (slg_score_uni4.hpp) takes batches without plans and without
-  // non-essential lists; everything else runs on the many-term kernel
-  out.uniform = out.max_terms <= tn.uniform_max_terms && !any_plan;
+  // which kernel: the few-term kernel (slg_score_uni4.hpp) takes batches of <= 8 lists per sub-query
+  // without non-essential lists — flat sums, and (its plan instantiation, blocked form only) flat score
+  // plans: Sum / DisMax over leaves of one or more terms, i.e. every multi-field query string
+  // (api/reader.rs:2576-2586: `fields: None` = all text fields).  Two-level plans, more lists and
+  // classified batches run on the many-term kernel
+  const bool plans_fit = !any_plan || (tn.uniform_kernel >= 4 && !out.nested && tn.uniform_plans != 0);
+  out.uniform = out.max_terms <= tn.uniform_max_terms && plans_fit;
   for (const slg::RoundQuery &sq : out.sqs)
     if (sq.ess_mask != full_mask(sq.n_terms)) {
       out.pruned = true;

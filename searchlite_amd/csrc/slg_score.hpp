@@ -43,6 +43,9 @@ struct RoundPartParams {
   uint32_t n_boundaries;
   uint32_t n_slices;
   uint32_t tpb_shift;  // log2(threads per boundary): 2 when no sub-query has more than 4 lists, else 3
+  // work counters of the persistent scoring waves (slg_desc.hpp: kWorkQueues), zeroed here
+  uint32_t *work_ctr;
+  uint32_t n_waves;
 };
 
 // first index of d[0, df) with d[idx] >= target, looked for in the 16 NP postings from `a` on: NP + 1
@@ -111,6 +114,7 @@ __device__ __forceinline__ uint32_t lower_bound_guess(const DocPtr d, uint32_t d
 static __global__ void __launch_bounds__(256) partition_rounds_kernel(RoundPartParams p) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid < p.nq) p.q_scored[gid] = 0;
+  if (gid < kWorkQueues && p.work_ctr) p.work_ctr[gid * kWorkCtrStride] = 0u;
   if (gid <= p.nq && p.skip_counts) p.skip_counts[gid] = 0ull;
   if (gid < p.n_slices) {  // the slice record of launch position gid
     const uint32_t slice = p.slice_order[gid];
@@ -137,6 +141,10 @@ static __global__ void __launch_bounds__(256) partition_rounds_kernel(RoundPartP
       d.l_df = L.df;
       d.l_off = L.off;
     }
+    d.plan = s.plan;
+    d.tie = s.tie;
+    d.max_init = s.max_init;
+    d.n_leaves = s.n_leaves;
     p.slice_desc[gid] = d;
   }
   const uint32_t tpb = 1u << p.tpb_shift;
@@ -222,6 +230,8 @@ struct RoundScoreParams {
   // postings of non-essential lists that were never loaded: [0] of the batch, [1 + q] of query q; or null
   unsigned long long *skip_counts;
   unsigned long long *stamps;  // [n_slices * 8] (SLG_STAMPS builds only)
+  uint32_t *work_ctr;          // persistent waves: kWorkQueues counters, kWorkCtrStride words apart
+  uint32_t n_waves;            // waves launched (few-term kernel: min(n_slices, wave slots of the device))
 };
 
 // inclusive wave scan (sum) with DPP row shifts + row broadcasts (gfx9 DPP controls)

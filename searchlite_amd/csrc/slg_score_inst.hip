@@ -42,12 +42,25 @@ void launch_score_kregs<SLG_INST_KREGS>(const RoundScoreParams &sp, int kind, hi
   }
 #endif
   if (kind == 6 || kind == 7) {  // <= 4 / 5..8 lists, blocked layout (slg_score_uni4.hpp)
+    // persistent waves: sp.n_waves / kU4WavesPerBlock workgroups (u4_launch_blocks, slg_api.hip), each wave
+    // pulls slices from sp.work_ctr
+    const uint32_t blocks = (sp.n_waves + (uint32_t)kU4WavesPerBlock - 1u) / (uint32_t)kU4WavesPerBlock;
     if (kind == 6)
-      hipLaunchKernelGGL((score_uniform4_kernel<SLG_INST_KREGS, 4>), dim3(sp.n_slices), dim3(64),
-                         u4_wave_lds(SLG_INST_KREGS, 4, u4_filter_words(4)), st, sp);
+      hipLaunchKernelGGL((score_uniform4_kernel<SLG_INST_KREGS, 4>), dim3(blocks), dim3(64 * kU4WavesPerBlock),
+                         kU4WavesPerBlock * u4_wave_lds(SLG_INST_KREGS, 4, u4_filter_words(4)), st, sp);
     else
-      hipLaunchKernelGGL((score_uniform4_kernel<SLG_INST_KREGS, 8>), dim3(sp.n_slices), dim3(64),
-                         u4_wave_lds(SLG_INST_KREGS, 8, u4_filter_words(8)), st, sp);
+      hipLaunchKernelGGL((score_uniform4_kernel<SLG_INST_KREGS, 8>), dim3(blocks), dim3(64 * kU4WavesPerBlock),
+                         kU4WavesPerBlock * u4_wave_lds(SLG_INST_KREGS, 8, u4_filter_words(8)), st, sp);
+    return;
+  }
+  if (kind == 8 || kind == 9) {  // the same kernel with score plans (flat Sum / DisMax over multi-term leaves)
+    const uint32_t blocks = (sp.n_waves + (uint32_t)kU4WavesPerBlock - 1u) / (uint32_t)kU4WavesPerBlock;
+    if (kind == 8)
+      hipLaunchKernelGGL((score_uniform4_kernel<SLG_INST_KREGS, 4, true>), dim3(blocks), dim3(64 * kU4WavesPerBlock),
+                         kU4WavesPerBlock * u4_wave_lds(SLG_INST_KREGS, 4, u4_filter_words(4)), st, sp);
+    else
+      hipLaunchKernelGGL((score_uniform4_kernel<SLG_INST_KREGS, 8, true>), dim3(blocks), dim3(64 * kU4WavesPerBlock),
+                         kU4WavesPerBlock * u4_wave_lds(SLG_INST_KREGS, 8, u4_filter_words(8)), st, sp);
     return;
   }
   // many lists: slots of one list each, 8 at a time (slg_score_multi.hpp)

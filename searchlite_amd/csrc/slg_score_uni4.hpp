@@ -57,16 +57,33 @@ constexpr int u4_wave_lds(int kregs, int ml, int fw) { return u4_tbl_off(kregs, 
 #endif
 constexpr int kU4JoinPairs = SLG_U4_JOIN_PAIRS;  // queues up to this many entries are joined all-pairs (<= 64: one lane per entry)
 constexpr int u4_filter_words(int ml) { return ml <= 4 ? kJoinWords : SLG_U4_FW8; }
-constexpr int u4_waves(int kregs, int ml) { return ml > 4 ? SLG_U4_WAVES8 : (kregs == 4 ? 5 : SLG_U4_WAVES); }  // (k 129..256: LDS)
+// (k 129..256: LDS; the plan instantiation's leaf close needs a few registers more than 6 waves leave)
+constexpr int u4_waves(int kregs, int ml, bool plan = false) {
+  return (ml > 4 || plan) ? SLG_U4_WAVES8 : (kregs == 4 ? 5 : SLG_U4_WAVES);
+}
+#ifndef SLG_U4_WPB
+#define SLG_U4_WPB 1  // waves per workgroup of the persistent launch (waves never synchronise with each other)
+#endif
+constexpr int kU4WavesPerBlock = SLG_U4_WPB;
+// persistent launch: workgroups to start so that every wave slot the kernel can occupy holds one wave
+// (n_cu compute units x 4 SIMDs x u4_waves), or one wave per slice if the batch has fewer
+inline uint32_t u4_launch_blocks(int kregs, int ml, bool plan, uint32_t n_slices, uint32_t n_cu) {
+  const uint32_t slots = n_cu * 4u * (uint32_t)u4_waves(kregs, ml, plan);
+  const uint32_t waves = n_slices < slots ? n_slices : slots;
+  return (waves + (uint32_t)kU4WavesPerBlock - 1u) / (uint32_t)kU4WavesPerBlock;
+}
 
 // 16-byte loads at 4-byte alignment (a lane's 8 postings start at any posting)
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef u32x4_t U4x4 __attribute__((aligned(4)));
 
-template <int KREGS, int ML>
-__global__ void __launch_bounds__(64)
-    __attribute__((amdgpu_waves_per_eu(u4_waves(KREGS, ML), u4_waves(KREGS, ML))))
-score_uniform4_kernel(RoundScoreParams p) {
+// PLAN: the batch has score plans (query/planner.rs:113-153, flat: Sum or DisMax over leaves that sum
+// one or more terms each): the lists arrive sorted by leaf and the join closes a doc's leaves in leaf
+// order.  Its own instantiation: the flat-sum batches (BASELINE configs 2, 3, 5) keep their registers.
+template <int KREGS, int ML, bool PLAN = false>
+__global__ void __launch_bounds__(64 * kU4WavesPerBlock)
+    __attribute__((amdgpu_waves_per_eu(u4_waves(KREGS, ML, PLAN), u4_waves(KREGS, ML, PLAN))))
+score_uniform4_kernel(RoundScoreParams p_arg) {
   constexpr int NS = kUniSlots;            // postings per lane and round
   constexpr int FW = u4_filter_words(ML);  // filter words
   constexpr int TE = ML + 1;               // table entries per row: the lists + the idle-lane entry
@@ -78,10 +95,51 @@ score_uniform4_kernel(RoundScoreParams p) {
   constexpr uint32_t FSM = LB == 4u ? 0x1Cu : 0x18u;
   static_assert(FW == 1024 || FW == 2048, "filter size");
   static_assert(FW * 4 >= kUniCap * 8, "the join queue ({doc, score} per posting) overlays the filter");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_wg[];
+  (void)p_arg;
+  // waves are independent (no workgroup barrier anywhere): each wave of the workgroup owns its own
+  // LDS region
+  const uint32_t wave_in_wg = kU4WavesPerBlock > 1 ? rfl(threadIdx.x >> 6) : 0u;  // (uniform: a scalar register)
+  unsigned char *const smem = smem_wg + wave_in_wg * (uint32_t)u4_wave_lds(KREGS, ML, FW);
+  // PERSISTENT WAVES: the launch holds one wave per wave slot of the device (or fewer, if the batch
+  // has fewer slices) and every wave pulls launch positions from the batch's work queues until they
+  // are empty — the longest slices first, as before (slice_desc is in launch order).  A wave slot and
+  // its LDS are allocated once per launch instead of once per slice: no workgroup dispatch between a
+  // wave's slices, no holes in the LDS allocator when slices of different lengths finish out of
+  // order.  Queues: slg_desc.hpp (kWorkQueues).  Every wave reaches the exit: the grid always drains.
+  const uint32_t wave_id = blockIdx.x * (uint32_t)kU4WavesPerBlock + wave_in_wg;
+  uint32_t wq = wave_id % kWorkQueues;  // the queue this wave pulls from
+  // (EVERY slice is pulled, the first one too: a wave whose workgroup is not resident when the launch
+  //  starts — the device may hold a few waves fewer than the grid — must not own a slice that then
+  //  waits for a wave slot until the other waves have drained the queues)
+  for (uint32_t widx = 0;;) {
+  // (per slice, the launch parameters are read again from the kernel-argument segment: what a slice
+  //  derives from them then lives in registers for that slice only, instead of being hoisted out of
+  //  this loop and held — spilled — across it)
+  typedef const __attribute__((address_space(4))) RoundScoreParams *kparams_t;
+  kparams_t pk = (kparams_t)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(pk));
+  const __attribute__((address_space(4))) RoundScoreParams &p = *pk;
   const uint32_t lane = threadIdx.x & 63;
-  const uint32_t widx = blockIdx.x;
-  if (widx >= p.n_slices) return;  // waves are independent: no workgroup barrier anywhere
+  {
+    const uint32_t n_sl = p.n_slices;
+    for (;;) {
+      uint32_t c = 0;
+      if (lane == 0) c = atomicAdd(p.work_ctr + wq * kWorkCtrStride, 1u);
+      widx = wq + kWorkQueues * rfl(c);
+      if (widx < n_sl) break;
+      // this queue is empty: the state of all queues in one coherent load (lane l: queue l)
+      const uint32_t seen = __hip_atomic_load(p.work_ctr + lane * kWorkCtrStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint64_t open = __ballot(lane < kWorkQueues && (uint64_t)lane + (uint64_t)kWorkQueues * seen < n_sl);
+      if (open == 0ull) break;
+      // the (wave_id mod open queues)-th open queue: the waves that run dry spread over them
+      uint32_t pick = wave_id % (uint32_t)__popcll(open);
+      uint64_t m = open;
+      while (pick--) m &= m - 1ull;
+      wq = (uint32_t)__builtin_ctzll(m);
+    }
+  }
+  if (widx >= p.n_slices) break;
   const SliceDesc sl = p.slice_desc[widx];
   const uint32_t slice = rfl(sl.slice);
 
@@ -95,15 +153,20 @@ score_uniform4_kernel(RoundScoreParams p) {
 
   const uint32_t T = rfl(sl.n_terms);
   const uint32_t n_r = rfl(sl.n_rounds);
-  const SegDev sd = p.segs[sl.seg];
-  const gu32_t gdocs = (gu32_t)sd.docs;
-  const gf32_t gimps = (gf32_t)sd.imps;
+  // (inside the slice loop the compiler cannot prove these loads invariant — earlier slices stored to
+  //  global memory — so they are vector loads: everything wave-uniform is moved to scalar registers by hand)
+  auto uni64 = [](const uint64_t v) { return ((uint64_t)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v); };
+  const uint32_t seg_id = rfl(sl.seg);
+  const SegDev sd_v = p.segs[seg_id];
+  const gu32_t gdocs = (gu32_t)uni64((uint64_t)sd_v.docs);
+  const gf32_t gimps = (gf32_t)uni64((uint64_t)sd_v.imps);
+  const uint32_t seg_n_docs = rfl(sd_v.n_docs);
   // per-lane bases: lane l's postings are lanebase[idx .. idx + 7]
   const gu32_t ldocs = gdocs + 8u * lane;
   const gf32_t limps = gimps + 8u * lane;
-  const uint64_t null_idx = sd.null_idx;
+  const uint64_t null_idx = uni64(sd_v.null_idx);
   const uint32_t fid = rfl(sl.filter);
-  const gu32_t gdel = (gu32_t)(fid ? p.reject_table[(size_t)(fid - 1) * p.n_segs + sl.seg] : sd.deleted);
+  const gu32_t gdel = (gu32_t)uni64((uint64_t)(fid ? p.reject_table[(size_t)(fid - 1) * p.n_segs + seg_id] : sd_v.deleted));
   const uint32_t k = p.k;
 
   // lane t < T: list t's weight and posting offset; all cut points of the slice (entry r*T + t:
@@ -112,7 +175,18 @@ score_uniform4_kernel(RoundScoreParams p) {
   uint32_t *const off_lo = bflat + BW, *const off_hi = off_lo + ML, *const wts = off_hi + ML, *const dfs = wts + ML;
   const bool inline_cuts = p.bounds == nullptr;
   TermRef tr{};
-  if (lane < T) tr = p.terms[sl.term_begin + lane];
+  if (lane < T) tr = p.terms[rfl(sl.term_begin) + lane];
+  // score plan (PLAN instantiation): 0 = flat sum in term order; 1 = Sum of leaves; 2 = DisMax of leaves.
+  // leaf_start: bit t = list t is the first list of its leaf (the lists are sorted by leaf)
+  const uint32_t plan = PLAN ? rfl(sl.plan) : 0u;
+  const float plan_tie = __uint_as_float(rfl(__float_as_uint(sl.tie)));
+  const float plan_max0 = __uint_as_float(rfl(__float_as_uint(sl.max_init)));
+  uint32_t leaf_start = 1u;
+  if (PLAN) {
+    const uint32_t prev_leaf = (uint32_t)wave_shr1((int32_t)tr.leaf);
+    leaf_start = (uint32_t)__ballot(lane < T && (lane == 0u || tr.leaf != prev_leaf));
+  }
+  const uint32_t plan_leaves = (uint32_t)__popc(leaf_start);  // leaves with a list in this sub-query
   // The wave cuts its own slice (what partition_rounds_kernel does for every boundary of the batch,
   // restricted to this slice's (rounds + 1) x lists boundaries): boundary j of the sub-query is the
   // doc id at position j * stride of its longest list, every other list is cut at its first
@@ -145,8 +219,8 @@ score_uniform4_kernel(RoundScoreParams p) {
   }
   if (!inline_cuts) {  // cut points from partition_rounds_kernel
 #pragma unroll
-    for (uint32_t i = 0; i < BW; i += 64) bflat[i + lane] = i + lane < (n_r + 1) * T ? p.bounds[sl.bounds_off + i + lane] : 0u;
-    if (lane < n_r) rend[lane] = p.rdoc[sl.rdoc_off + lane + 1];
+    for (uint32_t i = 0; i < BW; i += 64) bflat[i + lane] = i + lane < (n_r + 1) * T ? p.bounds[rfl(sl.bounds_off) + i + lane] : 0u;
+    if (lane < n_r) rend[lane] = p.rdoc[rfl(sl.rdoc_off) + lane + 1];
   } else {
     wave_fence();
     // the boundaries' docs: rend[i - 1] = end doc of round i - 1 (sentinels are 0xFFFFFFFF: never below
@@ -175,13 +249,13 @@ score_uniform4_kernel(RoundScoreParams p) {
       if (last_b) return df_t;
       if (t == lg) return (uint32_t)pos_l;
       const gu32_t d = gdocs + (((uint64_t)off_hi[t] << 32) | off_lo[t]);
-      if (!inner) return lower_bound_guess(d, df_t, target, sd.n_docs);
+      if (!inner) return lower_bound_guess(d, df_t, target, seg_n_docs);
       // between the slice's own first and last cut points the postings are spread evenly enough for a
       // 64-posting window around the interpolated position (half the lines of the global guess's
       // window; a miss bisects between the two known cuts)
       uint32_t lo = bflat[t], hi = bflat[n_r * T + t];
       const uint32_t d0 = *row0_doc, d1e = rend[n_r - 1u];
-      const uint32_t d1 = d1e < sd.n_docs ? d1e : sd.n_docs;
+      const uint32_t d1 = d1e < seg_n_docs ? d1e : seg_n_docs;
       const float fr = d1 > d0 ? (float)(target - d0) / (float)(d1 - d0) : 0.0f;
       uint32_t g = lo + (uint32_t)((float)(hi - lo) * fr);
       g = g < hi ? g : hi;
@@ -461,7 +535,15 @@ score_uniform4_kernel(RoundScoreParams p) {
           }
           const bool single = xf == 0u && dc < end;
           if (__ballot(single) == 0ull) continue;
-          take_checked(single, 0.0f + xs, dc);
+          float one = 0.0f + xs;  // the doc's only leaf; Sum: -0.0 + one + 0.0 ... = one
+          if (PLAN && plan == 2u) {
+            // DisMax of a doc found in one list: that leaf = one, every other leaf of the plan = 0.0
+            // (planner.rs:138-150): max over all of them, sum = one
+            float m = fmaxf(plan_max0, one);
+            if (plan_leaves > 1u) m = fmaxf(m, 0.0f);
+            one = m + plan_tie * (one - m);
+          }
+          take_checked(single, one, dc);
         }
       }
       // shared docs (and aliases), and hot singles, of THIS round are queued in position order =
@@ -507,15 +589,54 @@ score_uniform4_kernel(RoundScoreParams p) {
       const uint2 me = have ? queue[lane] : make_uint2(kDocEnd, 0u);
       float acc = 0.0f;
       uint32_t first = 64u;
-      for (uint32_t g = 0; g < n; g += 8) {
+      auto sender = [&](const uint32_t at, float &sum) {
+        const uint2 sq = queue[at];
+        const uint32_t diff = sq.x ^ me.x;
+        const uint32_t nm = 0u - (diff < 1u ? diff : 1u);  // 0: same doc, ~0: another doc
+        sum += __uint_as_float(sq.y & ~nm);
+        const uint32_t cand = at | nm;
+        first = cand < first ? cand : first;
+      };
+      if (PLAN && plan != 0u) {
+        // Score plan: the senders of one LEAF are a contiguous run of the queue (lists sorted by leaf,
+        // queue sorted by list).  Per leaf: its senders add into `la` (from +0.0, in term order:
+        // wand.rs:488-497 `buf[leaf] += score`), then the leaf closes into the root exactly as
+        // ScoreExpr::evaluate does (planner.rs:122-153) — every leaf of the sub-query, the ones without
+        // a posting of this doc as 0.0: Sum: tot += la (from -0.0); DisMax: max = max(max, la),
+        // tot += la (from 0.0).  Leaves of the plan without a term in this segment are in max_init.
+        const uint32_t bnd_lo = rfl(bnd_lo_v), bnd_hi = rfl(bnd_hi_v);
+        float tot = plan == 2u ? 0.0f : -0.0f, mx = plan_max0;
+        uint32_t lo = 0u, rest = leaf_start >> 1;  // bits of the leaf starts still ahead (bit 0 = list 1)
+        uint32_t t_at = 0u;                        // first list of the current leaf
+        for (;;) {
+          // next leaf start after t_at, or T
+          const uint32_t skip = rest != 0u ? (uint32_t)__builtin_ctz(rest) + 1u : T - t_at;
+          const uint32_t t2 = t_at + skip;
+          uint32_t hi = n;
+          if (t2 < T) {  // entries of the lists < t2: the prefix sum at the last lane before list t2's first
+            const uint32_t f = ((t2 <= 4u ? bnd_lo >> (8u * (t2 - 1u)) : bnd_hi >> (8u * (t2 - 5u))) & 0xFFu);
+            hi = f == 0u ? 0u : rl(qincl, (f < 64u ? f : 64u) - 1u);
+          }
+          float la = 0.0f;
+          uint32_t g = lo;
+          for (; g + 8u <= hi; g += 8u) {
 #pragma unroll
-        for (uint32_t l = 0; l < 8; l++) {
-          const uint2 sq = queue[g + l];
-          const uint32_t diff = sq.x ^ me.x;
-          const uint32_t nm = 0u - (diff < 1u ? diff : 1u);  // 0: same doc, ~0: another doc
-          acc += __uint_as_float(sq.y & ~nm);
-          const uint32_t cand = (g + l) | nm;
-          first = cand < first ? cand : first;
+            for (uint32_t l = 0; l < 8; l++) sender(g + l, la);
+          }
+#pragma unroll 1
+          for (; g < hi; g++) sender(g, la);
+          tot += la;
+          mx = fmaxf(mx, la);
+          if (t2 >= T) break;
+          rest = skip >= 32u ? 0u : rest >> skip;
+          t_at = t2;
+          lo = hi;
+        }
+        acc = plan == 2u ? mx + plan_tie * (tot - mx) : tot;
+      } else {
+        for (uint32_t g = 0; g < n; g += 8) {
+#pragma unroll
+          for (uint32_t l = 0; l < 8; l++) sender(g + l, acc);
         }
       }
       const bool own = have && first == lane;
@@ -549,6 +670,7 @@ score_uniform4_kernel(RoundScoreParams p) {
         for (int u = 1; u < ML; u++) ml += idx >= qe[u] ? 1u : 0u;
         float acc = 0.0f;
         bool lower = false;
+        float tot = (PLAN && plan == 2u) ? 0.0f : -0.0f, mx = plan_max0;  // score plan: root sum / max (see the all-pairs join)
         // the searches in the lists' segments are independent: one LDS read of each per step, four
         // lists at a time (the sum stays in list order)
 #pragma unroll
@@ -579,9 +701,19 @@ score_uniform4_kernel(RoundScoreParams p) {
             const uint2 kk = queue[lo[u] < qe[h + u + 1] ? lo[u] : 0u];  // (an empty segment reads entry 0: ignored)
             const bool mine = ml == (uint32_t)(h + u);
             const bool hit = have && (mine || (lo[u] < qe[h + u + 1] && kk.x == me.x));
+            if (PLAN && plan != 0u && (uint32_t)(h + u) != 0u && (uint32_t)(h + u) < T && ((leaf_start >> (h + u)) & 1u)) {
+              tot += acc;  // list h + u starts a new leaf: the one before it closes (acc = that leaf's sum)
+              mx = fmaxf(mx, acc);
+              acc = 0.0f;
+            }
             acc = hit ? acc + (mine ? __uint_as_float(me.y) : __uint_as_float(kk.y)) : acc;
             lower = lower || (hit && (uint32_t)(h + u) < ml);
           }
+        }
+        if (PLAN && plan != 0u) {  // the last leaf, then the root
+          tot += acc;
+          mx = fmaxf(mx, acc);
+          acc = plan == 2u ? mx + plan_tie * (tot - mx) : tot;
         }
         const bool own = have && !lower;
         n_scored += (uint32_t)__popcll(__ballot(own));
@@ -694,7 +826,7 @@ score_uniform4_kernel(RoundScoreParams p) {
     p.slice_cbeg[slice] = cbeg;
     p.slice_ccnt[slice] = ccur;
   }
-  if (p.q_scored && lane == 0 && n_scored) atomicAdd(&p.q_scored[sl.q], n_scored);
+  if (p.q_scored && lane == 0 && n_scored) atomicAdd(&p.q_scored[rfl(sl.q)], n_scored);
 #ifdef SLG_STAMPS
   const unsigned long long st_extra = st_ins | (st_queued << 32);
   if (p.stamps && lane == 0) {
@@ -705,6 +837,8 @@ score_uniform4_kernel(RoundScoreParams p) {
     p.stamps[(size_t)slice * 12 + 11] = ((unsigned long long)n_r << 32) | (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
   }
 #endif
+  wave_fence();  // (the next slice rewrites the LDS tables this one read)
+  }  // next slice of this wave
 }
 
 }  // namespace slg

@@ -208,6 +208,73 @@ void slh_stats(void *hp, double *out4) {
   out4[3] = (double)h->n_timed.load();
 }
 
+// forget what slh_stats has accumulated (bench.py: after the warm-up, so the means cover the timed regions only)
+void slh_reset_stats(void *hp) {
+  auto *h = static_cast<Harness *>(hp);
+  h->ns_prepare = 0;
+  h->ns_run = 0;
+  h->ns_fetch = 0;
+  h->n_timed = 0;
+}
+
+// ---- request coalescer: n_threads caller threads, each with ONE query at a time -------------------
+// What a server built on searchlite does (searchlite-http/src/lib.rs:628-652: a blocking thread per
+// request): every thread takes the next query of the set (round-robin over its nq queries), calls
+// slg_coalescer_search and compares its row with the expected one (exp_*: the same query set through
+// the batch API; NULL: no check).  Returns the seconds from the common start until total_queries have
+// been answered, or a negative value on error; *mismatches = rows that differ, *n_batches = batches the
+// coalescer ran.
+double slh_coalesce_bench(slg_index *ix, int device, int n_threads, int64_t total_queries, const uint32_t *offs,
+                          const uint32_t *terms, const float *w, uint32_t nq, uint32_t n_segs, uint32_t k,
+                          int strategy, uint32_t max_batch, uint32_t max_wait_us, const uint32_t *exp_doc,
+                          const float *exp_score, const uint32_t *exp_count, int64_t *mismatches,
+                          uint64_t *n_batches) {
+  slg_coalescer *co = slg_coalescer_create(ix, max_batch, max_wait_us);
+  if (!co) return -1.0;
+  std::atomic<int64_t> next{0}, bad{0}, failed{0};
+  std::atomic<int> ready{0};
+  std::atomic<bool> go{false};
+  std::vector<std::thread> pool;
+  for (int t = 0; t < n_threads; t++)
+    pool.emplace_back([&] {
+      (void)hipSetDevice(device);
+      std::vector<uint32_t> doc(k ? k : 1), seg(k ? k : 1);
+      std::vector<float> score(k ? k : 1);
+      uint32_t count = 0;
+      ready.fetch_add(1);
+      while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+      for (;;) {
+        const int64_t i = next.fetch_add(1);
+        if (i >= total_queries) break;
+        const uint32_t q = (uint32_t)(i % (int64_t)nq);
+        slg_query qq;
+        qq.n_terms = offs[q + 1] - offs[q];
+        qq.term_ids = terms + (size_t)offs[q] * n_segs;
+        qq.weights = w + offs[q];
+        if (slg_coalescer_search(co, &qq, k, strategy, doc.data(), seg.data(), score.data(), &count, nullptr) != SLG_OK) {
+          failed.fetch_add(1);
+          continue;
+        }
+        if (exp_count) {
+          bool same = count == exp_count[q];
+          for (uint32_t j = 0; same && j < count; j++)
+            same = doc[j] == exp_doc[(size_t)q * k + j] &&
+                   std::memcmp(&score[j], &exp_score[(size_t)q * k + j], 4) == 0;
+          if (!same) bad.fetch_add(1);
+        }
+      }
+    });
+  while (ready.load() < n_threads) std::this_thread::yield();
+  const auto t0 = std::chrono::steady_clock::now();
+  go.store(true, std::memory_order_release);
+  for (auto &th : pool) th.join();
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (mismatches) *mismatches = bad.load();
+  if (n_batches) (void)slg_coalescer_stats(co, n_batches, nullptr);
+  slg_coalescer_destroy(co);
+  return failed.load() ? -2.0 : secs;
+}
+
 const char *slh_error(void *hp) { return static_cast<Harness *>(hp)->error.c_str(); }
 
 // the results of the first batch of query set `set`; returns 1 if one was run

@@ -59,6 +59,7 @@ def default_tuning(**over):
     t.uniform_max_terms, t.multi_round_target, t.probe_target = 8, 448, 2048
     t.slices_per_subquery, t.cand_mode, t.slice_order, t.block_max = 16, 1, 1, 1
     t.uniform_kernel = 4
+    t.updatable, t.uniform_plans = 1, 1
     for k, v in over.items():
         setattr(t, k, v)
     return t

@@ -15,7 +15,10 @@ for kr in 1 2 4 8 16; do
   OBJS="$OBJS k$kr.o"
 done
 /opt/rocm/bin/hipcc $FLAGS -c slg_api.hip -o api.o &
+PLAN=""
+if [ -f slg_plan.cpp ]; then /opt/rocm/bin/hipcc $FLAGS -x c++ -c slg_plan.cpp -o plan.o & PLAN="plan.o"; fi
+if [ -f slg_coalesce.hip ]; then /opt/rocm/bin/hipcc $FLAGS -c slg_coalesce.hip -o coalesce.o & PLAN="$PLAN coalesce.o"; fi
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/searchlite_amd/lib/libsearchlite_gpu_$TAG.so" api.o $OBJS
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/searchlite_amd/lib/libsearchlite_gpu_$TAG.so" api.o $PLAN $OBJS
 rm -rf "$TMP"
 echo "$ROOT/searchlite_amd/lib/libsearchlite_gpu_$TAG.so"
