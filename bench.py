@@ -87,6 +87,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=0, help="queries in the CPU sample")
     ap.add_argument("--check", type=int, default=64, help="queries parity-checked vs the oracle")
+    ap.add_argument("--c4-threads", type=int, default=4, help="caller threads per rank of the index-sharded leg")
     ap.add_argument("--coalesce-threads", type=int, default=256,
                     help="caller threads of the request-coalescer leg (config c2, N = 1; 0: skip the leg)")
     ap.add_argument("--force-dist", action="store_true",
@@ -211,47 +212,67 @@ def main():
         else:
             uid = searcher.shard_unique_id()
         group = searcher.ShardGroup(index, rank, world, uid, per_rank)
-        live = [None] * n_flight
+        # The caller threads are native (lib/libslg_harness.so), as in the replica workload: `c4_threads`
+        # threads per rank, each keeping two batches going on two HIP streams of its own — prepare
+        # (host planning + H2D of the descriptors) of one batch overlaps the kernels, the all-gather
+        # and the merge of the others.  With several threads the ranks' collectives are ordered by the
+        # step number (slg_batch_run_sharded_seq): the same on every rank.
+        import ctypes as C
+        from searchlite_amd import build as sbuild
+        L = C.CDLL(sbuild.build_harness())
+        L.slh_create.restype = C.c_void_p
+        L.slh_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_uint32, C.c_uint32, C.c_int]
+        L.slh_set_group.argtypes = [C.c_void_p, C.c_void_p]
+        L.slh_run.restype = C.c_int
+        L.slh_run.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+        L.slh_error.restype = C.c_char_p
+        L.slh_error.argtypes = [C.c_void_p]
+        L.slh_first_result.restype = C.c_int
+        L.slh_first_result.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.slh_destroy.argtypes = [C.c_void_p]
+        L.slh_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.slh_reset_stats.argtypes = [C.c_void_p]
+        keep = [(np.ascontiguousarray(o, np.uint32), np.ascontiguousarray(t, np.uint32),
+                 np.ascontiguousarray(w_, np.float32)) for o, t, w_ in qs]
+        ptrs = lambda j: (C.c_void_p * len(keep))(*[x[j].ctypes.data for x in keep])
+        c4_threads = max(1, args.c4_threads)
+        hh = L.slh_create(index._h, local_rank, c4_threads, len(keep), ptrs(0), ptrs(1), ptrs(2), nq, k, strategy)
+        L.slh_set_group(hh, group._h)
         postings = []
-        last_res = [None]
+        for j in range(len(qs)):  # planning facts of every query set (not timed)
+            bb = index.prepare(*qs[j], k, strategy)
+            postings.append(bb.info())
+            bb.close()
 
-        def step(i):
-            f = i % n_flight
-            if live[f] is not None:  # the slot's previous batch: wait, merged top-k to the host
-                last_res[0] = live[f].fetch_sharded()
-                live[f].close()
-            offs, terms, w = qs[i % len(qs)]
-            b = index.prepare(offs, terms, w, k, strategy)  # host planning + H2D of the descriptors
-            b.set_stream(streams[f].cuda_stream)
-            b.run_sharded(group, fetch=False)               # asynchronous: collected one lap later
-            if len(postings) < len(qs):
-                postings.append(b.info())
-            live[f] = b
+        def run_steps(n, first):
+            if L.slh_run(hh, first, n) != 0:
+                raise RuntimeError("host harness (sharded): " + L.slh_error(hh).decode())
 
-        def drain():
-            order = sorted(range(n_flight), key=lambda f: 0 if live[f] is None else 1)
-            for f in range(n_flight):
-                ff = (drain.next + f) % n_flight
-                if live[ff] is not None:
-                    last_res[0] = live[ff].fetch_sharded()
-                    live[ff].close()
-                    live[ff] = None
-        drain.next = 0
-
-        for i in range(warmup):
-            step(i)
-        drain.next = warmup % n_flight
-        drain()
+        warm = max(warmup, 2 * c4_threads)
+        run_steps(warm, 0)
+        L.slh_reset_stats(hh)
+        index.profile(True)
+        group.stats()
         fence()
         t1 = time.perf_counter()
-        for i in range(steps):
-            step(warmup + i)
-        drain.next = (warmup + steps) % n_flight  # oldest batch first: the last step's result is collected last
-        drain()
+        run_steps(steps, warm)
         fence()
         elapsed = max_over_ranks(time.perf_counter() - t1)
+        index.profile(False)
+        hs = (C.c_double * 4)()
+        L.slh_stats(hh, hs)
+        gstats = group.stats()
+        d0 = np.zeros((nq, k), np.uint32)
+        s0 = np.zeros((nq, k), np.uint32)
+        sc0 = np.zeros((nq, k), np.float32)
+        c0 = np.zeros(nq, np.uint32)
+        if not L.slh_first_result(hh, 0, d0.ctypes.data, s0.ctypes.data, sc0.ctypes.data, c0.ctypes.data):
+            raise RuntimeError("host harness (sharded): no result for query set 0")
+        last_res = [(d0, s0, sc0, c0)]
+        L.slh_destroy(hh)
         res = tuple(np.asarray(x).copy() for x in last_res[0])
-        last_q = qs[(warmup + steps - 1) % len(qs)]
+        last_q = qs[0]  # (the harness keeps the first result of every query set: set 0)
         info = index.info()
         group.close()
         index.close()
@@ -262,6 +283,13 @@ def main():
                            f"behind the C ABI + device merge), merged top-k copied to the host",
                "queries_per_s": round(nq / (elapsed / steps), 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
                "steps": steps, "scaling": "strong", "segments_per_rank": per_rank,
+               "caller_threads_per_rank": c4_threads,
+               # rank 0's view of one step (means over the timed region): host time inside the C ABI per batch
+               # (a thread keeps two batches going: plan_ms overlaps the device work of other batches) and the
+               # device time of the batch's three phases (gather_ms includes waiting for the slowest rank)
+               "per_rank": {"plan_ms": round(hs[0], 3), "launch_ms": round(hs[1], 3), "fetch_wait_ms": round(hs[2], 3),
+                            "kernel_ms": round(gstats["kernel_ms"], 3), "gather_ms": round(gstats["gather_ms"], 3),
+                            "merge_ms": round(gstats["merge_ms"], 3), "runs_timed": gstats["runs"]},
                "postings_per_batch_this_rank": int(np.mean([p["n_postings"] for p in postings])),
                "index_postings_this_rank": int(info["n_postings"]), "corpus_build_s": round(t_corpus, 1)}
         return out, res, last_q, (n_docs, vocab, cseed, nq, T, k)

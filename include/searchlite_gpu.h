@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SLG_ABI_VERSION 3u  /* 3: slg_tuning grew (updatable, uniform_plans); index updates (slg_index_update_deleted / _add_segment /
+#define SLG_ABI_VERSION 3u  /* 3: slg_tuning grew (updatable, uniform_plans, score_waves_per_simd); index updates (slg_index_update_deleted / _add_segment /
                                _remove_segment / _generation); request coalescer; slg_batch_device_candidates.
                                2: pool_cap_mb, uniform_kernel, uniform_sigma_x100, inline_cuts; shard groups; slg_batch_prepare_plans */
 #define SLG_NO_TERM 0xFFFFFFFFu      /* term absent from a segment (api/reader.rs:2989) */
@@ -198,6 +198,11 @@ typedef struct {
                                     of one or more terms) and <= uniform_max_terms lists per sub-query run on the
                                     few-term kernel's plan instantiation; 0: on the many-term kernel, as two-level
                                     plans do (A/B timing) */
+  uint32_t score_waves_per_simd; /* SLG_SCORE_WAVES (0): 0 = the few-term kernel launches one wave per slice, longest
+                                    slices first (the hardware dispatcher hands out the work); n > 0 = persistent
+                                    waves: n_CU x 4 x min(n, what registers and LDS allow) waves that pull slices
+                                    from 64 work queues.  Measured slower on MI355X: kept for
+                                    A/B timing */
 } slg_tuning;
 void slg_tuning_default(slg_tuning *out);
 slg_index *slg_index_create_tuned(const slg_segment_desc *segs, uint32_t n_segs, int device,
@@ -406,6 +411,15 @@ void slg_coalescer_destroy(slg_coalescer *coalescer);
 int slg_coalescer_search(slg_coalescer *coalescer, const slg_query *query, uint32_t k, int strategy,
                          uint32_t *out_doc, uint32_t *out_seg, float *out_score, uint32_t *out_count,
                          slg_stats *stats_or_null);
+/* The same for a query with a flat score plan (slg_batch_prepare_plan: leaf[i] = leaf of query term i or
+ * NULL, plan = SLG_PLAN_SUM | SLG_PLAN_DISMAX over the leaves, tie in [0, 1], n_leaves = leaves of the
+ * plan or 0 = 1 + the largest leaf named) and / or a registered doc filter (filter_id, < 0: none): what
+ * an unmodified request over the default fields is (api/reader.rs:2576-2586).  Rows with and without
+ * plans or filters share batches.  Two-level plans go through slg_batch_prepare_plans directly. */
+int slg_coalescer_search_plan(slg_coalescer *coalescer, const slg_query *query, const uint32_t *leaf, int plan,
+                              float tie, uint32_t n_leaves, int32_t filter_id, uint32_t k, int strategy,
+                              uint32_t *out_doc, uint32_t *out_seg, float *out_score, uint32_t *out_count,
+                              slg_stats *stats_or_null);
 /* Thread-local text of the last failure of slg_coalescer_search on this thread. */
 const char *slg_coalescer_last_error(void);
 /* Batches run and queries served so far (their ratio = the mean batch size reached). */
@@ -434,6 +448,25 @@ void slg_shard_group_destroy(slg_shard_group *group);
  * to leave the result on the device (slg_batch_sharded_device_results) without waiting. */
 int slg_batch_run_sharded(slg_batch *batch, slg_shard_group *group, uint32_t *out_doc, uint32_t *out_seg,
                           float *out_score, uint32_t *out_count);
+/* Collectives on one communicator must be issued in the same order on every rank.  The group issues
+ * them on a stream of its own, one at a time: slg_batch_run_sharded takes its turn in CALL order — so
+ * every rank must call it for its batches in the same order, which one issuing thread per rank
+ * guarantees (several batches may still be in flight, each on its own stream).  With several caller
+ * threads per rank use the _seq form: `seq` numbers the sharded runs of the group 0, 1, 2, ... without
+ * gaps, the SAME number for the same query batch on every rank; run `seq` issues its all-gather when
+ * runs 0 .. seq-1 of this rank have issued theirs (a call may block until then; a failed run still
+ * passes its turn on).  Do not mix the two forms on one group. */
+int slg_batch_run_sharded_seq(slg_batch *batch, slg_shard_group *group, uint64_t seq, uint32_t *out_doc,
+                              uint32_t *out_seg, float *out_score, uint32_t *out_count);
+/* Passes the turn of run `seq` on without a collective: for a rank that could not prepare the batch of
+ * that number (the runs behind it would wait for ever).  The other ranks must skip the same number —
+ * an all-gather that one rank never joins does not complete. */
+int slg_shard_group_skip_seq(slg_shard_group *group, uint64_t seq);
+/* With slg_profile_enable on: device time (ms, summed) of the sharded runs FETCHED since the last call —
+ * this rank's kernels, the all-gather (incl. waiting for the slowest rank), the merge — and their number.
+ * Resets the sums. */
+int slg_shard_group_stats(slg_shard_group *group, double *ms_kernels, double *ms_gather, double *ms_merge,
+                          uint64_t *n_runs);
 int slg_batch_sharded_device_results(slg_batch *batch, void **d_doc, void **d_seg, void **d_score,
                                      void **d_count);
 /* Waits for the batch's sharded run and copies the merged top-k to host arrays (what

@@ -1,11 +1,19 @@
 // integration/searchlite-core/src/api/reader_gpu.patch.rs — the lines a maintainer adds to
 // IndexReader (searchlite-core/src/api/reader.rs of the surveyed snapshot).  UNVERIFIED SOURCE.
 //
-// (1) field of IndexReader, built in IndexReader::open after `segments` (and rebuilt by whatever
-//     refreshes the reader after a commit):
+// (1) The staged index lives on the INDEX, not on the reader: searchlite opens a fresh IndexReader
+//     per request (searchlite-http/src/lib.rs:640-643 -> index/mod.rs:98-100 ->
+//     api/reader.rs:1887-1913), and staging per reader would upload the whole index per request.
+//
+//     InnerIndex (index/mod.rs) gains the cache slot:
 //
 //       #[cfg(feature = "gpu")]
-//       gpu: Option<crate::gpu::GpuSegments>,
+//       pub(crate) gpu: std::sync::Mutex<Option<std::sync::Arc<crate::gpu::GpuSegments>>>,
+//
+//     IndexReader gains a field and fills it in IndexReader::open, after `segments`:
+//
+//       #[cfg(feature = "gpu")]
+//       gpu: Option<std::sync::Arc<crate::gpu::GpuSegments>>,
 //
 //       #[cfg(feature = "gpu")]
 //       let gpu = {
@@ -13,8 +21,11 @@
 //         let fields: Vec<String> = schema.text_fields.iter().map(|f| f.name.clone())
 //           .chain(schema.keyword_fields.iter().map(|f| f.name.clone())).collect();
 //         let vfield = schema.vector_fields.first().map(|f| f.name.as_str());
-//         // a missing GPU / library is not an error: the CPU scorer serves everything
-//         crate::gpu::GpuSegments::stage(&segments, &fields, vfield, options.bm25_k1, options.bm25_b, 0).ok()
+//         // unchanged manifest: an Arc clone.  After a commit: the device index follows it in place
+//         // (slg_index_update_deleted / _add_segment / _remove_segment); a missing GPU / library is
+//         // not an error: the CPU scorer serves everything
+//         crate::gpu::GpuSegments::for_reader(&inner.gpu, &segments, &fields, vfield,
+//                                            options.bm25_k1, options.bm25_b, 0)
 //       };
 //
 // (2) inside IndexReader::search, right after `expand_term_groups` (api/reader.rs:2629-2635) and the

@@ -29,7 +29,7 @@ pub struct slg_tuning {
     pub probe_target: u32, pub rounds_per_slice: u32, pub max_rounds_per_slice: u32,
     pub slices_per_subquery: u32, pub cand_mode: i32, pub slice_order: i32, pub block_max: i32,
     pub pool_cap_mb: u32, pub uniform_kernel: u32, pub uniform_sigma_x100: u32, pub inline_cuts: i32,
-    pub updatable: i32, pub uniform_plans: i32,
+    pub updatable: i32, pub uniform_plans: i32, pub score_waves_per_simd: u32,
 }
 #[repr(C)] pub struct slg_vector_field_desc {
     pub vec_dim: u32, pub vec_metric: i32, pub vec_offsets: *const u32, pub vec_values: *const c_float, pub vec_rows: u32,
@@ -66,6 +66,9 @@ extern "C" {
     pub fn slg_coalescer_search(coalescer: *mut slg_coalescer, query: *const slg_query, k: u32, strategy: c_int,
         out_doc: *mut u32, out_seg: *mut u32, out_score: *mut c_float, out_count: *mut u32,
         stats_or_null: *mut slg_stats) -> c_int;
+    pub fn slg_coalescer_search_plan(coalescer: *mut slg_coalescer, query: *const slg_query, leaf: *const u32,
+        plan: c_int, tie: c_float, n_leaves: u32, filter_id: i32, k: u32, strategy: c_int, out_doc: *mut u32,
+        out_seg: *mut u32, out_score: *mut c_float, out_count: *mut u32, stats_or_null: *mut slg_stats) -> c_int;
     pub fn slg_coalescer_last_error() -> *const c_char;
     pub fn slg_coalescer_stats(coalescer: *const slg_coalescer, n_batches: *mut u64, n_queries: *mut u64) -> c_int;
     // index sharding over RCCL (api/reader.rs:2670-2778 across GPUs)
@@ -75,6 +78,11 @@ extern "C" {
     pub fn slg_shard_group_destroy(group: *mut slg_shard_group);
     pub fn slg_batch_run_sharded(batch: *mut slg_batch, group: *mut slg_shard_group, out_doc: *mut u32,
         out_seg: *mut u32, out_score: *mut c_float, out_count: *mut u32) -> c_int;
+    pub fn slg_batch_run_sharded_seq(batch: *mut slg_batch, group: *mut slg_shard_group, seq: u64, out_doc: *mut u32,
+        out_seg: *mut u32, out_score: *mut c_float, out_count: *mut u32) -> c_int;
+    pub fn slg_shard_group_skip_seq(group: *mut slg_shard_group, seq: u64) -> c_int;
+    pub fn slg_shard_group_stats(group: *mut slg_shard_group, ms_kernels: *mut f64, ms_gather: *mut f64,
+        ms_merge: *mut f64, n_runs: *mut u64) -> c_int;
     pub fn slg_batch_sharded_device_results(batch: *mut slg_batch, d_doc: *mut *mut c_void, d_seg: *mut *mut c_void,
         d_score: *mut *mut c_void, d_count: *mut *mut c_void) -> c_int;
     pub fn slg_batch_fetch_sharded(batch: *mut slg_batch, out_doc: *mut u32, out_seg: *mut u32,

@@ -45,15 +45,34 @@ fn last_error() -> anyhow::Error {
   anyhow!("searchlite_gpu: {msg}")
 }
 
-/// All segments of one IndexReader staged in HBM (slg_index_create).  Segments are immutable;
-/// build it when the reader opens and again after a commit / compaction, or when live_docs changes
-/// (idf uses `docs = seg.live_docs()`, api/reader.rs:2985).
+/// All segments of an index staged in HBM (slg_index_create).  ONE per `Index`, not per reader:
+/// searchlite opens a fresh IndexReader for every request (searchlite-http/src/lib.rs:640-643 ->
+/// index/mod.rs:98-100 -> api/reader.rs:1887-1913), so the staged index lives on `InnerIndex`
+/// (`gpu: Mutex<Option<Arc<GpuSegments>>>`) and `IndexReader::open` calls `GpuSegments::for_reader`,
+/// which hands out the cached Arc while the manifest still describes what is staged and otherwise
+/// brings the device index up to date IN PLACE (slg_index_update_deleted / _add_segment /
+/// _remove_segment: a commit merges tombstones and appends at most one segment, api/writer.rs:150-192;
+/// `docs = seg.live_docs()` feeds every idf, api/reader.rs:2985) — a full re-stage only when the
+/// manifest changed in a way those three calls cannot express.
 pub struct GpuSegments {
   handle: *mut ffi::slg_index,
-  /// per segment: "field:term" key -> term id (rank of the key in the sorted dictionary)
-  dict: Vec<HashMap<String, u32>>,
+  /// concurrent single-query callers -> batches (slg_coalescer_*)
+  coalescer: *mut ffi::slg_coalescer,
+  /// what is staged: (segment id, tombstones) per ordinal, and the library's generation after the
+  /// last update.  A reader whose manifest snapshot differs falls back to the CPU scorer.
+  state: std::sync::RwLock<StagedState>,
   /// filters already registered: serialized Filter -> filter id (slg_index_add_filter)
   filters: Mutex<FilterCache>,  // bounded LRU of registered doc filters
+}
+
+/// (segment id, number of tombstones) per segment ordinal — what `Manifest` says a reader sees.
+pub(crate) type ManifestKey = Vec<(String, usize)>;
+
+struct StagedState {
+  key: ManifestKey,
+  generation: u64,
+  /// per segment: "field:term" key -> term id (rank of the key in the sorted dictionary)
+  dict: Vec<std::sync::Arc<HashMap<String, u32>>>,
 }
 
 // The library serialises launches internally and planning takes no lock.
@@ -62,8 +81,24 @@ unsafe impl Sync for GpuSegments {}
 
 impl Drop for GpuSegments {
   fn drop(&mut self) {
-    unsafe { ffi::slg_index_destroy(self.handle) }
+    unsafe {
+      ffi::slg_coalescer_destroy(self.coalescer); // (no request can be inside: they hold an Arc)
+      ffi::slg_index_destroy(self.handle)
+    }
   }
+}
+
+pub(crate) fn manifest_key(segments: &[SegmentReader]) -> ManifestKey {
+  segments.iter().map(|s| (s.meta.id.clone(), s.meta.deleted_docs.len())).collect()
+}
+
+fn tombstone_bitmap(seg: &SegmentReader) -> Vec<u8> {
+  let n_docs = seg.meta.doc_count as usize;
+  let mut bm = vec![0u8; n_docs.div_ceil(8)];
+  for &d in seg.meta.deleted_docs.iter() {
+    bm[(d >> 3) as usize] |= 1u8 << (d & 7);
+  }
+  bm
 }
 
 /// Host copies of one segment's arrays; they only have to outlive slg_index_create.
@@ -83,6 +118,85 @@ struct StagedSegment {
 }
 
 impl GpuSegments {
+  /// What `IndexReader::open` calls with the cache slot of its `InnerIndex`: the staged index for
+  /// this reader's manifest snapshot.  Cheap when nothing changed (a key compare + an Arc clone).
+  pub fn for_reader(
+    slot: &Mutex<Option<std::sync::Arc<GpuSegments>>>,
+    segments: &[SegmentReader],
+    fields: &[String],
+    vector_field: Option<&str>,
+    k1: f32,
+    b: f32,
+    device: i32,
+  ) -> Option<std::sync::Arc<GpuSegments>> {
+    let want = manifest_key(segments);
+    let mut guard = slot.lock().unwrap();
+    if let Some(g) = guard.as_ref() {
+      if g.state.read().unwrap().key == want || g.follow(segments, &want, fields, vector_field, k1, b).is_ok() {
+        return Some(g.clone());
+      }
+    }
+    // first reader, or a manifest the update calls cannot reach from what is staged: stage afresh
+    // (a missing GPU / library is not an error: the CPU scorer serves everything)
+    let fresh = GpuSegments::stage(segments, fields, vector_field, k1, b, device).ok().map(std::sync::Arc::new);
+    *guard = fresh.clone();
+    fresh
+  }
+
+  /// Bring the device index from `state.key` to `want` with the update calls: tombstones that grew
+  /// (same id at the same ordinal), segments appended at the end, segments that disappeared.
+  fn follow(
+    &self,
+    segments: &[SegmentReader],
+    want: &ManifestKey,
+    fields: &[String],
+    vector_field: Option<&str>,
+    k1: f32,
+    b: f32,
+  ) -> Result<()> {
+    let mut st = self.state.write().unwrap(); // no request builds term ids while the segment set changes
+    // segments that left the manifest (compaction), highest ordinal first
+    for ord in (0..st.key.len()).rev() {
+      if !want.iter().any(|(id, _)| *id == st.key[ord].0) {
+        if unsafe { ffi::slg_index_remove_segment(self.handle, ord as u32) } != 0 {
+          return Err(last_error());
+        }
+        st.key.remove(ord);
+        st.dict.remove(ord);
+      }
+    }
+    // what is left must be a prefix of the manifest, in order
+    if st.key.len() > want.len() || st.key.iter().zip(want.iter()).any(|(a, w)| a.0 != w.0 || a.1 > w.1) {
+      bail!("manifest is not reachable from the staged index");
+    }
+    for ord in 0..st.key.len() {
+      if st.key[ord].1 != want[ord].1 {
+        let seg = &segments[ord];
+        let bm = tombstone_bitmap(seg);
+        if unsafe { ffi::slg_index_update_deleted(self.handle, ord as u32, bm.as_ptr(), seg.live_docs() as f32) } != 0 {
+          return Err(last_error());
+        }
+        st.key[ord].1 = want[ord].1;
+      }
+    }
+    for ord in st.key.len()..want.len() {
+      let (staged, dict) = stage_one(&segments[ord], fields, vector_field)?;
+      let desc = staged.descriptor(&segments[ord], fields.len() as u32, k1, b);
+      if unsafe { ffi::slg_index_add_segment(self.handle, &desc) } < 0 {
+        return Err(last_error());
+      }
+      st.key.push(want[ord].clone());
+      st.dict.push(std::sync::Arc::new(dict));
+    }
+    st.generation = unsafe { ffi::slg_index_generation(self.handle) };
+    // registered filters predate the new segments / tombstones of other segments: start over
+    let mut cache = self.filters.lock().unwrap();
+    for (_, (id, _)) in cache.map.drain() {
+      unsafe { ffi::slg_index_remove_filter(self.handle, id) };
+    }
+    Ok(())
+  }
+
   /// `fields`: every field that owns "field:term" keys (schema text fields, then keyword
   /// fields); `vector_field`: the field slg_rerank_* serves, if any.
   pub fn stage(
@@ -93,102 +207,127 @@ impl GpuSegments {
     b: f32,
     device: i32,
   ) -> Result<Self> {
-    let field_id: HashMap<&str, u16> =
-      fields.iter().enumerate().map(|(i, f)| (f.as_str(), i as u16)).collect();
     let mut staged: Vec<StagedSegment> = Vec::with_capacity(segments.len());
-    let mut dict: Vec<HashMap<String, u32>> = Vec::with_capacity(segments.len());
+    let mut dict: Vec<std::sync::Arc<HashMap<String, u32>>> = Vec::with_capacity(segments.len());
     for seg in segments {
-      let n_docs = seg.meta.doc_count as usize;
-      let mut s = StagedSegment {
-        term_offsets: vec![0],
-        doc_ids: Vec::new(),
-        tfs: Vec::new(),
-        term_field: Vec::new(),
-        field_lens: Vec::new(),
-        field_len_ptrs: Vec::new(),
-        field_avgdl: Vec::new(),
-        deleted: vec![0u8; n_docs.div_ceil(8)],
-        vec_offsets: Vec::new(),
-        vec_values: std::sync::Arc::new(Vec::new()),
-        vec_dim: 0,
-        vec_metric: ffi::SLG_METRIC_COSINE,
-      };
-      let mut ids = HashMap::new();
-      // the dictionary iterates in sorted key order (TinyFst is a BTreeMap, util/fst.rs:4-31)
-      for key in seg.terms_with_prefix("") {
-        let Some((field, _)) = key.split_once(':') else { continue };
-        let Some(&fid) = field_id.get(field) else { continue };
-        let Some(postings) = seg.postings(key) else { continue };
-        ids.insert(key.clone(), s.term_field.len() as u32);
-        s.term_field.push(fid);
-        for e in postings.entries() {
-          s.doc_ids.push(e.doc_id);
-          s.tfs.push(e.term_freq);
-        }
-        s.term_offsets.push(s.doc_ids.len() as u64);
-      }
-      dict.push(ids);
-      for f in fields {
-        // field_lengths_for, api/reader.rs:3604-3621: absent -> 0 -> the scorer's max(avgdl, 1)
-        let key = doc_length_key(f);
-        let lens: Vec<f32> = (0..n_docs as DocId)
-          .map(|d| seg.fast_fields().i64_value(&key, d).unwrap_or(0) as f32)
-          .collect();
-        s.field_avgdl.push(seg.avg_field_length(f));
-        s.field_lens.push(Some(lens));
-      }
-      for d in 0..n_docs as DocId {
-        if seg.is_deleted(d) {
-          s.deleted[(d >> 3) as usize] |= 1u8 << (d & 7);
-        }
-      }
-      #[cfg(feature = "vectors")]
-      if let Some((_, store)) = vector_field.and_then(|vf| seg.vector_components(vf)) {
-        s.vec_dim = store.dim() as u32;
-        s.vec_metric = match store.metric() {
-          crate::vectors::VectorMetric::Cosine => ffi::SLG_METRIC_COSINE,
-          crate::vectors::VectorMetric::L2 => ffi::SLG_METRIC_L2,
-        };
-        s.vec_offsets = store.offsets().to_vec();
-        s.vec_values = store.values();
-      }
+      let (s, ids) = stage_one(seg, fields, vector_field)?;
       staged.push(s);
-    }
-    for s in staged.iter_mut() {
-      s.field_len_ptrs =
-        s.field_lens.iter().map(|l| l.as_ref().map_or(std::ptr::null(), |v| v.as_ptr())).collect();
+      dict.push(std::sync::Arc::new(ids));
     }
     let descs: Vec<ffi::slg_segment_desc> = segments
       .iter()
       .zip(staged.iter())
-      .map(|(seg, s)| ffi::slg_segment_desc {
-        n_docs: seg.meta.doc_count,
-        n_terms: s.term_field.len() as u32,
-        term_offsets: s.term_offsets.as_ptr(),
-        doc_ids: s.doc_ids.as_ptr(),
-        tfs: s.tfs.as_ptr(),
-        term_field: s.term_field.as_ptr(),
-        n_fields: fields.len() as u32,
-        field_doc_len: s.field_len_ptrs.as_ptr(),
-        field_avgdl: s.field_avgdl.as_ptr(),
-        docs: seg.live_docs() as f32, // api/reader.rs:2985
-        k1,
-        b,
-        deleted: s.deleted.as_ptr(),
-        vec_dim: s.vec_dim,
-        vec_metric: s.vec_metric,
-        vec_offsets: if s.vec_dim > 0 { s.vec_offsets.as_ptr() } else { std::ptr::null() },
-        vec_values: if s.vec_dim > 0 { s.vec_values.as_ptr() } else { std::ptr::null() },
-        vec_rows: if s.vec_dim > 0 { (s.vec_values.len() / s.vec_dim as usize) as u32 } else { 0 },
-      })
+      .map(|(seg, s)| s.descriptor(seg, fields.len() as u32, k1, b))
       .collect();
     let handle = unsafe { ffi::slg_index_create(descs.as_ptr(), descs.len() as u32, device) };
     if handle.is_null() {
       return Err(last_error());
     }
-    Ok(Self { handle, dict, filters: Mutex::new(FilterCache::default()) })
+    // batches of up to 1024 requests; a batch closes 30 us after its first request unless the device is idle
+    let coalescer = unsafe { ffi::slg_coalescer_create(handle, 1024, 30) };
+    if coalescer.is_null() {
+      unsafe { ffi::slg_index_destroy(handle) };
+      bail!("slg_coalescer_create failed");
+    }
+    let state = StagedState { key: manifest_key(segments), generation: 0, dict };
+    Ok(Self { handle, coalescer, state: std::sync::RwLock::new(state), filters: Mutex::new(FilterCache::default()) })
   }
+}
 
+impl StagedSegment {
+  fn descriptor(&self, seg: &SegmentReader, n_fields: u32, k1: f32, b: f32) -> ffi::slg_segment_desc {
+    let s = self;
+    ffi::slg_segment_desc {
+      n_docs: seg.meta.doc_count,
+      n_terms: s.term_field.len() as u32,
+      term_offsets: s.term_offsets.as_ptr(),
+      doc_ids: s.doc_ids.as_ptr(),
+      tfs: s.tfs.as_ptr(),
+      term_field: s.term_field.as_ptr(),
+      n_fields,
+      field_doc_len: s.field_len_ptrs.as_ptr(),
+      field_avgdl: s.field_avgdl.as_ptr(),
+      docs: seg.live_docs() as f32, // api/reader.rs:2985
+      k1,
+      b,
+      deleted: s.deleted.as_ptr(),
+      vec_dim: s.vec_dim,
+      vec_metric: s.vec_metric,
+      vec_offsets: if s.vec_dim > 0 { s.vec_offsets.as_ptr() } else { std::ptr::null() },
+      vec_values: if s.vec_dim > 0 { s.vec_values.as_ptr() } else { std::ptr::null() },
+      vec_rows: if s.vec_dim > 0 { (s.vec_values.len() / s.vec_dim as usize) as u32 } else { 0 },
+    }
+  }
+}
+
+/// Host arrays of ONE segment in the layout slg_segment_desc borrows, and its term dictionary.
+fn stage_one(
+  seg: &SegmentReader,
+  fields: &[String],
+  vector_field: Option<&str>,
+) -> Result<(StagedSegment, HashMap<String, u32>)> {
+  let field_id: HashMap<&str, u16> =
+    fields.iter().enumerate().map(|(i, f)| (f.as_str(), i as u16)).collect();
+  let _ = vector_field; // (read only with the `vectors` feature)
+  let n_docs = seg.meta.doc_count as usize;
+  let mut s = StagedSegment {
+    term_offsets: vec![0],
+    doc_ids: Vec::new(),
+    tfs: Vec::new(),
+    term_field: Vec::new(),
+    field_lens: Vec::new(),
+    field_len_ptrs: Vec::new(),
+    field_avgdl: Vec::new(),
+    deleted: vec![0u8; n_docs.div_ceil(8)],
+    vec_offsets: Vec::new(),
+    vec_values: std::sync::Arc::new(Vec::new()),
+    vec_dim: 0,
+    vec_metric: ffi::SLG_METRIC_COSINE,
+  };
+  let mut ids = HashMap::new();
+  // the dictionary iterates in sorted key order (TinyFst is a BTreeMap, util/fst.rs:4-31)
+  for key in seg.terms_with_prefix("") {
+    let Some((field, _)) = key.split_once(':') else { continue };
+    let Some(&fid) = field_id.get(field) else { continue };
+    let Some(postings) = seg.postings(key) else { continue };
+    ids.insert(key.clone(), s.term_field.len() as u32);
+    s.term_field.push(fid);
+    for e in postings.entries() {
+      s.doc_ids.push(e.doc_id);
+      s.tfs.push(e.term_freq);
+    }
+    s.term_offsets.push(s.doc_ids.len() as u64);
+  }
+  for f in fields {
+    // field_lengths_for, api/reader.rs:3604-3621: absent -> 0 -> the scorer's max(avgdl, 1)
+    let key = doc_length_key(f);
+    let lens: Vec<f32> = (0..n_docs as DocId)
+      .map(|d| seg.fast_fields().i64_value(&key, d).unwrap_or(0) as f32)
+      .collect();
+    s.field_avgdl.push(seg.avg_field_length(f));
+    s.field_lens.push(Some(lens));
+  }
+  for d in 0..n_docs as DocId {
+    if seg.is_deleted(d) {
+      s.deleted[(d >> 3) as usize] |= 1u8 << (d & 7);
+    }
+  }
+  #[cfg(feature = "vectors")]
+  if let Some((_, store)) = vector_field.and_then(|vf| seg.vector_components(vf)) {
+    s.vec_dim = store.dim() as u32;
+    s.vec_metric = match store.metric() {
+      crate::vectors::VectorMetric::Cosine => ffi::SLG_METRIC_COSINE,
+      crate::vectors::VectorMetric::L2 => ffi::SLG_METRIC_L2,
+    };
+    s.vec_offsets = store.offsets().to_vec();
+    s.vec_values = store.values();
+  }
+  s.field_len_ptrs =
+    s.field_lens.iter().map(|l| l.as_ref().map_or(std::ptr::null(), |v| v.as_ptr())).collect();
+  Ok((s, ids))
+}
+
+impl GpuSegments {
   pub(crate) fn raw(&self) -> *mut ffi::slg_index {
     self.handle
   }
@@ -407,9 +546,17 @@ pub(crate) fn gpu_top_k(
   top_k: usize,
 ) -> Result<(Vec<(u32, DocId, f32)>, u64)> {
   let n_segs = segments.len();
+  // the reader's manifest snapshot must be what is staged (a commit may have moved the device index
+  // on since this reader opened: such a request runs on the CPU scorer, as does the next one only if
+  // its reader is older still).  The read lock keeps the segment set fixed while the ids are built
+  // and the query is handed over.
+  let st = gpu.state.read().unwrap();
+  if st.key != manifest_key(segments) {
+    bail!("staged index has moved past this reader's manifest");
+  }
   let mut term_ids = Vec::with_capacity(folded.len() * n_segs);
   for t in folded {
-    for d in gpu.dict.iter() {
+    for d in st.dict.iter() {
       term_ids.push(d.get(&t.key).copied().unwrap_or(ffi::SLG_NO_TERM));
     }
   }
@@ -458,6 +605,27 @@ pub(crate) fn gpu_top_k(
     ExecutionStrategy::Bmw => ffi::SLG_STRATEGY_BMW,
   };
   let k = top_k as u32;
+  // Flat plans (every query string, multi_match, dis_max of terms) go through the coalescer: the
+  // reference has no batch API (api/reader.rs:2539) and serves a request per blocking thread
+  // (searchlite-http/src/lib.rs:628-652), so concurrent requests share one prepare / run / fetch.
+  if !matches!(score_plan, GpuScorePlan::Tree { .. }) {
+    let (mut doc, mut seg, mut score) = (vec![0u32; top_k], vec![0u32; top_k], vec![0f32; top_k]);
+    let mut count = 0u32;
+    let mut stats = ffi::slg_stats { scored_docs: 0, candidates_examined: 0, postings_advanced: 0 };
+    let q = ffi::slg_query { n_terms: folded.len() as u32, term_ids: term_ids.as_ptr(), weights: weights.as_ptr() };
+    let rc = unsafe {
+      ffi::slg_coalescer_search_plan(
+        gpu.coalescer, &q, leaves.as_ptr(), plan_kind, tie, n_leaves, filter_id, k, strategy,
+        doc.as_mut_ptr(), seg.as_mut_ptr(), score.as_mut_ptr(), &mut count, &mut stats,
+      )
+    };
+    drop(st);
+    if rc != 0 {
+      bail!("searchlite_gpu returned {rc}");
+    }
+    let hits = (0..count as usize).map(|i| (seg[i], doc[i] as DocId, score[i])).collect();
+    return Ok((hits, stats.scored_docs));
+  }
   let batch = unsafe {
     ffi::slg_batch_prepare_plans(
       gpu.raw(),

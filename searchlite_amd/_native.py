@@ -64,7 +64,7 @@ class Tuning(C.Structure):
                 ("slice_order", C.c_int32), ("block_max", C.c_int32), ("pool_cap_mb", C.c_uint32),
                 ("uniform_kernel", C.c_uint32), ("uniform_sigma_x100", C.c_uint32),
                 ("inline_cuts", C.c_int32), ("updatable", C.c_int32),
-                ("uniform_plans", C.c_int32)]
+                ("uniform_plans", C.c_int32), ("score_waves_per_simd", C.c_uint32)]
 
 
 class ScorePlans(C.Structure):
@@ -132,6 +132,7 @@ def load():
         "slg_coalescer_create": (vp, [vp, u32, u32]),
         "slg_coalescer_destroy": (None, [vp]),
         "slg_coalescer_search": (i32, [vp, vp, u32, i32, vp, vp, vp, vp, vp]),
+        "slg_coalescer_search_plan": (i32, [vp, vp, vp, i32, f32, u32, C.c_int32, u32, i32, vp, vp, vp, vp, vp]),
         "slg_coalescer_last_error": (C.c_char_p, []),
         "slg_coalescer_stats": (i32, [vp, vp, vp]),
         "slg_search_batch": (i32, [vp, vp, u32, u32, i32, vp, vp, vp, vp, vp]),
@@ -159,6 +160,9 @@ def load():
         "slg_shard_group_destroy": (None, [vp]),
         "slg_batch_run_sharded": (i32, [vp, vp, vp, vp, vp, vp]),
         "slg_batch_sharded_device_results": (i32, [vp, vp, vp, vp, vp]),
+        "slg_batch_run_sharded_seq": (i32, [vp, vp, C.c_uint64, vp, vp, vp, vp]),
+        "slg_shard_group_stats": (i32, [vp, vp, vp, vp, vp]),
+        "slg_shard_group_skip_seq": (i32, [vp, C.c_uint64]),
         "slg_batch_fetch_sharded": (i32, [vp, vp, vp, vp, vp]),
         "slg_profile_enable": (i32, [vp, i32]),
         "slg_profile_read": (i32, [vp, vp, vp]),
@@ -176,6 +180,8 @@ def load():
                                                  vp, vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():
+        if os.environ.get("SLG_LIB_TAG") and not hasattr(L, name):
+            continue  # an experiment build of an older revision (tools/build_variant.sh): A/B timing only
         fn = getattr(L, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args

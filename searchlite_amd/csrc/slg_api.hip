@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -405,6 +406,9 @@ struct slg_batch {
   // index-sharded runs (slg_batch_run_sharded): the gathered result blocks of all ranks and the merged
   // top-k doc | seg | score | count
   DevBuf d_gather, d_merged;
+  slg_shard_group *shard_group = nullptr;  // the group of the last sharded run (timing goes there)
+  hipEvent_t ev_shard[4] = {nullptr, nullptr, nullptr, nullptr};  // start | local kernels done | gathered | merged
+  bool shard_timed = false;
   uint64_t n_postings_nonessential = 0;  // postings of the pruning-classified (non-essential) lists
 };
 
@@ -839,6 +843,7 @@ void slg_tuning_default(slg_tuning *t) {
   t->inline_cuts = env_i32("SLG_INLINE_CUTS", -1);
   t->updatable = env_i32("SLG_NOT_UPDATABLE", 0) == 0;
   t->uniform_plans = env_i32("SLG_NO_UNIFORM_PLANS", 0) == 0;
+  t->score_waves_per_simd = env_u32("SLG_SCORE_WAVES", 0);
 }
 
 slg_index *slg_index_create(const slg_segment_desc *segs, uint32_t n_segs, int device) {
@@ -1385,14 +1390,17 @@ int slg_batch_run(slg_batch *b) {
       pp.n_boundaries = inline_cuts ? 0u : b->n_boundaries;
       pp.n_slices = b->n_slices;
       pp.tpb_shift = b->max_terms <= 4 ? 2u : 3u;
-      // few-term kernel: persistent waves, one per wave slot of the device (slg_score_uni4.hpp)
+      // few-term kernel: one wave per slice, or (slg_tuning.score_waves_per_simd) persistent waves that
+      // pull slices from the batch's work queues (slg_score_uni4.hpp)
       const int score_kind =
           b->uniform ? uniform_kind(ix->tune.uniform_kernel, b->max_terms, b->plan_batch) : (b->pruned ? 3 : 2);
       uint32_t n_waves = b->n_slices;
-      if (score_kind >= 6 && score_kind <= 9)
-        n_waves = slg::u4_launch_blocks(kregs_for(b->k), (score_kind & 1) ? 8 : 4, score_kind >= 8, b->n_slices, ix->n_cu) *
+      const bool persistent = score_kind >= 6 && score_kind <= 9 && ix->tune.score_waves_per_simd != 0;
+      if (persistent)
+        n_waves = slg::u4_launch_blocks(kregs_for(b->k), (score_kind & 1) ? 8 : 4, score_kind >= 8, b->n_slices, ix->n_cu,
+                                        ix->tune.score_waves_per_simd) *
                   (uint32_t)slg::kU4WavesPerBlock;
-      pp.work_ctr = b->d_work_ctr.as<uint32_t>();
+      pp.work_ctr = persistent ? b->d_work_ctr.as<uint32_t>() : nullptr;
       pp.n_waves = n_waves;
       const uint64_t pthreads = std::max<uint64_t>(
           std::max<uint64_t>((uint64_t)pp.n_boundaries << pp.tpb_shift, (uint64_t)b->nq + 1), b->n_slices);
@@ -1622,6 +1630,8 @@ void slg_batch_destroy(slg_batch *b) {
     }
   }
   (void)hipStreamSynchronize(st);
+  for (hipEvent_t e : b->ev_shard)
+    if (e) (void)hipEventDestroy(e);
   delete b;
   if (prev >= 0) (void)hipSetDevice(prev);
 }
@@ -1765,6 +1775,19 @@ struct slg_shard_group {
   int rank = 0, world = 1;
   uint32_t segs_per_rank = 1;
   void *comm = nullptr;  // ncclComm_t
+  // Collectives on one communicator must be issued in the same order on every rank.  The group owns
+  // the stream they run on and hands out turns: sharded run number `seq` issues its all-gather when
+  // the runs 0 .. seq-1 have issued theirs, whatever host thread or batch stream it comes from (the
+  // batch's stream and the collective stream are tied together with events).
+  hipStream_t coll_stream = nullptr;
+  std::mutex mu;
+  std::condition_variable cv;
+  uint64_t next_seq = 0;   // the run whose collective may be issued next
+  uint64_t auto_seq = 0;   // tickets of slg_batch_run_sharded (call order)
+  // device time of the sharded runs fetched so far (slg_index profiling on): local kernels, all-gather
+  // (incl. waiting for the slowest rank), merge; ms sums and the number of runs
+  double ms_kernels = 0.0, ms_gather = 0.0, ms_merge = 0.0;
+  uint64_t n_timed = 0;
 };
 
 int slg_shard_unique_id(void *out, size_t out_bytes) {
@@ -1792,6 +1815,7 @@ slg_shard_group *slg_shard_group_create(slg_index *ix, int rank, int world, cons
     g->world = world;
     g->segs_per_rank = segs_per_rank;
     nccl_check(rccl().init_rank(&g->comm, world, id, rank), "ncclCommInitRank");
+    SLG_HIP(hipStreamCreateWithFlags(&g->coll_stream, hipStreamNonBlocking));
   });
   if (rc != SLG_OK) {
     const std::string keep = g_last_error;
@@ -1814,34 +1838,72 @@ void slg_shard_group_destroy(slg_shard_group *g) {
       (void)rccl().destroy(g->comm);
     } catch (...) {
     }
+    if (g->coll_stream) (void)hipStreamDestroy(g->coll_stream);
     if (prev >= 0) (void)hipSetDevice(prev);
   }
   delete g;
 }
 
-int slg_batch_run_sharded(slg_batch *b, slg_shard_group *g, uint32_t *out_doc, uint32_t *out_seg,
-                          float *out_score, uint32_t *out_count) {
+namespace {
+int run_sharded_impl(slg_batch *b, slg_shard_group *g, bool have_seq, uint64_t seq, uint32_t *out_doc,
+                     uint32_t *out_seg, float *out_score, uint32_t *out_count) {
   int rc = guarded([&] {
     SLG_REQUIRE_LIVE(b);
     SLG_REQUIRE(g != nullptr && g->idx == b->idx, "shard group is NULL or belongs to another index");
     SLG_REQUIRE(g->segs_per_rank >= b->snap->segs.size(), "the shard grew beyond the group's segs_per_rank");
   });
   if (rc != SLG_OK) return rc;
-  rc = slg_batch_run(b);  // this rank's segments: partition + score + merge, on the batch's stream
-  if (rc != SLG_OK) return rc;
+  if (!have_seq) {  // call order = the order on every rank, if one thread issues the runs
+    std::lock_guard<std::mutex> lk(g->mu);
+    seq = g->auto_seq++;
+  }
+  slg_index *ix = b->idx;
+  const bool timed = ix->profile;
   rc = guarded([&] {
-    slg_index *ix = b->idx;
+    DeviceGuard dg(ix->device);
+    for (int i = 0; i < 4; i++)
+      if (!b->ev_shard[i]) SLG_HIP(hipEventCreateWithFlags(&b->ev_shard[i], timed ? hipEventDefault : hipEventDisableTiming));
+    if (timed) {
+      std::lock_guard<std::mutex> lk(ix->mu);
+      SLG_HIP(hipEventRecord(b->ev_shard[0], batch_stream(b)));
+    }
+  });
+  if (rc == SLG_OK) rc = slg_batch_run(b);  // this rank's segments: partition + score + merge, on the batch's stream
+  // From here on the turn MUST be passed on, error or not: the runs behind this one wait for it.
+  int rc2 = guarded([&] {
     const size_t n = (size_t)b->nq * b->k, blk = 3 * n + b->nq;  // words of one rank's block
-    if (b->nq == 0) return;
+    DeviceGuard dg(ix->device);
     hipStream_t st;
     {
       std::lock_guard<std::mutex> lk(ix->mu);
-      DeviceGuard dg(ix->device);
       st = batch_stream(b);
-      if (!b->d_gather.p) b->d_gather.alloc_pooled(&ix->pool, (size_t)g->world * blk * 4);
-      if (!b->d_merged.p) b->d_merged.alloc_pooled(&ix->pool, blk * 4);
-      // ONE collective: every rank's contiguous block, in rank order
-      nccl_check(rccl().allgather(b->d_out.p, b->d_gather.p, blk, kNcclInt32, g->comm, st), "ncclAllGather");
+      if (rc == SLG_OK && b->nq) {
+        if (!b->d_gather.p) b->d_gather.alloc_pooled(&ix->pool, (size_t)g->world * blk * 4);
+        if (!b->d_merged.p) b->d_merged.alloc_pooled(&ix->pool, blk * 4);
+        SLG_HIP(hipEventRecord(b->ev_shard[1], st));  // the local result block is complete
+      }
+    }
+    {
+      // my turn: ONE collective, every rank's contiguous block in rank order, on the group's stream
+      std::unique_lock<std::mutex> lk(g->mu);
+      g->cv.wait(lk, [&] { return g->next_seq == seq; });
+      struct PassOn {
+        slg_shard_group *g;
+        std::unique_lock<std::mutex> &lk;
+        ~PassOn() {
+          g->next_seq++;
+          lk.unlock();
+          g->cv.notify_all();
+        }
+      } pass{g, lk};
+      if (rc != SLG_OK || b->nq == 0) return;
+      SLG_HIP(hipStreamWaitEvent(g->coll_stream, b->ev_shard[1], 0));
+      nccl_check(rccl().allgather(b->d_out.p, b->d_gather.p, blk, kNcclInt32, g->comm, g->coll_stream), "ncclAllGather");
+      SLG_HIP(hipEventRecord(b->ev_shard[2], g->coll_stream));
+    }
+    {
+      std::lock_guard<std::mutex> lk(ix->mu);
+      SLG_HIP(hipStreamWaitEvent(st, b->ev_shard[2], 0));
       uint32_t *m = b->d_merged.as<uint32_t>();
       const uint32_t *gb = b->d_gather.as<uint32_t>();
       if (b->k == 0) {
@@ -1864,11 +1926,50 @@ int slg_batch_run_sharded(slg_batch *b, slg_shard_group *g, uint32_t *out_doc, u
         mp.cnt_stride = blk;
         launch_shard_merge(mp, st);
       }
+      if (timed) SLG_HIP(hipEventRecord(b->ev_shard[3], st));
+      b->shard_group = g;
+      b->shard_timed = timed;
     }
   });
+  if (rc == SLG_OK) rc = rc2;
   // merged top-k to the caller's host arrays (else: slg_batch_fetch_sharded / _device_results later)
   if (rc == SLG_OK && out_count) rc = slg_batch_fetch_sharded(b, out_doc, out_seg, out_score, out_count);
   return rc;
+}
+}  // namespace
+
+int slg_batch_run_sharded(slg_batch *b, slg_shard_group *g, uint32_t *out_doc, uint32_t *out_seg,
+                          float *out_score, uint32_t *out_count) {
+  return run_sharded_impl(b, g, false, 0, out_doc, out_seg, out_score, out_count);
+}
+
+int slg_batch_run_sharded_seq(slg_batch *b, slg_shard_group *g, uint64_t seq, uint32_t *out_doc, uint32_t *out_seg,
+                              float *out_score, uint32_t *out_count) {
+  return run_sharded_impl(b, g, true, seq, out_doc, out_seg, out_score, out_count);
+}
+
+int slg_shard_group_skip_seq(slg_shard_group *g, uint64_t seq) {
+  return guarded([&] {
+    SLG_REQUIRE(g != nullptr, "shard group is NULL");
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->cv.wait(lk, [&] { return g->next_seq == seq; });
+    g->next_seq++;
+    lk.unlock();
+    g->cv.notify_all();
+  });
+}
+
+int slg_shard_group_stats(slg_shard_group *g, double *ms_kernels, double *ms_gather, double *ms_merge, uint64_t *n_runs) {
+  return guarded([&] {
+    SLG_REQUIRE(g != nullptr, "shard group is NULL");
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (ms_kernels) *ms_kernels = g->ms_kernels;
+    if (ms_gather) *ms_gather = g->ms_gather;
+    if (ms_merge) *ms_merge = g->ms_merge;
+    if (n_runs) *n_runs = g->n_timed;
+    g->ms_kernels = g->ms_gather = g->ms_merge = 0.0;
+    g->n_timed = 0;
+  });
 }
 
 int slg_batch_fetch_sharded(slg_batch *b, uint32_t *out_doc, uint32_t *out_seg, float *out_score,
@@ -1890,6 +1991,19 @@ int slg_batch_fetch_sharded(slg_batch *b, uint32_t *out_doc, uint32_t *out_seg, 
     std::vector<uint32_t> h(blk);
     SLG_HIP(hipMemcpyAsync(h.data(), b->d_merged.p, blk * 4, hipMemcpyDeviceToHost, st));
     SLG_HIP(hipStreamSynchronize(st));
+    if (b->shard_timed && b->shard_group) {  // device time of this run's three phases
+      float k_ms = 0.0f, g_ms = 0.0f, m_ms = 0.0f;
+      if (hipEventElapsedTime(&k_ms, b->ev_shard[0], b->ev_shard[1]) == hipSuccess &&
+          hipEventElapsedTime(&g_ms, b->ev_shard[1], b->ev_shard[2]) == hipSuccess &&
+          hipEventElapsedTime(&m_ms, b->ev_shard[2], b->ev_shard[3]) == hipSuccess) {
+        std::lock_guard<std::mutex> lk(b->shard_group->mu);
+        b->shard_group->ms_kernels += k_ms;
+        b->shard_group->ms_gather += g_ms;
+        b->shard_group->ms_merge += m_ms;
+        b->shard_group->n_timed++;
+      }
+      b->shard_timed = false;
+    }
     if (n) {
       std::memcpy(out_doc, h.data(), n * 4);
       std::memcpy(out_seg, h.data() + n, n * 4);

@@ -48,9 +48,13 @@ struct CoBatch {
   std::atomic<uint32_t> leaving{0};     // callers that have copied their result out
   std::vector<uint32_t> slot_ids, slot_nt;
   std::vector<float> slot_w;
-  std::atomic<bool> want_stats{false};
+  // per-row score plan and doc filter (slg_coalescer_search_plan); plain rows: leaf i = term i, Sum, no filter
+  std::vector<uint32_t> slot_leaf, slot_nleaves;
+  std::vector<int32_t> slot_plan, slot_filter;
+  std::vector<float> slot_tie;
+  std::atomic<bool> want_stats{false}, any_plan{false}, any_filter{false};
   // the closed batch as CSR (built by the leader), and its results
-  std::vector<uint32_t> offs, term_ids;
+  std::vector<uint32_t> offs, term_ids, leaves;
   std::vector<float> weights;
   std::vector<uint32_t> doc, seg, count;
   std::vector<float> score;
@@ -122,11 +126,14 @@ void run_batch(slg_coalescer *c, CoBatch &b) {
   for (uint32_t q = 0; q < nq; q++) b.offs[q + 1] = b.offs[q] + b.slot_nt[q];
   b.term_ids.resize((size_t)b.offs[nq] * ns);
   b.weights.resize(b.offs[nq]);
+  const bool plans = b.any_plan.load(), filters = b.any_filter.load();
+  if (plans) b.leaves.resize(b.offs[nq]);
   for (uint32_t q = 0; q < nq; q++) {
     const uint32_t nt = b.slot_nt[q];
     if (!nt) continue;
     std::memcpy(b.term_ids.data() + (size_t)b.offs[q] * ns, b.slot_ids.data() + (size_t)q * b.slot_terms, (size_t)nt * ns * 4);
     std::memcpy(b.weights.data() + b.offs[q], b.slot_w.data() + (size_t)q * SLG_MAX_QUERY_TERMS, (size_t)nt * 4);
+    if (plans) std::memcpy(b.leaves.data() + b.offs[q], b.slot_leaf.data() + (size_t)q * SLG_MAX_QUERY_TERMS, (size_t)nt * 4);
   }
   const size_t n = (size_t)nq * b.k;
   b.doc.resize(n ? n : 1);
@@ -136,7 +143,10 @@ void run_batch(slg_coalescer *c, CoBatch &b) {
   const bool want_stats = b.want_stats.load();
   if (want_stats) b.stats.assign(nq, slg_stats{});
   void *stream = take_stream(c);
-  slg_batch *sb = slg_batch_prepare(c->index, nq, b.offs.data(), b.term_ids.data(), b.weights.data(), b.k, b.strategy);
+  slg_batch *sb = slg_batch_prepare_plan(c->index, nq, b.offs.data(), b.term_ids.data(), b.weights.data(),
+                                         plans ? b.leaves.data() : nullptr, plans ? b.slot_plan.data() : nullptr,
+                                         plans ? b.slot_tie.data() : nullptr, plans ? b.slot_nleaves.data() : nullptr,
+                                         filters ? b.slot_filter.data() : nullptr, b.k, b.strategy);
   int rc = sb ? SLG_OK : slg_last_error_code();
   if (sb && stream) rc = slg_batch_set_stream(sb, stream);
   if (sb && rc == SLG_OK) rc = slg_batch_run(sb);
@@ -190,6 +200,13 @@ int slg_coalescer_stats(const slg_coalescer *c, uint64_t *n_batches, uint64_t *n
 
 int slg_coalescer_search(slg_coalescer *c, const slg_query *query, uint32_t k, int strategy, uint32_t *out_doc,
                          uint32_t *out_seg, float *out_score, uint32_t *out_count, slg_stats *stats_or_null) {
+  return slg_coalescer_search_plan(c, query, nullptr, SLG_PLAN_SUM, 0.0f, 0, -1, k, strategy, out_doc, out_seg,
+                                   out_score, out_count, stats_or_null);
+}
+
+int slg_coalescer_search_plan(slg_coalescer *c, const slg_query *query, const uint32_t *leaf, int plan, float tie,
+                              uint32_t n_leaves, int32_t filter_id, uint32_t k, int strategy, uint32_t *out_doc,
+                              uint32_t *out_seg, float *out_score, uint32_t *out_count, slg_stats *stats_or_null) {
   g_co_error.clear();
   if (!c || !query || !out_count || (k && (!out_doc || !out_seg || !out_score)) ||
       (query->n_terms && (!query->term_ids || !query->weights))) {
@@ -239,7 +256,14 @@ int slg_coalescer_search(slg_coalescer *c, const slg_query *query, uint32_t k, i
         b->slot_ids.resize((size_t)c->max_batch * b->slot_terms);
         b->slot_w.resize((size_t)c->max_batch * SLG_MAX_QUERY_TERMS);
         b->slot_nt.resize(c->max_batch);
+        b->slot_leaf.resize((size_t)c->max_batch * SLG_MAX_QUERY_TERMS);
+        b->slot_nleaves.resize(c->max_batch);
+        b->slot_plan.resize(c->max_batch);
+        b->slot_filter.resize(c->max_batch);
+        b->slot_tie.resize(c->max_batch);
       }
+      b->any_plan.store(false);
+      b->any_filter.store(false);
       c->open.push_back(b);
       leader = true;
     }
@@ -256,6 +280,20 @@ int slg_coalescer_search(slg_coalescer *c, const slg_query *query, uint32_t k, i
     std::memcpy(b->slot_ids.data() + (size_t)row * b->slot_terms, query->term_ids, (size_t)query->n_terms * n_segs * 4);
     std::memcpy(b->slot_w.data() + (size_t)row * SLG_MAX_QUERY_TERMS, query->weights, (size_t)query->n_terms * 4);
   }
+  // (every row carries its plan: a batch may mix plain rows with planned ones)
+  const bool planned = leaf != nullptr || plan != SLG_PLAN_SUM || n_leaves != 0;
+  for (uint32_t i = 0; i < query->n_terms; i++) b->slot_leaf[(size_t)row * SLG_MAX_QUERY_TERMS + i] = leaf ? leaf[i] : i;
+  b->slot_plan[row] = plan;
+  b->slot_tie[row] = tie;
+  b->slot_nleaves[row] = n_leaves ? n_leaves : (leaf ? 0u : query->n_terms);
+  if (leaf && !n_leaves) {  // 1 + the largest leaf named
+    uint32_t mx = 0;
+    for (uint32_t i = 0; i < query->n_terms; i++) mx = leaf[i] + 1u > mx ? leaf[i] + 1u : mx;
+    b->slot_nleaves[row] = mx;
+  }
+  b->slot_filter[row] = filter_id;
+  if (planned) b->any_plan.store(true);
+  if (filter_id >= 0) b->any_filter.store(true);
   if (stats_or_null) b->want_stats.store(true);
   b->ready.fetch_add(1, std::memory_order_release);
   if (filled && !leader) {  // the row that filled the batch wakes its leader

@@ -124,11 +124,11 @@ struct QueryRef {
 // 195 us for 12 288 tickets; 8 counters 1.8 ns per ticket, 64 counters 0.43 ns) — config 2's 13.4K
 // slices would take longer to hand out than to score.  So the launch order is dealt round-robin over
 // kWorkQueues queues (position p: queue p % kWorkQueues, index p / kWorkQueues — every queue gets the
-// same mix of long and short slices), each with its own counter on its own 256-byte line; wave w starts
-// with position w, pulls from queue w % kWorkQueues, and when that is empty looks at all counters at
-// once (one coherent load, lane l = queue l) and moves to a queue that still has work.
+// same mix of long and short slices), each with its own counter on its own 256-byte line; wave w pulls
+// from queue w % kWorkQueues and, when that has run dry, tries kWorkSteals other queues before it exits.
 constexpr uint32_t kWorkQueues = 64;
 constexpr uint32_t kWorkCtrStride = 64;  // words between two counters (256 bytes)
+constexpr uint32_t kWorkSteals = 2;      // other queues a wave tries when its own has run dry
 
 // ---- planning constants (the kernels that consume them: slg_score*.hpp) ------------------------
 constexpr int kMaxRoundsPerSlice = 16;  // and (rounds+1)*T <= 64: cut points live in one VGPR

@@ -67,8 +67,9 @@ constexpr int u4_waves(int kregs, int ml, bool plan = false) {
 constexpr int kU4WavesPerBlock = SLG_U4_WPB;
 // persistent launch: workgroups to start so that every wave slot the kernel can occupy holds one wave
 // (n_cu compute units x 4 SIMDs x u4_waves), or one wave per slice if the batch has fewer
-inline uint32_t u4_launch_blocks(int kregs, int ml, bool plan, uint32_t n_slices, uint32_t n_cu) {
-  const uint32_t slots = n_cu * 4u * (uint32_t)u4_waves(kregs, ml, plan);
+inline uint32_t u4_launch_blocks(int kregs, int ml, bool plan, uint32_t n_slices, uint32_t n_cu, uint32_t waves_per_simd = 0) {
+  const uint32_t fit = (uint32_t)u4_waves(kregs, ml, plan);
+  const uint32_t slots = n_cu * 4u * (waves_per_simd != 0u && waves_per_simd < fit ? waves_per_simd : fit);
   const uint32_t waves = n_slices < slots ? n_slices : slots;
   return (waves + (uint32_t)kU4WavesPerBlock - 1u) / (uint32_t)kU4WavesPerBlock;
 }
@@ -76,6 +77,20 @@ inline uint32_t u4_launch_blocks(int kregs, int ml, bool plan, uint32_t n_slices
 // 16-byte loads at 4-byte alignment (a lane's 8 postings start at any posting)
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef u32x4_t U4x4 __attribute__((aligned(4)));
+
+// *src read through the constant address space (scalar loads when the address is wave-uniform): for
+// data written before the kernel starts and never during it
+template <typename T>
+__device__ __forceinline__ T load_const(const T *src) {
+  static_assert(sizeof(T) % 4 == 0, "whole words");
+  typedef const __attribute__((address_space(4))) uint32_t *c_u32_t;
+  const c_u32_t w = (c_u32_t)(uintptr_t)src;
+  T out;
+  uint32_t *dst = reinterpret_cast<uint32_t *>(&out);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; i++) dst[i] = w[i];
+  return out;
+}
 
 // PLAN: the batch has score plans (query/planner.rs:113-153, flat: Sum or DisMax over leaves that sum
 // one or more terms each): the lists arrive sorted by leaf and the join closes a doc's leaves in leaf
@@ -101,18 +116,27 @@ score_uniform4_kernel(RoundScoreParams p_arg) {
   // LDS region
   const uint32_t wave_in_wg = kU4WavesPerBlock > 1 ? rfl(threadIdx.x >> 6) : 0u;  // (uniform: a scalar register)
   unsigned char *const smem = smem_wg + wave_in_wg * (uint32_t)u4_wave_lds(KREGS, ML, FW);
-  // PERSISTENT WAVES: the launch holds one wave per wave slot of the device (or fewer, if the batch
-  // has fewer slices) and every wave pulls launch positions from the batch's work queues until they
-  // are empty — the longest slices first, as before (slice_desc is in launch order).  A wave slot and
-  // its LDS are allocated once per launch instead of once per slice: no workgroup dispatch between a
-  // wave's slices, no holes in the LDS allocator when slices of different lengths finish out of
-  // order.  Queues: slg_desc.hpp (kWorkQueues).  Every wave reaches the exit: the grid always drains.
+  // Two launch forms (RoundScoreParams::work_ctr):
+  //  * one wave per slice (work_ctr == nullptr; the default): wave w of the grid runs launch position w,
+  //    the longest slices first; the hardware dispatcher is the work queue.
+  //  * PERSISTENT WAVES (slg_tuning.score_waves_per_simd): the launch holds that many waves per SIMD and
+  //    every wave pulls launch positions from the batch's work queues (slg_desc.hpp: kWorkQueues) until
+  //    they are empty.  Built because the slice timelines show the wave slots only 63 % / 72 % occupied
+  //    (configs 2 / 3) and measured: it does not pay on MI355X.  One counter hands out a ticket every
+  //    ~11-16 ns (config 2: 0.198 ms); 64 counters with an all-counter scan at the end 0.109 ms (every
+  //    wave reads every counter: same-address reads are served one at a time too); 64 counters with
+  //    bounded stealing 0.0846 ms at 6 waves per SIMD, 0.0876 at 5, 0.0945 at 4 — against 0.0776 ms for
+  //    the dispatcher on the same box; config 3: 5.23 against 5.06 ms.  Instruction counts and HBM
+  //    fetch are identical (profiles/r04_persistent_waves.txt): what the dispatcher does for free — a
+  //    new wave the moment a slot and its LDS are free, no ticket latency in the slice's start-up chain,
+  //    no end-game — costs more as software than the occupancy it recovers.
+  //    Every wave reaches the exit: the grid always drains.
   const uint32_t wave_id = blockIdx.x * (uint32_t)kU4WavesPerBlock + wave_in_wg;
   uint32_t wq = wave_id % kWorkQueues;  // the queue this wave pulls from
-  // (EVERY slice is pulled, the first one too: a wave whose workgroup is not resident when the launch
-  //  starts — the device may hold a few waves fewer than the grid — must not own a slice that then
-  //  waits for a wave slot until the other waves have drained the queues)
-  for (uint32_t widx = 0;;) {
+  // (in the persistent form EVERY slice is pulled, the first one too: a wave whose workgroup is not
+  //  resident when the launch starts must not own a slice that then waits for a wave slot until the
+  //  other waves have drained the queues)
+  for (uint32_t widx = wave_id, done_slices = 0;; done_slices++) {
   // (per slice, the launch parameters are read again from the kernel-argument segment: what a slice
   //  derives from them then lives in registers for that slice only, instead of being hoisted out of
   //  this loop and held — spilled — across it)
@@ -121,26 +145,33 @@ score_uniform4_kernel(RoundScoreParams p_arg) {
   asm volatile("" : "+s"(pk));
   const __attribute__((address_space(4))) RoundScoreParams &p = *pk;
   const uint32_t lane = threadIdx.x & 63;
+  if (p.work_ctr == nullptr) {
+    if (done_slices != 0u) break;  // one wave per slice
+  } else
   {
+    // A queue that has run dry is left for another one at most kWorkSteals times, then the wave exits.
+    // (Looking at ALL counters to find the queues that still hold work was measured and is a trap: at
+    //  the end of the launch every wave reads every counter, 6144 reads of each of the 64 lines, and
+    //  reads of one address are served one at a time like the atomics — the tail grew by ~30 us.)
     const uint32_t n_sl = p.n_slices;
-    for (;;) {
+    for (uint32_t tries = 0;; tries++) {
       uint32_t c = 0;
       if (lane == 0) c = atomicAdd(p.work_ctr + wq * kWorkCtrStride, 1u);
       widx = wq + kWorkQueues * rfl(c);
-      if (widx < n_sl) break;
-      // this queue is empty: the state of all queues in one coherent load (lane l: queue l)
-      const uint32_t seen = __hip_atomic_load(p.work_ctr + lane * kWorkCtrStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint64_t open = __ballot(lane < kWorkQueues && (uint64_t)lane + (uint64_t)kWorkQueues * seen < n_sl);
-      if (open == 0ull) break;
-      // the (wave_id mod open queues)-th open queue: the waves that run dry spread over them
-      uint32_t pick = wave_id % (uint32_t)__popcll(open);
-      uint64_t m = open;
-      while (pick--) m &= m - 1ull;
-      wq = (uint32_t)__builtin_ctzll(m);
+      if (widx < n_sl || tries >= kWorkSteals) break;
+      wq = (wq + 21u) % kWorkQueues;
     }
   }
   if (widx >= p.n_slices) break;
-  const SliceDesc sl = p.slice_desc[widx];
+  // The slice record, the segment descriptor and the reject-table row are written before this kernel
+  // starts and never during it: they are read through the CONSTANT address space, i.e. by scalar
+  // loads (a few hundred cycles from the scalar cache).  Inside this loop the compiler cannot prove
+  // that for a plain global pointer — earlier slices stored to global memory — and would use vector
+  // loads, which put two more HBM-latency steps into every slice's dependent start-up chain
+  // (record -> segment -> term references -> cut-point searches -> first round): measured on config
+  // 2, whose slices are 4 rounds long, 0.111 ms against 0.078 ms for the one-wave-per-slice launch.
+  typedef const __attribute__((address_space(4))) uint64_t *c_u64_t;
+  const SliceDesc sl = load_const(p.slice_desc + widx);
   const uint32_t slice = rfl(sl.slice);
 
   constexpr bool BUF = uni_buffered(KREGS);
@@ -157,7 +188,7 @@ score_uniform4_kernel(RoundScoreParams p_arg) {
   //  global memory — so they are vector loads: everything wave-uniform is moved to scalar registers by hand)
   auto uni64 = [](const uint64_t v) { return ((uint64_t)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v); };
   const uint32_t seg_id = rfl(sl.seg);
-  const SegDev sd_v = p.segs[seg_id];
+  const SegDev sd_v = load_const(p.segs + seg_id);
   const gu32_t gdocs = (gu32_t)uni64((uint64_t)sd_v.docs);
   const gf32_t gimps = (gf32_t)uni64((uint64_t)sd_v.imps);
   const uint32_t seg_n_docs = rfl(sd_v.n_docs);
@@ -166,7 +197,8 @@ score_uniform4_kernel(RoundScoreParams p_arg) {
   const gf32_t limps = gimps + 8u * lane;
   const uint64_t null_idx = uni64(sd_v.null_idx);
   const uint32_t fid = rfl(sl.filter);
-  const gu32_t gdel = (gu32_t)uni64((uint64_t)(fid ? p.reject_table[(size_t)(fid - 1) * p.n_segs + seg_id] : sd_v.deleted));
+  const gu32_t gdel = (gu32_t)uni64(fid ? ((c_u64_t)(uintptr_t)p.reject_table)[(size_t)(fid - 1) * p.n_segs + seg_id]
+                                        : (uint64_t)sd_v.deleted);
   const uint32_t k = p.k;
 
   // lane t < T: list t's weight and posting offset; all cut points of the slice (entry r*T + t:

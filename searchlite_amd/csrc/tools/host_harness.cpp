@@ -41,6 +41,9 @@ struct Worker {
 
 struct Harness {
   slg_index *ix = nullptr;
+  // index-sharded mode (config 4): every batch runs slg_batch_run_sharded_seq(seq = step number) and is
+  // collected with slg_batch_fetch_sharded; the step numbers of all slh_run calls must then be 0, 1, 2, ...
+  slg_shard_group *group = nullptr;
   int device = 0;
   uint32_t nq = 0, k = 0;
   int strategy = 0;
@@ -67,7 +70,8 @@ void collect(Harness *h, Pending &p, std::vector<uint32_t> &doc, std::vector<uin
              std::vector<float> &score, std::vector<uint32_t> &count) {
   if (!p.b) return;
   const auto t0 = std::chrono::steady_clock::now();
-  const int rc = slg_batch_fetch(p.b, doc.data(), seg.data(), score.data(), count.data(), nullptr);
+  const int rc = h->group ? slg_batch_fetch_sharded(p.b, doc.data(), seg.data(), score.data(), count.data())
+                          : slg_batch_fetch(p.b, doc.data(), seg.data(), score.data(), count.data(), nullptr);
   slg_batch_destroy(p.b);
   h->ns_fetch += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
   const size_t set = (size_t)(p.step % (int64_t)h->sets.size());
@@ -116,7 +120,9 @@ void worker_main(Harness *h, Worker *w) {
     const auto t1 = std::chrono::steady_clock::now();
     int rc = b ? SLG_OK : slg_last_error_code();
     if (b) rc = slg_batch_set_stream(b, (void *)w->streams[lap++ & 1u]);
-    if (b && rc == SLG_OK) rc = slg_batch_run(b);
+    if (b && rc == SLG_OK)
+      rc = h->group ? slg_batch_run_sharded_seq(b, h->group, (uint64_t)step, nullptr, nullptr, nullptr, nullptr)
+                    : slg_batch_run(b);
     const auto t2 = std::chrono::steady_clock::now();
     h->ns_prepare += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
     h->ns_run += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count();
@@ -125,6 +131,7 @@ void worker_main(Harness *h, Worker *w) {
       std::lock_guard<std::mutex> lk(h->done_mu);
       if (h->error.empty()) h->error = std::string("prepare/run: ") + slg_last_error();
     }
+    if (!b && h->group) (void)slg_shard_group_skip_seq(h->group, (uint64_t)step);  // (no batch: the turn still moves on)
     collect(h, prev, doc, seg, score, count);  // the batch launched one lap ago
     if (b && rc == SLG_OK) {
       prev.b = b;
@@ -167,6 +174,13 @@ void *slh_create(slg_index *ix, int device, int n_threads, int n_sets, const uin
   for (auto *w : h->workers) w->th = std::thread(worker_main, h, w);
   return h;
 }
+
+// index-sharded mode: the shard group every batch runs in (NULL: back to plain runs).  Call it before
+// the first slh_run; from then on the step numbers must be 0, 1, 2, ... on every rank.
+void slh_set_group(void *hp, slg_shard_group *group) { static_cast<Harness *>(hp)->group = group; }
+
+// the most recent result of a worker thread is not kept; for parity checks bench.py reads the FIRST
+// result of every query set (slh_first_result)
 
 // Runs steps [first, first + n_steps), round-robin over the threads, and returns when every one of
 // them has been fetched.  0 on success, -1 on error (slh_error).

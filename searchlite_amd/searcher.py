@@ -415,6 +415,14 @@ class ShardGroup:
         if not self._h:
             raise N.SlgError(N.last_error_code() or N.ERR_INVALID, N.last_error())
 
+    def stats(self) -> dict:
+        """slg_shard_group_stats (with GpuIndex.profile(True)): mean device ms per sharded run fetched
+        since the last call — this rank's kernels, the all-gather, the merge."""
+        a, b, c, n = C.c_double(), C.c_double(), C.c_double(), C.c_uint64()
+        N.check(self._lib.slg_shard_group_stats(self._h, C.addressof(a), C.addressof(b), C.addressof(c), C.addressof(n)))
+        d = max(1, n.value)
+        return {"runs": int(n.value), "kernel_ms": a.value / d, "gather_ms": b.value / d, "merge_ms": c.value / d}
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             self._lib.slg_shard_group_destroy(self._h)
@@ -482,12 +490,16 @@ class PreparedBatch:
     def run(self) -> None:
         N.check(self._lib.slg_batch_run(self._h))
 
-    def run_sharded(self, group: "ShardGroup", fetch: bool = True):
+    def run_sharded(self, group: "ShardGroup", fetch: bool = True, seq: Optional[int] = None):
         """slg_batch_run_sharded: this rank's segments, ONE ncclAllGather of the result blocks,
         device merge.  fetch=True -> merged (doc, seg, score, count) host arrays (waits);
-        fetch=False -> None, the merged block stays on the device (sharded_device_results)."""
+        fetch=False -> None, the merged block stays on the device (sharded_device_results).
+        seq: slg_batch_run_sharded_seq — the run's number in the group's order of collectives."""
         if not fetch:
-            N.check(self._lib.slg_batch_run_sharded(self._h, group._h, None, None, None, None))
+            if seq is None:
+                N.check(self._lib.slg_batch_run_sharded(self._h, group._h, None, None, None, None))
+            else:
+                N.check(self._lib.slg_batch_run_sharded_seq(self._h, group._h, int(seq), None, None, None, None))
             return None
         nq, k = self.nq, self.k
         out_doc = np.zeros((nq, k), dtype=np.uint32)
