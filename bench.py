@@ -449,7 +449,7 @@ def main():
                         "value_is": "median over the regions"}
 
     # ---- leg 2: device-resident pre-planned batches, rotating, `inflight` streams ----
-    inflight = max(1, args.inflight) if not rerank else 1
+    inflight = max(1, args.inflight)
     batches = [index.prepare(*q, k, strategy, q_leaf=None if q_leaves is None else q_leaves[j])
                for j, q in enumerate(qs)]
     infos = [b.info() for b in batches]
@@ -464,11 +464,13 @@ def main():
         cnt_t = [torch.as_tensor(_DevArray(d[3], (nq,), "<i4"), device="cuda") for d in d_res]
         qv = torch.from_numpy(corpus.unit_vectors(nq, args.dim, seed=12)).cuda()
         alpha = torch.full((nq,), 0.5, dtype=torch.float32, device="cuda")
-        r_doc = torch.empty((nq, k_out), dtype=torch.int32, device="cuda")
-        r_seg = torch.empty_like(r_doc)
-        r_score = torch.empty((nq, k_out), dtype=torch.float32, device="cuda")
-        r_vec = torch.empty_like(r_score)
-        r_count = torch.empty((nq,), dtype=torch.int32, device="cuda")
+        # one set of rerank outputs per pipeline in flight (r_* = set 0: the parity check reads it)
+        r_sets = [(torch.empty((nq, k_out), dtype=torch.int32, device="cuda"),
+                   torch.empty((nq, k_out), dtype=torch.int32, device="cuda"),
+                   torch.empty((nq, k_out), dtype=torch.float32, device="cuda"),
+                   torch.empty((nq, k_out), dtype=torch.float32, device="cuda"),
+                   torch.empty((nq,), dtype=torch.int32, device="cuda")) for _ in range(inflight)]
+        r_doc, r_seg, r_score, r_vec, r_count = r_sets[0]
         ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
         ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     turn = [0]
@@ -478,15 +480,15 @@ def main():
         turn[0] += 1
         b = batches[j]
         b.run()
-        if rerank:  # candidates = the BM25 pass's device results (no host round trip)
+        if rerank:  # candidates = the BM25 pass's device results, reranked on the batch's own stream
+            st_j = streams[j % inflight] if inflight > 1 else stream
             if timed_idx is not None:
-                ev_a[timed_idx].record()
-            d = d_res[j]
-            index.rerank_batch_device(nq, qv.data_ptr(), alpha.data_ptr(), d[0], d[1], d[2], d[3], k, k_out,
-                                      r_doc.data_ptr(), r_seg.data_ptr(), r_score.data_ptr(),
-                                      r_vec.data_ptr(), r_count.data_ptr())
+                ev_a[timed_idx].record(st_j)
+            rs = r_sets[j % inflight]
+            b.rerank_device(1, qv.data_ptr(), alpha.data_ptr(), None, k_out, rs[0].data_ptr(), rs[1].data_ptr(),
+                            rs[2].data_ptr(), rs[3].data_ptr(), rs[4].data_ptr())
             if timed_idx is not None:
-                ev_b[timed_idx].record()
+                ev_b[timed_idx].record(st_j)
 
     for _ in range(args.warmup):
         resident_step()
@@ -559,9 +561,9 @@ def main():
                                     if not (rerank or plans) else
                                     "device-resident pre-planned batches with score plans, rotating" if plans else
                                     "device-resident pipeline BM25 top-1000 -> rerank -> top-10 of pre-planned batches"),
-                       "host_threads": None if rerank else n_thr,
+                       "host_threads": None if (rerank or plans) else n_thr,
                        "host_call_ms": host_ms,
-                       "host_warmup_steps": None if (rerank or args.kernel_leg_only) else host_warm,
+                       "host_warmup_steps": None if (rerank or plans or args.kernel_leg_only) else host_warm,
                        "rotating_query_sets": n_sets,
                        # 8 B x postings of the DISTINCT lists the rotating query sets touch (the resident
                        # doc-id + impact streams a pass over all sets reads at least once)
@@ -609,6 +611,7 @@ def main():
             n_mf = max(4, min(args.steps, 16))
             me_a = [torch.cuda.Event(enable_timing=True) for _ in range(n_mf)]
             me_b = [torch.cuda.Event(enable_timing=True) for _ in range(n_mf)]
+            torch.cuda.synchronize()
             for i in range(-2, n_mf):
                 d = d_res[i % n_sets]
                 if i >= 0:
@@ -662,10 +665,8 @@ def main():
         if rerank and nchk:
             # rerank spot check against the oracle (tolerance 1e-5 on blended scores): re-run set 0
             batches[0].run()
-            d = d_res[0]
-            index.rerank_batch_device(nq, qv.data_ptr(), alpha.data_ptr(), d[0], d[1], d[2], d[3], k, k_out,
-                                      r_doc.data_ptr(), r_seg.data_ptr(), r_score.data_ptr(),
-                                      r_vec.data_ptr(), r_count.data_ptr())
+            batches[0].rerank_device(1, qv.data_ptr(), alpha.data_ptr(), None, k_out, r_doc.data_ptr(), r_seg.data_ptr(),
+                                     r_score.data_ptr(), r_vec.data_ptr(), r_count.data_ptr())
             torch.cuda.synchronize()
             got = batches[0].fetch()
             hv = index.segments[0]
@@ -746,7 +747,7 @@ def main():
         Lh.slh_coalesce_bench.restype = C.c_double
         Lh.slh_coalesce_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32,
-                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         offs, terms, w = (np.ascontiguousarray(x) for x in qs[0])
         batches[0].run()
         exp = batches[0].fetch()
@@ -755,17 +756,20 @@ def main():
         legs = []
         for thr, wait_us in ((args.coalesce_threads, 30), (4 * args.coalesce_threads, 30)):
             bad, nb = C.c_int64(0), C.c_uint64(0)
+            ph = (C.c_double * 4)()
             total = 64 * nq
             Lh.slh_coalesce_bench(index._h, local_rank, thr, 8 * nq, offs.ctypes.data, terms.ctypes.data, w.ctypes.data,
-                                  nq, 1, k, strategy, 1024, wait_us, None, None, None, None, None)  # warm-up
+                                  nq, 1, k, strategy, 1024, wait_us, None, None, None, None, None, None)  # warm-up
             secs = Lh.slh_coalesce_bench(index._h, local_rank, thr, total, offs.ctypes.data, terms.ctypes.data,
                                          w.ctypes.data, nq, 1, k, strategy, 1024, wait_us, e_doc.ctypes.data,
-                                         e_score.ctypes.data, e_cnt.ctypes.data, C.addressof(bad), C.addressof(nb))
+                                         e_score.ctypes.data, e_cnt.ctypes.data, C.addressof(bad), C.addressof(nb), ph)
             if secs <= 0:
                 raise SystemExit("bench.py: the coalescer leg failed")
             legs.append({"caller_threads": thr, "max_wait_us": wait_us, "queries": total,
                          "queries_per_s": round(total / secs, 1), "batches": int(nb.value),
                          "mean_batch": round(total / max(1, nb.value), 1),
+                         "leader_ms_per_batch": {"collect": round(ph[0], 3), "prepare": round(ph[1], 3),
+                                                 "run": round(ph[2], 3), "fetch_destroy": round(ph[3], 3)},
                          "rows_differing_from_the_batch_api": int(bad.value)})
             if bad.value:
                 print(json.dumps(legs))

@@ -422,6 +422,10 @@ int slg_coalescer_search_plan(slg_coalescer *coalescer, const slg_query *query, 
                               slg_stats *stats_or_null);
 /* Thread-local text of the last failure of slg_coalescer_search on this thread. */
 const char *slg_coalescer_last_error(void);
+/* Mean time (ms) a batch's leader spent collecting / in slg_batch_prepare / in set_stream + run / in
+ * fetch + destroy, over the batches run so far. */
+int slg_coalescer_phase_ms(const slg_coalescer *coalescer, double *collect, double *prepare, double *run,
+                           double *fetch);
 /* Batches run and queries served so far (their ratio = the mean batch size reached). */
 int slg_coalescer_stats(const slg_coalescer *coalescer, uint64_t *n_batches, uint64_t *n_queries);
 
@@ -520,6 +524,15 @@ int slg_rerank_batch_device(slg_index *index, uint32_t nq, const float *d_qvecs,
                             const uint32_t *d_cand_count, uint32_t max_cand, uint32_t k_out,
                             uint32_t *d_out_doc, uint32_t *d_out_seg, float *d_out_score,
                             float *d_out_vec_score, uint32_t *d_out_count);
+
+/* Rerank a batch's OWN device results (k candidates per query, as slg_batch_run left them) with
+ * n_clauses vector clauses, asynchronously on the batch's stream: BM25 top-k -> rerank chains without a
+ * host round trip and without leaving the batch's stream, so several such pipelines can be in flight
+ * (slg_batch_set_stream).  Arguments as slg_rerank_multi_batch_device; n_clauses == 1 with d_boost ==
+ * NULL takes the single-clause kernel. */
+int slg_batch_rerank_device(slg_batch *batch, uint32_t n_clauses, const float *d_qvecs, const float *d_alpha,
+                            const float *d_boost, uint32_t k_out, uint32_t *d_out_doc, uint32_t *d_out_seg,
+                            float *d_out_score, float *d_out_vec_score, uint32_t *d_out_count);
 
 /*
  * Hybrid rerank with several vector clauses over one candidate set (api/reader.rs:225-254;

@@ -70,6 +70,8 @@ extern "C" {
         plan: c_int, tie: c_float, n_leaves: u32, filter_id: i32, k: u32, strategy: c_int, out_doc: *mut u32,
         out_seg: *mut u32, out_score: *mut c_float, out_count: *mut u32, stats_or_null: *mut slg_stats) -> c_int;
     pub fn slg_coalescer_last_error() -> *const c_char;
+    pub fn slg_coalescer_phase_ms(coalescer: *const slg_coalescer, collect: *mut f64, prepare: *mut f64, run: *mut f64,
+        fetch: *mut f64) -> c_int;
     pub fn slg_coalescer_stats(coalescer: *const slg_coalescer, n_batches: *mut u64, n_queries: *mut u64) -> c_int;
     // index sharding over RCCL (api/reader.rs:2670-2778 across GPUs)
     pub fn slg_shard_unique_id(out: *mut c_void, out_bytes: usize) -> c_int;
@@ -138,6 +140,9 @@ extern "C" {
     pub fn slg_rerank_batch_device(index: *mut slg_index, nq: u32, d_qvecs: *const c_float, d_alpha: *const c_float,
         d_cand_doc: *const u32, d_cand_seg: *const u32, d_cand_bm25: *const c_float, d_cand_count: *const u32,
         max_cand: u32, k_out: u32, d_out_doc: *mut u32, d_out_seg: *mut u32, d_out_score: *mut c_float,
+        d_out_vec_score: *mut c_float, d_out_count: *mut u32) -> c_int;
+    pub fn slg_batch_rerank_device(batch: *mut slg_batch, n_clauses: u32, d_qvecs: *const c_float, d_alpha: *const c_float,
+        d_boost: *const c_float, k_out: u32, d_out_doc: *mut u32, d_out_seg: *mut u32, d_out_score: *mut c_float,
         d_out_vec_score: *mut c_float, d_out_count: *mut u32) -> c_int;
     pub fn slg_index_add_vector_field(index: *mut slg_index, per_segment: *const slg_vector_field_desc, n_segs: u32) -> c_int;
     pub fn slg_rerank_fields_batch(index: *mut slg_index, nq: u32, n_clauses: u32, clause_field: *const u32,

@@ -135,6 +135,7 @@ def load():
         "slg_coalescer_search_plan": (i32, [vp, vp, vp, i32, f32, u32, C.c_int32, u32, i32, vp, vp, vp, vp, vp]),
         "slg_coalescer_last_error": (C.c_char_p, []),
         "slg_coalescer_stats": (i32, [vp, vp, vp]),
+        "slg_coalescer_phase_ms": (i32, [vp, vp, vp, vp, vp]),
         "slg_search_batch": (i32, [vp, vp, u32, u32, i32, vp, vp, vp, vp, vp]),
         "slg_index_add_filter": (i32, [vp, vp]),
         "slg_index_add_filter_range_i64": (i32, [vp, vp, C.c_int64, C.c_int64]),
@@ -174,6 +175,7 @@ def load():
         "slg_rerank_multi_batch_device": (i32, [vp, u32, u32, vp, vp, vp, vp, vp, vp, vp, u32, u32, vp,
                                                 vp, vp, vp, vp]),
         "slg_index_add_vector_field": (i32, [vp, vp, u32]),
+        "slg_batch_rerank_device": (i32, [vp, u32, vp, vp, vp, u32, vp, vp, vp, vp, vp]),
         "slg_rerank_fields_batch": (i32, [vp, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp,
                                           vp, vp]),
         "slg_rerank_fields_batch_device": (i32, [vp, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, vp,

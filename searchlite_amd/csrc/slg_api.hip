@@ -1514,25 +1514,42 @@ int slg_batch_fetch(slg_batch *b, uint32_t *out_doc, uint32_t *out_seg, float *o
     std::vector<uint32_t> scored;
     std::vector<unsigned long long> skipped;
     if (b->nq) {
-      // the results are one contiguous block doc | seg | score | count: one D2H copy
-      std::vector<uint32_t> blk(3 * n + b->nq);
-      SLG_HIP(hipMemcpyAsync(blk.data(), b->d_out.p, blk.size() * 4, hipMemcpyDeviceToHost, st));
-      if (stats) {
-        scored.resize(b->nq);
-        SLG_HIP(hipMemcpyAsync(scored.data(), b->d_q_scored.p, (size_t)b->nq * 4,
-                               hipMemcpyDeviceToHost, st));
-        if (b->d_blk_skip.p && b->launched) {
-          skipped.resize((size_t)b->nq + 1);
-          SLG_HIP(hipMemcpyAsync(skipped.data(), b->d_blk_skip.p, skipped.size() * 8, hipMemcpyDeviceToHost, st));
+      // the results are one contiguous block doc | seg | score | count: one D2H copy, into a PINNED
+      // staging image of the index's pool (a pageable destination makes the runtime stage the copy
+      // itself, chunk by chunk behind a lock that every caller thread's copies share)
+      const size_t words = 3 * n + b->nq;
+      const size_t extra = stats ? (size_t)b->nq + ((b->d_blk_skip.p && b->launched) ? 2 * ((size_t)b->nq + 1) : 0) : 0;
+      struct ImageLease {
+        BufPool *pool;
+        void *p = nullptr;
+        size_t bytes = 0;
+        ~ImageLease() {
+          if (p) pool->give_image(p, bytes);
         }
+      } lease{&ix->pool};
+      lease.p = ix->pool.take_image((words + extra) * 4, &lease.bytes);
+      if (!lease.p) throw SlgError(SLG_ERR_OOM, "pinned staging image: hipHostMalloc failed");
+      uint32_t *blk = static_cast<uint32_t *>(lease.p);
+      SLG_HIP(hipMemcpyAsync(blk, b->d_out.p, words * 4, hipMemcpyDeviceToHost, st));
+      if (stats) {
+        SLG_HIP(hipMemcpyAsync(blk + words, b->d_q_scored.p, (size_t)b->nq * 4, hipMemcpyDeviceToHost, st));
+        if (b->d_blk_skip.p && b->launched)
+          SLG_HIP(hipMemcpyAsync(blk + words + b->nq, b->d_blk_skip.p, ((size_t)b->nq + 1) * 8, hipMemcpyDeviceToHost, st));
       }
       SLG_HIP(hipStreamSynchronize(st));
       if (n) {
-        std::memcpy(out_doc, blk.data(), n * 4);
-        std::memcpy(out_seg, blk.data() + n, n * 4);
-        std::memcpy(out_score, blk.data() + 2 * n, n * 4);
+        std::memcpy(out_doc, blk, n * 4);
+        std::memcpy(out_seg, blk + n, n * 4);
+        std::memcpy(out_score, blk + 2 * n, n * 4);
       }
-      std::memcpy(out_count, blk.data() + 3 * n, (size_t)b->nq * 4);
+      std::memcpy(out_count, blk + 3 * n, (size_t)b->nq * 4);
+      if (stats) {
+        scored.assign(blk + words, blk + words + b->nq);
+        if (b->d_blk_skip.p && b->launched) {
+          skipped.resize((size_t)b->nq + 1);
+          std::memcpy(skipped.data(), blk + words + b->nq, skipped.size() * 8);
+        }
+      }
     }
     if (stats)
       for (uint32_t q = 0; q < b->nq; q++) {
@@ -1988,8 +2005,18 @@ int slg_batch_fetch_sharded(slg_batch *b, uint32_t *out_doc, uint32_t *out_seg, 
       st = batch_stream(b);
     }
     const size_t n = (size_t)b->nq * b->k, blk = 3 * n + b->nq;
-    std::vector<uint32_t> h(blk);
-    SLG_HIP(hipMemcpyAsync(h.data(), b->d_merged.p, blk * 4, hipMemcpyDeviceToHost, st));
+    struct ImageLease {  // pinned staging (see slg_batch_fetch)
+      BufPool *pool;
+      void *p = nullptr;
+      size_t bytes = 0;
+      ~ImageLease() {
+        if (p) pool->give_image(p, bytes);
+      }
+    } lease{&ix->pool};
+    lease.p = ix->pool.take_image(blk * 4, &lease.bytes);
+    if (!lease.p) throw SlgError(SLG_ERR_OOM, "pinned staging image: hipHostMalloc failed");
+    uint32_t *h = static_cast<uint32_t *>(lease.p);
+    SLG_HIP(hipMemcpyAsync(h, b->d_merged.p, blk * 4, hipMemcpyDeviceToHost, st));
     SLG_HIP(hipStreamSynchronize(st));
     if (b->shard_timed && b->shard_group) {  // device time of this run's three phases
       float k_ms = 0.0f, g_ms = 0.0f, m_ms = 0.0f;
@@ -2005,11 +2032,11 @@ int slg_batch_fetch_sharded(slg_batch *b, uint32_t *out_doc, uint32_t *out_seg, 
       b->shard_timed = false;
     }
     if (n) {
-      std::memcpy(out_doc, h.data(), n * 4);
-      std::memcpy(out_seg, h.data() + n, n * 4);
-      std::memcpy(out_score, h.data() + 2 * n, n * 4);
+      std::memcpy(out_doc, h, n * 4);
+      std::memcpy(out_seg, h + n, n * 4);
+      std::memcpy(out_score, h + 2 * n, n * 4);
     }
-    std::memcpy(out_count, h.data() + 3 * n, (size_t)b->nq * 4);
+    std::memcpy(out_count, h + 3 * n, (size_t)b->nq * 4);
   });
 }
 
@@ -2051,6 +2078,14 @@ int slg_profile_read(slg_index *ix, uint32_t *n_launches, float *total_ms) {
     ix->prof_used = 0;
   });
 }
+
+namespace {
+// slg_batch_rerank_device runs the rerank kernels on the batch's stream: the launch sites below take
+// the stream from here when it is set (this thread only, for the duration of that call)
+thread_local bool g_rerank_stream_set = false;
+thread_local hipStream_t g_rerank_stream = nullptr;
+inline hipStream_t rerank_stream(slg_index *ix) { return g_rerank_stream_set ? g_rerank_stream : ix->stream; }
+}  // namespace
 
 int slg_rerank_batch_device(slg_index *ix, uint32_t nq, const float *d_qvecs, const float *d_alpha,
                             const uint32_t *d_cand_doc, const uint32_t *d_cand_seg,
@@ -2095,7 +2130,7 @@ int slg_rerank_batch_device(slg_index *ix, uint32_t nq, const float *d_qvecs, co
     rp.out_vec = d_out_vec_score;
     rp.out_count = d_out_count;
     rp.nq = nq;
-    SLG_HIP(slg::launch_rerank(rp, kregs_for(k_out ? k_out : 1), ix->stream));
+    SLG_HIP(slg::launch_rerank(rp, kregs_for(k_out ? k_out : 1), rerank_stream(ix)));
   });
 }
 
@@ -2157,8 +2192,26 @@ int slg_rerank_multi_batch_device(slg_index *ix, uint32_t nq, uint32_t n_clauses
     mp.boost = d_boost;
     mp.n_clauses = n_clauses;
     mp.q_stride = dim + 4;
-    SLG_HIP(slg::launch_rerank_multi(mp, kregs_for(k_out ? k_out : 1), ix->stream));
+    SLG_HIP(slg::launch_rerank_multi(mp, kregs_for(k_out ? k_out : 1), rerank_stream(ix)));
   });
+}
+
+int slg_batch_rerank_device(slg_batch *b, uint32_t n_clauses, const float *d_qvecs, const float *d_alpha,
+                            const float *d_boost, uint32_t k_out, uint32_t *d_out_doc, uint32_t *d_out_seg,
+                            float *d_out_score, float *d_out_vec_score, uint32_t *d_out_count) {
+  int rc = guarded([&] { SLG_REQUIRE_LIVE(b); });
+  if (rc != SLG_OK) return rc;
+  slg_index *ix = b->idx;
+  {
+    std::lock_guard<std::mutex> lk(ix->mu);
+    g_rerank_stream = batch_stream(b);
+  }
+  g_rerank_stream_set = true;
+  rc = slg_rerank_multi_batch_device(ix, b->nq, n_clauses, d_qvecs, d_alpha, d_boost, b->d_out_doc, b->d_out_seg,
+                                     b->d_out_score, b->d_out_count, b->k, k_out, d_out_doc, d_out_seg, d_out_score,
+                                     d_out_vec_score, d_out_count);
+  g_rerank_stream_set = false;
+  return rc;
 }
 
 int slg_index_add_vector_field(slg_index *ix, const slg_vector_field_desc *per_segment, uint32_t n_segs) {

@@ -80,6 +80,7 @@ struct slg_coalescer {
   std::vector<void *> free_streams;
   // accounting (slg_coalescer_stats)
   std::atomic<uint64_t> n_batches{0}, n_queries{0};
+  std::atomic<uint64_t> ns_collect{0}, ns_prepare{0}, ns_run{0}, ns_fetch{0};  // leaders' time per phase, summed
 };
 
 namespace {
@@ -143,18 +144,26 @@ void run_batch(slg_coalescer *c, CoBatch &b) {
   const bool want_stats = b.want_stats.load();
   if (want_stats) b.stats.assign(nq, slg_stats{});
   void *stream = take_stream(c);
+  const auto t0 = std::chrono::steady_clock::now();
   slg_batch *sb = slg_batch_prepare_plan(c->index, nq, b.offs.data(), b.term_ids.data(), b.weights.data(),
                                          plans ? b.leaves.data() : nullptr, plans ? b.slot_plan.data() : nullptr,
                                          plans ? b.slot_tie.data() : nullptr, plans ? b.slot_nleaves.data() : nullptr,
                                          filters ? b.slot_filter.data() : nullptr, b.k, b.strategy);
+  const auto t1 = std::chrono::steady_clock::now();
   int rc = sb ? SLG_OK : slg_last_error_code();
   if (sb && stream) rc = slg_batch_set_stream(sb, stream);
   if (sb && rc == SLG_OK) rc = slg_batch_run(sb);
+  const auto t2 = std::chrono::steady_clock::now();
   if (sb && rc == SLG_OK)
     rc = slg_batch_fetch(sb, b.doc.data(), b.seg.data(), b.score.data(), b.count.data(),
                          want_stats ? b.stats.data() : nullptr);
   if (rc != SLG_OK) b.error = slg_last_error();
   if (sb) slg_batch_destroy(sb);
+  const auto t3 = std::chrono::steady_clock::now();
+  auto nanos = [](auto a, auto z) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(z - a).count(); };
+  c->ns_prepare += nanos(t0, t1);
+  c->ns_run += nanos(t1, t2);
+  c->ns_fetch += nanos(t2, t3);
   give_stream(c, stream);
   c->in_flight.fetch_sub(1);
   c->n_batches.fetch_add(1);
@@ -190,6 +199,16 @@ void slg_coalescer_destroy(slg_coalescer *c) {
 }
 
 const char *slg_coalescer_last_error(void) { return g_co_error.c_str(); }
+
+int slg_coalescer_phase_ms(const slg_coalescer *c, double *collect, double *prepare, double *run, double *fetch) {
+  if (!c) return SLG_ERR_INVALID;
+  const double n = (double)(c->n_batches.load() ? c->n_batches.load() : 1);
+  if (collect) *collect = (double)c->ns_collect.load() / n * 1e-6;
+  if (prepare) *prepare = (double)c->ns_prepare.load() / n * 1e-6;
+  if (run) *run = (double)c->ns_run.load() / n * 1e-6;
+  if (fetch) *fetch = (double)c->ns_fetch.load() / n * 1e-6;
+  return SLG_OK;
+}
 
 int slg_coalescer_stats(const slg_coalescer *c, uint64_t *n_batches, uint64_t *n_queries) {
   if (!c) return SLG_ERR_INVALID;
@@ -304,6 +323,7 @@ int slg_coalescer_search_plan(slg_coalescer *c, const slg_query *query, const ui
     b->cv.notify_all();
   }
   if (leader) {
+    const auto tc0 = std::chrono::steady_clock::now();
     // collect: until full, or max_wait_us — unless nothing else is in flight (an idle device: waiting
     // would only add latency; under load the batches in flight give the next one time to fill)
     if (!filled && c->max_wait_us != 0 && c->in_flight.load() != 0) {
@@ -318,6 +338,7 @@ int slg_coalescer_search_plan(slg_coalescer *c, const slg_query *query, const ui
       }
       c->in_flight.fetch_add(1);
     }
+    c->ns_collect += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tc0).count();
     run_batch(c, *b);
   } else {
     std::unique_lock<std::mutex> bl(b->mu);

@@ -242,7 +242,7 @@ double slh_coalesce_bench(slg_index *ix, int device, int n_threads, int64_t tota
                           const uint32_t *terms, const float *w, uint32_t nq, uint32_t n_segs, uint32_t k,
                           int strategy, uint32_t max_batch, uint32_t max_wait_us, const uint32_t *exp_doc,
                           const float *exp_score, const uint32_t *exp_count, int64_t *mismatches,
-                          uint64_t *n_batches) {
+                          uint64_t *n_batches, double *phase_ms4) {
   slg_coalescer *co = slg_coalescer_create(ix, max_batch, max_wait_us);
   if (!co) return -1.0;
   std::atomic<int64_t> next{0}, bad{0}, failed{0};
@@ -285,6 +285,7 @@ double slh_coalesce_bench(slg_index *ix, int device, int n_threads, int64_t tota
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (mismatches) *mismatches = bad.load();
   if (n_batches) (void)slg_coalescer_stats(co, n_batches, nullptr);
+  if (phase_ms4) (void)slg_coalescer_phase_ms(co, phase_ms4, phase_ms4 + 1, phase_ms4 + 2, phase_ms4 + 3);
   slg_coalescer_destroy(co);
   return failed.load() ? -2.0 : secs;
 }

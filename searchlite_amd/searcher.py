@@ -533,6 +533,12 @@ class PreparedBatch:
         h = C.c_void_p(-1) if hip_stream is None else C.c_void_p(int(hip_stream) or None)
         N.check(self._lib.slg_batch_set_stream(self._h, h))
 
+    def rerank_device(self, n_clauses, d_qvecs, d_alpha, d_boost, k_out, d_out_doc, d_out_seg, d_out_score,
+                      d_out_vec, d_out_count) -> None:
+        """slg_batch_rerank_device: rerank this batch's own device results on the batch's stream."""
+        N.check(self._lib.slg_batch_rerank_device(self._h, n_clauses, d_qvecs, d_alpha, d_boost, k_out, d_out_doc,
+                                                  d_out_seg, d_out_score, d_out_vec, d_out_count))
+
     def sync(self) -> None:
         N.check(self._lib.slg_batch_sync(self._h))
 

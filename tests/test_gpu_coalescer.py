@@ -27,7 +27,7 @@ def harness():
     L.slh_coalesce_bench.restype = C.c_double
     L.slh_coalesce_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32,
-                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return L
 
 
@@ -49,7 +49,7 @@ def test_concurrent_callers_get_the_batch_api_rows(gpu, oracle, k, threads, max_
         bad, nb = C.c_int64(-1), C.c_uint64(0)
         secs = L.slh_coalesce_bench(ix._h, 0, threads, 20 * nq, offs_c.ctypes.data, terms_c.ctypes.data,
                                     w_c.ctypes.data, nq, 2, k, gpu.Wand, max_batch, 50, e_doc.ctypes.data,
-                                    e_score.ctypes.data, e_cnt.ctypes.data, C.addressof(bad), C.addressof(nb))
+                                    e_score.ctypes.data, e_cnt.ctypes.data, C.addressof(bad), C.addressof(nb), None)
         assert secs > 0 and bad.value == 0
         assert 1 <= nb.value <= 20 * nq
         if threads >= 32 and max_batch >= threads:
