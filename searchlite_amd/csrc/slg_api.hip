@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
@@ -355,6 +356,7 @@ struct slg_index {
   hipStream_t upload_streams[kUploadStreams] = {};
   hipStream_t stream = nullptr;
   std::shared_ptr<const IndexState> state;  // the current state (under mu)
+  std::atomic<uint64_t> generation{0};      // = state->generation, readable without the lock
   std::mutex mu;
   std::mutex update_mu;  // serialises slg_index_update_* / add_filter / add_vector_field (taken before mu)
   // profiling of the scoring kernel
@@ -782,6 +784,7 @@ void publish(slg_index *ix, std::unique_ptr<IndexState> ns) {
     std::lock_guard<std::mutex> lk(ix->mu);
     keep.swap(ix->state);
     ix->state = fresh;
+    ix->generation.store(fresh->generation, std::memory_order_release);
   }
 }
 
@@ -1188,8 +1191,7 @@ int slg_index_remove_segment(slg_index *ix, uint32_t seg) {
 }
 
 uint64_t slg_index_generation(const slg_index *ix) {
-  if (!ix) return 0;
-  return const_cast<slg_index *>(ix)->snapshot()->generation;
+  return ix ? ix->generation.load(std::memory_order_acquire) : 0;  // (no lock: callers poll it per request)
 }
 
 slg_batch *slg_batch_prepare(slg_index *ix, uint32_t nq, const uint32_t *q_offsets,

@@ -9,13 +9,20 @@
 // slg_batch_prepare / run / fetch and each gets its own row back.
 //
 // Mechanism: leader / followers.  The first caller to find no open batch opens one and becomes its
-// leader; callers that arrive while it is open append their query (same k and strategy; otherwise
-// they open a batch of their own kind).  The leader closes the batch when it is full (max_batch) or
-// max_wait_us after opening it — right away if the device is idle, i.e. no other batch of this
-// coalescer is in flight (a lone request never waits) — then plans, runs and fetches it on a HIP
-// stream of its own while the NEXT batch is already collecting behind a new leader: several batches
-// are in flight at once, which is what keeps the device fed.  Followers sleep on the batch's
-// condition variable and copy their row out after the leader's fetch.
+// leader; callers that arrive while it is open append their query (same k, strategy and segment
+// count: a "kind"; other kinds collect in batches of their own).  The leader closes the batch when it
+// is full (max_batch) or max_wait_us after opening it — right away if the device is idle, i.e. no
+// other batch of this coalescer is in flight (a lone request never waits) — then plans, runs and
+// fetches it on a HIP stream of its own while the NEXT batch is already collecting behind a new
+// leader: several batches are in flight at once, which is what keeps the device fed.  Followers spin
+// briefly, then sleep on the batch's condition variable, and copy their row out after the leader's fetch.
+//
+// Joining a batch takes no lock: a row is ONE fetch_add on the batch's ticket counter (the first
+// version took a mutex per request: with 256 caller threads the leaders spent 0.4 ms of every batch
+// queueing for it); the query is written into the row's fixed-size slot, `ready` counts the rows
+// written.  Closing = setting the counter's top bit (later tickets bounce and open the next batch).
+// Batch objects are recycled per kind, so a caller that still holds the pointer of a batch that has
+// been recycled meanwhile joins a batch of its own kind or bounces — never a foreign one.
 //
 // Host code on top of the public ABI (no kernels here; HIP only for the leaders' streams); part of
 // libsearchlite_gpu.so.
@@ -35,17 +42,27 @@
 
 namespace {
 
-// One collecting / running batch.  A caller reserves a row under the coalescer's mutex (a counter
-// increment) and writes its query into the row's fixed-size slot OUTSIDE the lock; `ready` counts the
-// rows written.  Batch objects are recycled (the slot arrays are a megabyte for an 8-segment index).
+constexpr uint32_t kClosed = 0x80000000u;  // ticket counter: top bit = the batch takes no more rows
+constexpr int kMaxKinds = 8;               // (k, strategy, segment count) combinations collecting at once
+
+inline void cpu_relax() {
+#if defined(__x86_64__)
+  __builtin_ia32_pause();
+#else
+  std::this_thread::yield();
+#endif
+}
+
+// One collecting / running batch (see the header comment).  Fixed-size slots: SLG_MAX_QUERY_TERMS x
+// n_segs term ids per row (a megabyte for an 8-segment index: objects are recycled, per kind).
 struct CoBatch {
   uint32_t k = 0;
   int strategy = 0;
-  uint32_t n_segs = 0, slot_terms = 0;  // slot: SLG_MAX_QUERY_TERMS x n_segs term ids
-  uint32_t nq = 0;                      // rows reserved (under slg_coalescer::mu)
-  bool closed = false;                  // no more rows (under slg_coalescer::mu)
-  std::atomic<uint32_t> ready{0};       // rows written
-  std::atomic<uint32_t> leaving{0};     // callers that have copied their result out
+  uint32_t n_segs = 0, slot_terms = 0, cap = 0;
+  std::atomic<uint32_t> tickets{kClosed};  // rows handed out; >= kClosed: closed
+  uint32_t nq = 0;                         // rows of the closed batch (set by its leader)
+  std::atomic<uint32_t> ready{0};          // rows written
+  std::atomic<uint32_t> leaving{0};        // callers that have copied their result out
   std::vector<uint32_t> slot_ids, slot_nt;
   std::vector<float> slot_w;
   // per-row score plan and doc filter (slg_coalescer_search_plan); plain rows: leaf i = term i, Sum, no filter
@@ -63,8 +80,19 @@ struct CoBatch {
   std::string error;
   std::mutex mu;
   std::condition_variable cv;
-  bool done = false;
-  bool full = false;  // the leader's wake-up: max_batch reached
+  std::atomic<bool> done{false};  // results are in (followers spin on it, then sleep on cv)
+  std::atomic<bool> full{false};  // the leader's wake-up: max_batch reached
+  int kind = 0;
+};
+
+struct Kind {
+  std::atomic<bool> used{false};
+  uint32_t k = 0, n_segs = 0;
+  int strategy = 0;
+  std::atomic<CoBatch *> cur{nullptr};  // the batch that is collecting, or null
+  std::mutex mu;                        // spare list
+  std::vector<CoBatch *> spare;
+  std::vector<CoBatch *> all;           // every batch object of the kind (destroy)
 };
 
 }  // namespace
@@ -72,15 +100,16 @@ struct CoBatch {
 struct slg_coalescer {
   slg_index *index = nullptr;
   uint32_t max_batch = 1024, max_wait_us = 50;
-  std::mutex mu;
-  std::vector<CoBatch *> open;        // at most one per (k, strategy, segment count) kind
-  std::vector<CoBatch *> spare;       // recycled batch objects
+  Kind kinds[kMaxKinds];
+  std::mutex mu;                       // kind registration, stream free list
   std::atomic<uint32_t> in_flight{0};  // batches closed and not yet fetched
-  // HIP streams for the leaders' batches (a leader takes one for the life of its batch)
-  std::vector<void *> free_streams;
-  // accounting (slg_coalescer_stats)
+  std::vector<void *> free_streams;    // HIP streams for the leaders' batches
+  // the index's segment count, cached per generation (slg_index_info takes the index mutex)
+  std::atomic<uint64_t> seen_generation{~0ull};
+  std::atomic<uint32_t> seen_n_segs{0};
+  // accounting (slg_coalescer_stats / _phase_ms)
   std::atomic<uint64_t> n_batches{0}, n_queries{0};
-  std::atomic<uint64_t> ns_collect{0}, ns_prepare{0}, ns_run{0}, ns_fetch{0};  // leaders' time per phase, summed
+  std::atomic<uint64_t> ns_collect{0}, ns_prepare{0}, ns_run{0}, ns_fetch{0};
 };
 
 namespace {
@@ -107,20 +136,75 @@ void give_stream(slg_coalescer *c, void *s) {
   c->free_streams.push_back(s);
 }
 
-// (under c->mu) take `b` off the open list
-void unlist(slg_coalescer *c, CoBatch *b) {
-  for (size_t i = 0; i < c->open.size(); i++)
-    if (c->open[i] == b) {
-      c->open[i] = c->open.back();
-      c->open.pop_back();
-      return;
+Kind *find_kind(slg_coalescer *c, uint32_t k, int strategy, uint32_t n_segs) {
+  for (int i = 0; i < kMaxKinds; i++) {
+    Kind &kd = c->kinds[i];
+    if (kd.used.load(std::memory_order_acquire) && kd.k == k && kd.strategy == strategy && kd.n_segs == n_segs) return &kd;
+  }
+  std::lock_guard<std::mutex> lk(c->mu);
+  for (int i = 0; i < kMaxKinds; i++) {
+    Kind &kd = c->kinds[i];
+    if (kd.used.load() && kd.k == k && kd.strategy == strategy && kd.n_segs == n_segs) return &kd;
+  }
+  for (int i = 0; i < kMaxKinds; i++) {
+    Kind &kd = c->kinds[i];
+    if (!kd.used.load()) {
+      kd.k = k;
+      kd.strategy = strategy;
+      kd.n_segs = n_segs;
+      kd.used.store(true, std::memory_order_release);
+      return &kd;
     }
+  }
+  return nullptr;
+}
+
+// a closed, reset batch object of the kind (recycled or new)
+CoBatch *fresh_batch(slg_coalescer *c, Kind &kd) {
+  CoBatch *b = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(kd.mu);
+    if (!kd.spare.empty()) {
+      b = kd.spare.back();
+      kd.spare.pop_back();
+    } else {
+      b = new CoBatch();
+      kd.all.push_back(b);
+    }
+  }
+  b->k = kd.k;
+  b->strategy = kd.strategy;
+  b->n_segs = kd.n_segs;
+  b->kind = (int)(&kd - c->kinds);
+  if (b->cap != c->max_batch || b->slot_terms != SLG_MAX_QUERY_TERMS * kd.n_segs) {
+    b->cap = c->max_batch;
+    b->slot_terms = SLG_MAX_QUERY_TERMS * kd.n_segs;
+    b->slot_ids.resize((size_t)b->cap * b->slot_terms);
+    b->slot_w.resize((size_t)b->cap * SLG_MAX_QUERY_TERMS);
+    b->slot_nt.resize(b->cap);
+    b->slot_leaf.resize((size_t)b->cap * SLG_MAX_QUERY_TERMS);
+    b->slot_nleaves.resize(b->cap);
+    b->slot_plan.resize(b->cap);
+    b->slot_filter.resize(b->cap);
+    b->slot_tie.resize(b->cap);
+  }
+  b->nq = 0;
+  b->ready.store(0);
+  b->leaving.store(0);
+  b->want_stats.store(false);
+  b->any_plan.store(false);
+  b->any_filter.store(false);
+  b->done.store(false);
+  b->full.store(false);
+  b->rc = SLG_OK;
+  b->error.clear();
+  return b;
 }
 
 // the leader's part: plan + run + fetch the closed batch, publish the results
 void run_batch(slg_coalescer *c, CoBatch &b) {
-  // every reserved row has been written?  (writers are a few stores behind their reservation)
-  while (b.ready.load(std::memory_order_acquire) < b.nq) std::this_thread::yield();
+  // every reserved row has been written?  (writers are a few stores behind their ticket)
+  while (b.ready.load(std::memory_order_acquire) < b.nq) cpu_relax();
   const uint32_t nq = b.nq, ns = b.n_segs;
   b.offs.resize((size_t)nq + 1);
   b.offs[0] = 0;
@@ -154,6 +238,10 @@ void run_batch(slg_coalescer *c, CoBatch &b) {
   if (sb && stream) rc = slg_batch_set_stream(sb, stream);
   if (sb && rc == SLG_OK) rc = slg_batch_run(sb);
   const auto t2 = std::chrono::steady_clock::now();
+  // the leader polls for the batch's kernels (a blocking stream wait costs a sleep / wake-up of tens of
+  // microseconds on a batch that takes about as long): a batch has ONE leader, the followers sleep
+  if (sb && rc == SLG_OK && stream)
+    while (hipStreamQuery((hipStream_t)stream) == hipErrorNotReady) cpu_relax();
   if (sb && rc == SLG_OK)
     rc = slg_batch_fetch(sb, b.doc.data(), b.seg.data(), b.score.data(), b.count.data(),
                          want_stats ? b.stats.data() : nullptr);
@@ -168,10 +256,10 @@ void run_batch(slg_coalescer *c, CoBatch &b) {
   c->in_flight.fetch_sub(1);
   c->n_batches.fetch_add(1);
   c->n_queries.fetch_add(nq);
+  b.rc = rc;
   {
     std::lock_guard<std::mutex> lk(b.mu);
-    b.rc = rc;
-    b.done = true;
+    b.done.store(true, std::memory_order_release);
   }
   b.cv.notify_all();
 }
@@ -184,7 +272,7 @@ slg_coalescer *slg_coalescer_create(slg_index *index, uint32_t max_batch, uint32
   if (!index) return nullptr;
   auto *c = new slg_coalescer();
   c->index = index;
-  c->max_batch = max_batch ? max_batch : 1024u;
+  c->max_batch = max_batch ? (max_batch < kClosed / 2 ? max_batch : 1024u) : 1024u;
   c->max_wait_us = max_wait_us;
   return c;
 }
@@ -193,8 +281,8 @@ slg_coalescer *slg_coalescer_create(slg_index *index, uint32_t max_batch, uint32
 void slg_coalescer_destroy(slg_coalescer *c) {
   if (!c) return;
   for (void *s : c->free_streams) (void)hipStreamDestroy((hipStream_t)s);
-  for (CoBatch *b : c->spare) delete b;
-  for (CoBatch *b : c->open) delete b;
+  for (Kind &kd : c->kinds)
+    for (CoBatch *b : kd.all) delete b;
   delete c;
 }
 
@@ -236,64 +324,57 @@ int slg_coalescer_search_plan(slg_coalescer *c, const slg_query *query, const ui
     g_co_error = "query has more than SLG_MAX_QUERY_TERMS terms";
     return SLG_ERR_UNSUPPORTED;
   }
-  uint32_t n_segs = 0;
-  if (slg_index_info(c->index, &n_segs, nullptr, nullptr) != SLG_OK) {
-    g_co_error = slg_last_error();
-    return SLG_ERR_INVALID;
+  // the index's segment count (the width of the query's term-id rows), cached per index generation
+  const uint64_t gen = slg_index_generation(c->index);
+  uint32_t n_segs = c->seen_n_segs.load(std::memory_order_acquire);
+  if (c->seen_generation.load(std::memory_order_acquire) != gen) {
+    if (slg_index_info(c->index, &n_segs, nullptr, nullptr) != SLG_OK) {
+      g_co_error = slg_last_error();
+      return SLG_ERR_INVALID;
+    }
+    c->seen_n_segs.store(n_segs, std::memory_order_release);
+    c->seen_generation.store(gen, std::memory_order_release);
   }
+  Kind *kd = find_kind(c, k, strategy, n_segs);
+  if (!kd) {
+    g_co_error = "too many (k, strategy) combinations collecting at once";
+    return SLG_ERR_UNSUPPORTED;
+  }
+  // ---- a row: one fetch_add on the collecting batch's ticket counter, or a batch of my own ----
   CoBatch *b = nullptr;
   uint32_t row = 0;
-  bool leader = false, filled = false;
-  {
-    std::lock_guard<std::mutex> lk(c->mu);
-    for (CoBatch *ob : c->open)
-      if (ob->k == k && ob->strategy == strategy && ob->n_segs == n_segs) {
-        b = ob;
+  bool leader = false;
+  for (;;) {
+    b = kd->cur.load(std::memory_order_acquire);
+    if (b) {
+      const uint32_t t = b->tickets.fetch_add(1, std::memory_order_acq_rel);
+      if (t < c->max_batch) {  // (closed: t >= kClosed; full: t >= max_batch)
+        row = t;
         break;
       }
-    if (!b) {
-      if (!c->spare.empty()) {
-        b = c->spare.back();
-        c->spare.pop_back();
-      } else {
-        b = new CoBatch();
-      }
-      b->k = k;
-      b->strategy = strategy;
-      b->n_segs = n_segs;
-      b->nq = 0;
-      b->closed = false;
-      b->ready.store(0);
-      b->leaving.store(0);
-      b->want_stats.store(false);
-      b->done = false;
-      b->full = false;
-      b->rc = SLG_OK;
-      b->error.clear();
-      if (b->slot_terms != SLG_MAX_QUERY_TERMS * n_segs || b->slot_nt.size() != c->max_batch) {
-        b->slot_terms = SLG_MAX_QUERY_TERMS * n_segs;
-        b->slot_ids.resize((size_t)c->max_batch * b->slot_terms);
-        b->slot_w.resize((size_t)c->max_batch * SLG_MAX_QUERY_TERMS);
-        b->slot_nt.resize(c->max_batch);
-        b->slot_leaf.resize((size_t)c->max_batch * SLG_MAX_QUERY_TERMS);
-        b->slot_nleaves.resize(c->max_batch);
-        b->slot_plan.resize(c->max_batch);
-        b->slot_filter.resize(c->max_batch);
-        b->slot_tie.resize(c->max_batch);
-      }
-      b->any_plan.store(false);
-      b->any_filter.store(false);
-      c->open.push_back(b);
-      leader = true;
+      if (kd->cur.load(std::memory_order_acquire) != b) continue;  // the next batch is already collecting
     }
-    row = b->nq++;
-    if (b->nq >= c->max_batch) {  // full: no more rows; the leader goes
-      b->closed = true;
-      unlist(c, b);
-      filled = true;
+    // no batch is collecting: open one (row 0 is mine) and publish it
+    CoBatch *nb = fresh_batch(c, *kd);
+    nb->tickets.store(1, std::memory_order_release);
+    CoBatch *expect = b;
+    if (!kd->cur.compare_exchange_strong(expect, nb, std::memory_order_acq_rel)) {
+      // another caller published its batch first: join that one — unless somebody already joined mine
+      // (a caller that still held the pointer of this recycled object), then it runs as it is
+      const uint32_t had = nb->tickets.exchange(kClosed, std::memory_order_acq_rel);
+      if (had == 1u) {
+        std::lock_guard<std::mutex> lk(kd->mu);
+        kd->spare.push_back(nb);
+        continue;
+      }
+      nb->tickets.store(had, std::memory_order_release);  // (reopen: rows 1 .. had-1 are real callers)
     }
+    b = nb;
+    row = 0;
+    leader = true;
+    break;
   }
-  // my row (outside the lock)
+  // ---- my row ----
   b->slot_nt[row] = query->n_terms;
   if (query->n_terms) {
     std::memcpy(b->slot_ids.data() + (size_t)row * b->slot_terms, query->term_ids, (size_t)query->n_terms * n_segs * 4);
@@ -315,10 +396,10 @@ int slg_coalescer_search_plan(slg_coalescer *c, const slg_query *query, const ui
   if (filter_id >= 0) b->any_filter.store(true);
   if (stats_or_null) b->want_stats.store(true);
   b->ready.fetch_add(1, std::memory_order_release);
-  if (filled && !leader) {  // the row that filled the batch wakes its leader
+  if (!leader && row + 1 == c->max_batch) {  // the row that filled the batch wakes its leader
     {
       std::lock_guard<std::mutex> bl(b->mu);
-      b->full = true;
+      b->full.store(true);
     }
     b->cv.notify_all();
   }
@@ -326,25 +407,35 @@ int slg_coalescer_search_plan(slg_coalescer *c, const slg_query *query, const ui
     const auto tc0 = std::chrono::steady_clock::now();
     // collect: until full, or max_wait_us — unless nothing else is in flight (an idle device: waiting
     // would only add latency; under load the batches in flight give the next one time to fill)
-    if (!filled && c->max_wait_us != 0 && c->in_flight.load() != 0) {
-      std::unique_lock<std::mutex> bl(b->mu);
-      b->cv.wait_for(bl, std::chrono::microseconds(c->max_wait_us), [&] { return b->full; });
-    }
-    {
-      std::lock_guard<std::mutex> lk(c->mu);
-      if (!b->closed) {
-        b->closed = true;
-        unlist(c, b);
+    if (c->max_wait_us != 0 && c->in_flight.load() != 0 && c->max_batch > 1) {
+      const auto until = tc0 + std::chrono::microseconds(c->max_wait_us);
+      if (c->max_wait_us <= 200) {  // short waits: poll (a timed sleep overshoots by more than the wait)
+        while (!b->full.load() && b->tickets.load(std::memory_order_relaxed) < c->max_batch &&
+               std::chrono::steady_clock::now() < until)
+          cpu_relax();
+      } else {
+        std::unique_lock<std::mutex> bl(b->mu);
+        b->cv.wait_until(bl, until, [&] { return b->full.load(); });
       }
-      c->in_flight.fetch_add(1);
     }
+    // close: later tickets bounce (and open the next batch); rows = the tickets handed out so far
+    const uint32_t t = b->tickets.fetch_or(kClosed, std::memory_order_acq_rel);
+    b->nq = t < c->max_batch ? t : c->max_batch;
+    CoBatch *expect = b;
+    (void)kd->cur.compare_exchange_strong(expect, nullptr, std::memory_order_acq_rel);
+    c->in_flight.fetch_add(1);
     c->ns_collect += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tc0).count();
     run_batch(c, *b);
   } else {
-    std::unique_lock<std::mutex> bl(b->mu);
-    b->cv.wait(bl, [&] { return b->done; });
+    // a short spin (the batch is usually a few tens of microseconds from done once it is full), then sleep
+    const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(20);
+    while (!b->done.load(std::memory_order_acquire) && std::chrono::steady_clock::now() < spin_until) cpu_relax();
+    if (!b->done.load(std::memory_order_acquire)) {
+      std::unique_lock<std::mutex> bl(b->mu);
+      b->cv.wait(bl, [&] { return b->done.load(std::memory_order_acquire); });
+    }
   }
-  int rc = b->rc;
+  const int rc = b->rc;
   if (rc != SLG_OK) {
     g_co_error = b->error;
   } else {
@@ -356,10 +447,10 @@ int slg_coalescer_search_plan(slg_coalescer *c, const slg_query *query, const ui
     }
     if (stats_or_null) *stats_or_null = b->stats[row];
   }
-  // the last caller to leave hands the batch object back
+  // the last caller to leave hands the batch object back to its kind (b->nq is final: done was seen)
   if (b->leaving.fetch_add(1) + 1 == b->nq) {
-    std::lock_guard<std::mutex> lk(c->mu);
-    c->spare.push_back(b);
+    std::lock_guard<std::mutex> lk(kd->mu);
+    kd->spare.push_back(b);
   }
   return rc;
 }

@@ -10,10 +10,16 @@ if len(sys.argv) > 1:
     os.environ["SLG_ROUNDS_PER_SLICE"] = sys.argv[1]
 # (DOCS=10000000 VOCAB=1048576 SEED=43 TERMS=5: config 3's corpus)
 n_docs, vocab = int(os.environ.get("DOCS", "1000000")), int(os.environ.get("VOCAB", str(1 << 18)))
-seg = corpus.zipf_segment(n_docs, vocab, seed=int(os.environ.get("SEED", "42")))
-offs, terms, w = corpus.zipf_queries(1024, int(os.environ.get("TERMS", "3")), seed=7, vocab=vocab)
+MF = int(os.environ.get("MF", "0"))  # MF=4: bench.py --config mf (4 fields, TERMS words per query string, a leaf per word)
+if MF:
+    seg = corpus.zipf_multifield_segment(n_docs, vocab, MF, seed=int(os.environ.get("SEED", "42")))
+    offs, terms, w, leaf = corpus.multifield_queries(1024, int(os.environ.get("TERMS", "2")), MF, vocab, seed=7)
+else:
+    seg = corpus.zipf_segment(n_docs, vocab, seed=int(os.environ.get("SEED", "42")))
+    offs, terms, w = corpus.zipf_queries(1024, int(os.environ.get("TERMS", "3")), seed=7, vocab=vocab)
+    leaf = None
 ix = searcher.GpuIndex([seg])
-b = ix.prepare(offs, terms, w, int(os.environ.get("K", "11")), int(os.environ.get("STRATEGY", "1")))
+b = ix.prepare(offs, terms, w, int(os.environ.get("K", "11")), int(os.environ.get("STRATEGY", "1")), q_leaf=leaf)
 for _ in range(3):
     b.run()
 b.sync()
@@ -24,7 +30,7 @@ L = N.load()
 L.slg_debug_read_stamps.restype = C.c_int
 L.slg_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 assert L.slg_debug_read_stamps(b._h, out.ctypes.data, n) == 0
-T_ = int(os.environ.get("TERMS", "3"))
+T_ = int(os.environ.get("TERMS", "3")) * (MF if MF else 1)
 names = (["0 describe + issue next", "1 chunk setup / loop", "2 P0+P1 clear+or", "3 P2+P3 read back + flags", "4 queue build",
           "5 -", "6 join + candidates", "7 wait loads + settle"] if os.environ.get("SLG_UNIFORM_KERNEL", "3") != "2" else
          ["0 plan/issue next", "1 chunk setup", "2 P0+P1 clear+or", "3 P2 read back", "4 P3 queue",
