@@ -230,6 +230,7 @@ struct RoundScoreParams {
   // postings of non-essential lists that were never loaded: [0] of the batch, [1 + q] of query q; or null
   unsigned long long *skip_counts;
   unsigned long long *stamps;  // [n_slices * 8] (SLG_STAMPS builds only)
+  uint32_t *error_flag;        // set (non-zero) by a wave that gave up on a round: slg_batch_fetch fails then
   uint32_t *work_ctr;          // persistent waves: kWorkQueues counters, kWorkCtrStride words apart
   uint32_t n_waves;            // waves launched (few-term kernel: min(n_slices, wave slots of the device))
 };

@@ -42,15 +42,23 @@ void launch_score_kregs<SLG_INST_KREGS>(const RoundScoreParams &sp, int kind, hi
   }
 #endif
   if (kind == 6 || kind == 7) {  // <= 4 / 5..8 lists, blocked layout (slg_score_uni4.hpp)
-    // persistent waves: sp.n_waves / kU4WavesPerBlock workgroups (u4_launch_blocks, slg_api.hip), each wave
-    // pulls slices from sp.work_ctr
+    // one wave per slice (sp.work_ctr == nullptr), or persistent waves: sp.n_waves / kU4WavesPerBlock
+    // workgroups (u4_launch_blocks, slg_api.hip), each wave pulls slices from sp.work_ctr
     const uint32_t blocks = (sp.n_waves + (uint32_t)kU4WavesPerBlock - 1u) / (uint32_t)kU4WavesPerBlock;
-    if (kind == 6)
-      hipLaunchKernelGGL((score_uniform4_kernel<SLG_INST_KREGS, 4>), dim3(blocks), dim3(64 * kU4WavesPerBlock),
-                         kU4WavesPerBlock * u4_wave_lds(SLG_INST_KREGS, 4, u4_filter_words(4)), st, sp);
-    else
-      hipLaunchKernelGGL((score_uniform4_kernel<SLG_INST_KREGS, 8>), dim3(blocks), dim3(64 * kU4WavesPerBlock),
-                         kU4WavesPerBlock * u4_wave_lds(SLG_INST_KREGS, 8, u4_filter_words(8)), st, sp);
+    const dim3 grid(blocks), wg(64 * kU4WavesPerBlock);
+    const size_t lds4 = kU4WavesPerBlock * u4_wave_lds(SLG_INST_KREGS, 4, u4_filter_words(4));
+    const size_t lds8 = kU4WavesPerBlock * u4_wave_lds(SLG_INST_KREGS, 8, u4_filter_words(8));
+    if (sp.work_ctr == nullptr) {
+      if (kind == 6)
+        hipLaunchKernelGGL((score_uniform4_kernel<SLG_INST_KREGS, 4, false, false>), grid, wg, lds4, st, sp);
+      else
+        hipLaunchKernelGGL((score_uniform4_kernel<SLG_INST_KREGS, 8, false, false>), grid, wg, lds8, st, sp);
+    } else {
+      if (kind == 6)
+        hipLaunchKernelGGL((score_uniform4_kernel<SLG_INST_KREGS, 4, false, true>), grid, wg, lds4, st, sp);
+      else
+        hipLaunchKernelGGL((score_uniform4_kernel<SLG_INST_KREGS, 8, false, true>), grid, wg, lds8, st, sp);
+    }
     return;
   }
   if (kind == 8 || kind == 9) {  // the same kernel with score plans (flat Sum / DisMax over multi-term leaves)
