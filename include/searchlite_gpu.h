@@ -17,10 +17,10 @@
  * Eligibility (the caller keeps every other request shape on searchlite's CPU scorer;
  * SURVEY.md section 8b): ScoreMode::Score, sort = _score desc, no collector/aggs, no
  * score_adjust/explain, no cursor, matcher = pure disjunction; filters as doc bitmaps
- * (slg_index_add_filter*: accept() = !is_deleted(doc) && filter(doc)); ScorePlan = Sum or DisMax
- * over leaves, each leaf the sum of one or more scored terms (slg_batch_prepare_plan; the
- * default is leaf i == query term i); k = limit + 1 up to 20 001; up to 32 scored terms per
- * query and segment.
+ * (slg_index_add_filter*: accept() = !is_deleted(doc) && filter(doc)); ScorePlan = any tree of Sum /
+ * DisMax nodes up to SLG_MAX_PLAN_DEPTH levels above its leaves, each leaf the sum of one or more
+ * scored terms (slg_batch_prepare_plans; the default is leaf i == query term i, summed);
+ * k = limit + 1 up to 20 001; up to 32 scored terms per query and segment.
  */
 #ifndef SEARCHLITE_GPU_H
 #define SEARCHLITE_GPU_H
@@ -253,6 +253,8 @@ int slg_index_update_deleted(slg_index *index, uint32_t seg, const uint8_t *dele
 int slg_index_add_segment(slg_index *index, const slg_segment_desc *seg);
 /* Drop segment `seg` (compaction, index/mod.rs:102+); the ordinals above it move down by one. */
 int slg_index_remove_segment(slg_index *index, uint32_t seg);
+/* The HIP device the index lives on (>= 0), or a negative error code. */
+int slg_index_device(const slg_index *index);
 /* Number of updates applied since creation (0 for a fresh index). */
 uint64_t slg_index_generation(const slg_index *index);
 
@@ -357,7 +359,20 @@ typedef struct {
   const uint32_t *q_group_offsets;  /* [nq + 1] into group_plan / group_tie */
   const int32_t *group_plan;        /* SLG_PLAN_SUM | SLG_PLAN_DISMAX per group */
   const float *group_tie;           /* tie breaker per group, in [0, 1] */
+  /* Trees of any shape (ScoreExpr is recursive, query/planner.rs:113-153), up to SLG_MAX_PLAN_DEPTH levels
+   * of Sum / DisMax nodes above the leaves: per query a node array in PRE-ORDER (node 0 = the root,
+   * node_parent[i] < i, node_parent[0] ignored), node_kind = SLG_PLAN_SUM | SLG_PLAN_DISMAX | SLG_PLAN_LEAF,
+   * node_tie in [0, 1] for DisMax nodes; the i-th LEAF node of a query in pre-order is ScorePlan leaf i
+   * (q_leaf names it per query term).  Every Sum / DisMax node has at least one child.  With
+   * q_node_offsets != NULL the root / group arrays above are not read (q_leaf still is).  Trees of one
+   * or two levels run exactly as the forms above; deeper ones on the many-term kernel's tree mode. */
+  const uint32_t *q_node_offsets;   /* [nq + 1] into node_kind / node_tie / node_parent; NULL: the forms above */
+  const int32_t *node_kind;
+  const float *node_tie;
+  const uint32_t *node_parent;
 } slg_score_plans;
+#define SLG_PLAN_LEAF 2
+#define SLG_MAX_PLAN_DEPTH 4u
 slg_batch *slg_batch_prepare_plans(slg_index *index, uint32_t nq, const uint32_t *q_offsets,
                                    const uint32_t *q_term_ids, const float *q_weights,
                                    const slg_score_plans *plans_or_null, const int32_t *q_filter_or_null,

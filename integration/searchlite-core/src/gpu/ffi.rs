@@ -38,6 +38,8 @@ pub struct slg_tuning {
     pub q_leaf: *const u32, pub q_plan: *const i32, pub q_tie: *const c_float, pub q_nleaves: *const u32,
     pub q_leaf_offsets: *const u32, pub leaf_group: *const u32, pub q_group_offsets: *const u32,
     pub group_plan: *const i32, pub group_tie: *const c_float,
+    // trees of any shape: per query a node array in pre-order (SLG_PLAN_SUM | _DISMAX | _LEAF)
+    pub q_node_offsets: *const u32, pub node_kind: *const i32, pub node_tie: *const c_float, pub node_parent: *const u32,
 }
 #[repr(C)] pub struct slg_stats { pub scored_docs: u64, pub candidates_examined: u64, pub postings_advanced: u64 }
 #[repr(C)] pub struct slg_query { pub n_terms: u32, pub term_ids: *const u32, pub weights: *const c_float }
@@ -60,6 +62,7 @@ extern "C" {
     pub fn slg_index_add_segment(index: *mut slg_index, seg: *const slg_segment_desc) -> c_int;
     pub fn slg_index_remove_segment(index: *mut slg_index, seg: u32) -> c_int;
     pub fn slg_index_generation(index: *const slg_index) -> u64;
+    pub fn slg_index_device(index: *const slg_index) -> c_int;
     // request coalescer: concurrent single-query callers -> batches (searchlite-http/src/lib.rs:628-652)
     pub fn slg_coalescer_create(index: *mut slg_index, max_batch: u32, max_wait_us: u32) -> *mut slg_coalescer;
     pub fn slg_coalescer_destroy(coalescer: *mut slg_coalescer);
@@ -172,3 +175,5 @@ pub const SLG_STRATEGY_WAND: c_int = 1;
 pub const SLG_STRATEGY_BMW: c_int = 2;
 pub const SLG_PLAN_SUM: i32 = 0;
 pub const SLG_PLAN_DISMAX: i32 = 1;
+pub const SLG_PLAN_LEAF: i32 = 2;
+pub const SLG_MAX_PLAN_DEPTH: usize = 4;

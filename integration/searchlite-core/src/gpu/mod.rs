@@ -422,6 +422,40 @@ pub(crate) enum GpuScorePlan {
   /// `dis_max{queries}` (planner.rs:470-487) and `bool{should: [multi_match ...]}` (:670-690) build.
   /// leaf_group[l] = group of leaf l; a bare leaf child is a Sum group of one leaf.
   Tree { root_dismax: bool, root_tie: f32, leaf_group: Vec<u32>, group_plan: Vec<i32>, group_tie: Vec<f32> },
+  /// anything deeper (up to SLG_MAX_PLAN_DEPTH levels of Sum / DisMax above the leaves): the tree node
+  /// by node in pre-order (slg_score_plans::q_node_offsets)
+  Nodes { kind: Vec<i32>, tie: Vec<f32>, parent: Vec<u32> },
+}
+
+/// Pre-order node arrays of `e`; leaves must come out numbered 0, 1, 2, ... (the planner assigns leaf ids
+/// in traversal order) and every Sum / DisMax needs a child.  `depth` = levels of internal nodes above `e`.
+fn push_nodes(e: &ScoreExpr, parent: u32, depth: usize, next_leaf: &mut usize, kind: &mut Vec<i32>, tie: &mut Vec<f32>, par: &mut Vec<u32>) -> bool {
+  let me = kind.len() as u32;
+  match e {
+    ScoreExpr::Leaf(i) => {
+      if *i != *next_leaf {
+        return false;
+      }
+      *next_leaf += 1;
+      kind.push(ffi::SLG_PLAN_LEAF);
+      tie.push(0.0);
+      par.push(parent);
+      true
+    }
+    ScoreExpr::Sum(cs) | ScoreExpr::DisMax { children: cs, .. } => {
+      if cs.is_empty() || depth >= ffi::SLG_MAX_PLAN_DEPTH {
+        return false;
+      }
+      let (k, t) = match e {
+        ScoreExpr::DisMax { tie_breaker, .. } => (ffi::SLG_PLAN_DISMAX, *tie_breaker),
+        _ => (ffi::SLG_PLAN_SUM, 0.0),
+      };
+      kind.push(k);
+      tie.push(t);
+      par.push(parent);
+      cs.iter().all(|c| push_nodes(c, me, depth + 1, next_leaf, kind, tie, par))
+    }
+  }
 }
 
 fn plan_shape(plan: &QueryPlan) -> Option<(GpuScorePlan, u32)> {
@@ -453,7 +487,15 @@ fn plan_shape(plan: &QueryPlan) -> Option<(GpuScorePlan, u32)> {
         ffi::SLG_PLAN_DISMAX,
         *tie_breaker,
       ),
-      _ => return None, // three levels or more stay on the CPU scorer
+      _ => {
+        // three levels or more: the whole tree node by node
+        let (mut kind, mut tie, mut par) = (Vec::new(), Vec::new(), Vec::new());
+        let mut next = 0usize;
+        if push_nodes(&sp.root, 0, 0, &mut next, &mut kind, &mut tie, &mut par) && next == sp.leaf_count {
+          return Some((GpuScorePlan::Nodes { kind, tie, parent: par }, n_leaves));
+        }
+        return None;
+      }
     };
     for l in leaves {
       if l != next_leaf || l >= leaf_group.len() {
@@ -569,6 +611,11 @@ pub(crate) fn gpu_top_k(
     GpuScorePlan::Tree { root_dismax, root_tie, .. } => {
       (if *root_dismax { ffi::SLG_PLAN_DISMAX } else { ffi::SLG_PLAN_SUM }, *root_tie)
     }
+    GpuScorePlan::Nodes { .. } => (ffi::SLG_PLAN_SUM, 0.0f32), // (not read: the node arrays carry the root)
+  };
+  let node_offsets = match score_plan {
+    GpuScorePlan::Nodes { kind, .. } => [0u32, kind.len() as u32],
+    _ => [0u32, 0],
   };
   // two-level plans: CSR of one query (slg_score_plans)
   let (leaf_offsets, group_offsets) = match score_plan {
@@ -594,6 +641,22 @@ pub(crate) fn gpu_top_k(
       GpuScorePlan::Tree { group_tie, .. } => group_tie.as_ptr(),
       _ => std::ptr::null(),
     },
+    q_node_offsets: match score_plan {
+      GpuScorePlan::Nodes { .. } => node_offsets.as_ptr(),
+      _ => std::ptr::null(),
+    },
+    node_kind: match score_plan {
+      GpuScorePlan::Nodes { kind, .. } => kind.as_ptr(),
+      _ => std::ptr::null(),
+    },
+    node_tie: match score_plan {
+      GpuScorePlan::Nodes { tie, .. } => tie.as_ptr(),
+      _ => std::ptr::null(),
+    },
+    node_parent: match score_plan {
+      GpuScorePlan::Nodes { parent, .. } => parent.as_ptr(),
+      _ => std::ptr::null(),
+    },
   };
   let filter_id = match filter {
     Some(f) => gpu.filter_id(segments, f)?,
@@ -608,7 +671,7 @@ pub(crate) fn gpu_top_k(
   // Flat plans (every query string, multi_match, dis_max of terms) go through the coalescer: the
   // reference has no batch API (api/reader.rs:2539) and serves a request per blocking thread
   // (searchlite-http/src/lib.rs:628-652), so concurrent requests share one prepare / run / fetch.
-  if !matches!(score_plan, GpuScorePlan::Tree { .. }) {
+  if matches!(score_plan, GpuScorePlan::Sum | GpuScorePlan::DisMax { .. }) {
     let (mut doc, mut seg, mut score) = (vec![0u32; top_k], vec![0u32; top_k], vec![0f32; top_k]);
     let mut count = 0u32;
     let mut stats = ffi::slg_stats { scored_docs: 0, candidates_examined: 0, postings_advanced: 0 };

@@ -93,6 +93,11 @@ def lib():
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.slo_search_batch_nodes.restype = C.c_int
+        L.slo_search_batch_nodes.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.slo_normalize_in_place.restype = None
         L.slo_normalize_in_place.argtypes = [C.c_void_p, C.c_uint32]
         L.slo_metric_similarity.restype = f32
@@ -184,13 +189,14 @@ def _pack_segments(segments):
     return arr, keep
 
 
-PLAN_SUM, PLAN_DISMAX = 0, 1
+PLAN_SUM, PLAN_DISMAX, PLAN_LEAF = 0, 1, 2
 
 
 def search_batch(segments, q_offsets, q_terms, q_weights, k, strategy=WAND, block_size=None,
                  n_threads=1, cache_min_len=False, want_stats=False, q_leaf=None, q_plan=None,
                  q_tie=None, q_nleaves=None, q_leaf_offsets=None, leaf_group=None, q_group_offsets=None,
-                 group_plan=None, group_tie=None):
+                 group_plan=None, group_tie=None, q_node_offsets=None, node_kind=None, node_tie=None,
+                 node_parent=None):
     """api/reader.rs search() over segments for a batch of pure-disjunction queries.
 
     q_terms has shape [total_query_terms, n_segs] (per-segment term ids, NO_TERM if absent).
@@ -198,7 +204,9 @@ def search_batch(segments, q_offsets, q_terms, q_weights, k, strategy=WAND, bloc
     a query is leaf i), q_plan[q] = PLAN_SUM | PLAN_DISMAX over the leaves, q_tie[q] = DisMax
     tie breaker, q_nleaves[q] = leaves of the plan.  Two-level plans (ScoreExpr::evaluate recursion,
     planner.rs:122-153): leaf_group / group_plan / group_tie with their per-query CSR offsets — the
-    root combines groups, a group combines its consecutive leaves.
+    root combines groups, a group combines its consecutive leaves.  Trees of any depth: per query a
+    node array in pre-order (q_node_offsets CSR; node_kind PLAN_SUM / PLAN_DISMAX / PLAN_LEAF, node_tie,
+    node_parent; the i-th LEAF node of a query is leaf i).
     Returns (doc[nq,k], seg[nq,k], score[nq,k], count[nq]).
     """
     segs, keep = _pack_segments(segments)
@@ -220,6 +228,21 @@ def search_batch(segments, q_offsets, q_terms, q_weights, k, strategy=WAND, bloc
     qgo = None if q_group_offsets is None else np.ascontiguousarray(q_group_offsets, dtype=np.uint32)
     gp = None if group_plan is None else np.ascontiguousarray(group_plan, dtype=np.int32)
     gt = None if group_tie is None else np.ascontiguousarray(group_tie, dtype=np.float32)
+    if q_node_offsets is not None:
+        qno = np.ascontiguousarray(q_node_offsets, dtype=np.uint32)
+        nk = np.ascontiguousarray(node_kind, dtype=np.int32)
+        nt = np.ascontiguousarray(node_tie, dtype=np.float32)
+        npar = np.ascontiguousarray(node_parent, dtype=np.uint32)
+        rc = lib().slo_search_batch_nodes(segs, len(segments), nq, _ptr(q_offsets), _ptr(q_terms), _ptr(q_weights),
+                                          _ptr(ql), _ptr(qno), _ptr(nk), _ptr(nt), _ptr(npar), k, strategy,
+                                          block_size or 0, n_threads, int(cache_min_len), _ptr(out_doc),
+                                          _ptr(out_seg), _ptr(out_score), _ptr(out_count),
+                                          None if stats is None else C.addressof(stats))
+        if rc != 0:
+            raise RuntimeError(f"slo_search_batch_nodes failed: {rc}")
+        if want_stats:
+            return out_doc, out_seg, out_score, out_count, stats
+        return out_doc, out_seg, out_score, out_count
     rc = lib().slo_search_batch_tree(segs, len(segments), nq, _ptr(q_offsets), _ptr(q_terms),
                                      _ptr(q_weights), _ptr(ql), _ptr(qp), _ptr(qt), _ptr(qn),
                                      _ptr(qlo), _ptr(lg), _ptr(qgo), _ptr(gp), _ptr(gt), k,

@@ -323,6 +323,44 @@ static void plan_tree(plan_t *p, expr *nodes, int kind, float tie, uint32_t leaf
   p->leaf_count = leaf_count;
 }
 
+/* Any tree (ScoreExpr is recursive, planner.rs:113-153): nodes in PRE-ORDER, node 0 the root,
+ * parent[i] < i; kind SLO_PLAN_SUM / SLO_PLAN_DISMAX / SLO_PLAN_LEAF; the i-th LEAF node in pre-order is
+ * leaf i.  store: caller storage for 2 * n_nodes expressions (the nodes, then their child arrays). */
+static void plan_nodes(plan_t *p, expr *store, uint32_t n_nodes, const int32_t *kind, const float *tie,
+                       const uint32_t *parent) {
+  uint32_t *cnt = (uint32_t *)calloc(n_nodes ? n_nodes : 1, sizeof(uint32_t));
+  uint32_t *first = (uint32_t *)malloc((n_nodes ? n_nodes : 1) * sizeof(uint32_t));
+  for (uint32_t i = 1; i < n_nodes; i++) cnt[parent[i]]++;
+  uint32_t at = 0;
+  for (uint32_t i = 0; i < n_nodes; i++) {
+    first[i] = at;
+    at += cnt[i];
+  }
+  expr *slots = store + n_nodes;
+  uint32_t leaf = 0;
+  for (uint32_t i = 0; i < n_nodes; i++) {
+    expr e = {EXPR_SUM, 0.0f, 0, cnt[i], slots + first[i]};
+    if (kind[i] == SLO_PLAN_LEAF) {
+      e.kind = EXPR_LEAF;
+      e.leaf = leaf++;
+      e.n_children = 0;
+      e.children = NULL;
+    } else if (kind[i] == SLO_PLAN_DISMAX) {
+      e.kind = EXPR_DISMAX;
+      e.tie = tie[i];
+    }
+    store[i] = e;
+  }
+  /* children in pre-order = the reference's child order; a copied expr keeps pointing at its own
+   * (stable) child slots, so the copy order does not matter */
+  memset(cnt, 0, (n_nodes ? n_nodes : 1) * sizeof(uint32_t));
+  for (uint32_t i = 1; i < n_nodes; i++) slots[first[parent[i]] + cnt[parent[i]]++] = store[i];
+  free(cnt);
+  free(first);
+  p->root = &store[0];
+  p->leaf_count = leaf;
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* brute force (ExecutionStrategy::Bm25)  query/wand.rs:459-566                          */
 /* ------------------------------------------------------------------------------------ */
@@ -738,6 +776,19 @@ int slo_execute_top_k_tree(const slo_term *terms, uint32_t n_terms, uint32_t k, 
   return n;
 }
 
+int slo_execute_top_k_nodes(const slo_term *terms, uint32_t n_terms, uint32_t k, int strategy,
+                            uint32_t block_size, uint32_t n_nodes, const int32_t *node_kind, const float *node_tie,
+                            const uint32_t *node_parent, const uint8_t *deleted, const float *min_len_cache,
+                            uint32_t *out_doc, float *out_score, slo_stats *stats) {
+  expr *nodes = (expr *)malloc(((size_t)2 * n_nodes + 1) * sizeof(expr));
+  plan_t plan;
+  plan_nodes(&plan, nodes, n_nodes, node_kind, node_tie, node_parent);
+  int n = execute_with_plan(terms, n_terms, k, strategy, block_size, &plan, deleted, min_len_cache,
+                            out_doc, out_score, stats);
+  free(nodes);
+  return n;
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* batch driver: api/reader.rs:2670-2745 (segment loop), :2908-3128 (search_segment),    */
 /* :2776-2778 + query/sort.rs:80-93 (merge order)                                        */
@@ -778,6 +829,10 @@ typedef struct {
   const uint32_t *q_leaf_offsets, *leaf_group, *q_group_offsets;
   const int32_t *group_plan;
   const float *group_tie;
+  /* any tree (NULL q_node_offsets: the forms above): CSR of per-query node arrays in pre-order */
+  const uint32_t *q_node_offsets, *node_parent;
+  const int32_t *node_kind;
+  const float *node_tie;
 } batch_ctx;
 
 static void run_query(const batch_ctx *c, uint32_t q, slo_term *terms, float *mins, uint32_t *tmp_doc,
@@ -816,7 +871,12 @@ static void run_query(const batch_ctx *c, uint32_t q, slo_term *terms, float *mi
     }
     if (n == 0) continue; /* api/reader.rs:3003-3005 */
     int got;
-    if (c->leaf_group) {
+    if (c->q_node_offsets) {
+      uint32_t no = c->q_node_offsets[q];
+      got = slo_execute_top_k_nodes(terms, n, c->k, c->strategy, c->block_size, c->q_node_offsets[q + 1] - no,
+                                    c->node_kind + no, c->node_tie + no, c->node_parent + no, seg->deleted,
+                                    c->min_len ? mins : NULL, tmp_doc, tmp_score, c->stats ? &c->stats[q] : NULL);
+    } else if (c->leaf_group) {
       uint32_t lo = c->q_leaf_offsets[q], go = c->q_group_offsets[q];
       got = slo_execute_top_k_tree(terms, n, c->k, c->strategy, c->block_size,
                                    c->q_plan ? c->q_plan[q] : SLO_PLAN_SUM, c->q_tie ? c->q_tie[q] : 0.0f,
@@ -890,6 +950,17 @@ int slo_search_batch_plan(const slo_segment *segs, uint32_t n_segs, uint32_t nq,
                                out_doc, out_seg, out_score, out_count, stats_or_null);
 }
 
+static int search_batch_any(const slo_segment *segs, uint32_t n_segs, uint32_t nq,
+                          const uint32_t *q_offsets, const uint32_t *q_terms, const float *q_weights,
+                          const uint32_t *q_leaf, const int32_t *q_plan, const float *q_tie,
+                          const uint32_t *q_nleaves, const uint32_t *q_leaf_offsets,
+                          const uint32_t *leaf_group, const uint32_t *q_group_offsets,
+                          const int32_t *group_plan, const float *group_tie, const uint32_t *q_node_offsets,
+                          const int32_t *node_kind, const float *node_tie, const uint32_t *node_parent, uint32_t k,
+                          int strategy, uint32_t block_size, int n_threads, int cache_min_len, uint32_t *out_doc,
+                          uint32_t *out_seg, float *out_score, uint32_t *out_count,
+                          slo_stats *stats_or_null);
+
 int slo_search_batch_tree(const slo_segment *segs, uint32_t n_segs, uint32_t nq,
                           const uint32_t *q_offsets, const uint32_t *q_terms, const float *q_weights,
                           const uint32_t *q_leaf, const int32_t *q_plan, const float *q_tie,
@@ -897,6 +968,34 @@ int slo_search_batch_tree(const slo_segment *segs, uint32_t n_segs, uint32_t nq,
                           const uint32_t *leaf_group, const uint32_t *q_group_offsets,
                           const int32_t *group_plan, const float *group_tie, uint32_t k, int strategy,
                           uint32_t block_size, int n_threads, int cache_min_len, uint32_t *out_doc,
+                          uint32_t *out_seg, float *out_score, uint32_t *out_count,
+                          slo_stats *stats_or_null) {
+  return search_batch_any(segs, n_segs, nq, q_offsets, q_terms, q_weights, q_leaf, q_plan, q_tie, q_nleaves,
+                          q_leaf_offsets, leaf_group, q_group_offsets, group_plan, group_tie, NULL, NULL, NULL, NULL, k,
+                          strategy, block_size, n_threads, cache_min_len, out_doc, out_seg, out_score, out_count,
+                          stats_or_null);
+}
+
+int slo_search_batch_nodes(const slo_segment *segs, uint32_t n_segs, uint32_t nq, const uint32_t *q_offsets,
+                           const uint32_t *q_terms, const float *q_weights, const uint32_t *q_leaf,
+                           const uint32_t *q_node_offsets, const int32_t *node_kind, const float *node_tie,
+                           const uint32_t *node_parent, uint32_t k, int strategy, uint32_t block_size, int n_threads,
+                           int cache_min_len, uint32_t *out_doc, uint32_t *out_seg, float *out_score,
+                           uint32_t *out_count, slo_stats *stats_or_null) {
+  if (!q_node_offsets || !node_kind || !node_tie || !node_parent) return -1;
+  return search_batch_any(segs, n_segs, nq, q_offsets, q_terms, q_weights, q_leaf, NULL, NULL, NULL, NULL, NULL, NULL,
+                          NULL, NULL, q_node_offsets, node_kind, node_tie, node_parent, k, strategy, block_size,
+                          n_threads, cache_min_len, out_doc, out_seg, out_score, out_count, stats_or_null);
+}
+
+static int search_batch_any(const slo_segment *segs, uint32_t n_segs, uint32_t nq,
+                          const uint32_t *q_offsets, const uint32_t *q_terms, const float *q_weights,
+                          const uint32_t *q_leaf, const int32_t *q_plan, const float *q_tie,
+                          const uint32_t *q_nleaves, const uint32_t *q_leaf_offsets,
+                          const uint32_t *leaf_group, const uint32_t *q_group_offsets,
+                          const int32_t *group_plan, const float *group_tie, const uint32_t *q_node_offsets,
+                          const int32_t *node_kind, const float *node_tie, const uint32_t *node_parent, uint32_t k,
+                          int strategy, uint32_t block_size, int n_threads, int cache_min_len, uint32_t *out_doc,
                           uint32_t *out_seg, float *out_score, uint32_t *out_count,
                           slo_stats *stats_or_null) {
   if (!segs || !q_offsets || !out_doc || !out_seg || !out_score || !out_count) return -1;
@@ -926,7 +1025,8 @@ int slo_search_batch_tree(const slo_segment *segs, uint32_t n_segs, uint32_t nq,
     batch_ctx c = {segs,      n_segs,   nq,        q_offsets, q_terms,   q_weights, k,
                    strategy,  block_size, min_len, max_fields, out_doc,  out_seg,   out_score,
                    out_count, stats_or_null, t,    n_threads, q_leaf, q_plan, q_tie, q_nleaves,
-                   q_leaf_offsets, leaf_group, q_group_offsets, group_plan, group_tie};
+                   q_leaf_offsets, leaf_group, q_group_offsets, group_plan, group_tie,
+                   q_node_offsets, node_parent, node_kind, node_tie};
     ctxs[t] = c;
   }
   if (n_threads == 1) {

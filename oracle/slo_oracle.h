@@ -146,6 +146,17 @@ int slo_search_batch_tree(const slo_segment *segs, uint32_t n_segs, uint32_t nq,
                           uint32_t block_size, int n_threads, int cache_min_len, uint32_t *out_doc,
                           uint32_t *out_seg, float *out_score, uint32_t *out_count,
                           slo_stats *stats_or_null);
+/* Any score tree (ScoreExpr::evaluate is recursive, query/planner.rs:122-153): per query a node array
+ * in PRE-ORDER (node 0 = the root, node_parent[i] < i), node_kind SLO_PLAN_SUM / SLO_PLAN_DISMAX (node_tie)
+ * / SLO_PLAN_LEAF; the i-th LEAF node of a query in pre-order is ScorePlan leaf i (q_leaf names it per
+ * query term). */
+#define SLO_PLAN_LEAF 2
+int slo_search_batch_nodes(const slo_segment *segs, uint32_t n_segs, uint32_t nq, const uint32_t *q_offsets,
+                           const uint32_t *q_terms, const float *q_weights, const uint32_t *q_leaf,
+                           const uint32_t *q_node_offsets, const int32_t *node_kind, const float *node_tie,
+                           const uint32_t *node_parent, uint32_t k, int strategy, uint32_t block_size, int n_threads,
+                           int cache_min_len, uint32_t *out_doc, uint32_t *out_seg, float *out_score,
+                           uint32_t *out_count, slo_stats *stats_or_null);
 int slo_execute_top_k_tree(const slo_term *terms, uint32_t n_terms, uint32_t k, int strategy,
                            uint32_t block_size, int plan_kind, float tie_breaker, uint32_t leaf_count,
                            uint32_t n_groups, const uint32_t *leaf_group, const int32_t *group_plan,

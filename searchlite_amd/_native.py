@@ -21,7 +21,7 @@ SHARD_UNIQUE_ID_BYTES = 128
 OK, ERR_INVALID, ERR_DEVICE, ERR_OOM, ERR_UNSUPPORTED, ERR_INTERNAL = 0, -1, -2, -3, -4, -5
 STRATEGY_BM25, STRATEGY_WAND, STRATEGY_BMW = 0, 1, 2
 METRIC_COSINE, METRIC_L2 = 0, 1
-PLAN_SUM, PLAN_DISMAX = 0, 1
+PLAN_SUM, PLAN_DISMAX, PLAN_LEAF = 0, 1, 2
 
 
 class SlgError(RuntimeError):
@@ -71,7 +71,9 @@ class ScorePlans(C.Structure):
     """slg_score_plans: flat (leaf_group NULL) or two-level score plans."""
     _fields_ = [("q_leaf", C.c_void_p), ("q_plan", C.c_void_p), ("q_tie", C.c_void_p), ("q_nleaves", C.c_void_p),
                 ("q_leaf_offsets", C.c_void_p), ("leaf_group", C.c_void_p), ("q_group_offsets", C.c_void_p),
-                ("group_plan", C.c_void_p), ("group_tie", C.c_void_p)]
+                ("group_plan", C.c_void_p), ("group_tie", C.c_void_p),
+                ("q_node_offsets", C.c_void_p), ("node_kind", C.c_void_p), ("node_tie", C.c_void_p),
+                ("node_parent", C.c_void_p)]
 
 
 class Query(C.Structure):
@@ -129,6 +131,7 @@ def load():
         "slg_index_add_segment": (i32, [vp, vp]),
         "slg_index_remove_segment": (i32, [vp, u32]),
         "slg_index_generation": (C.c_uint64, [vp]),
+        "slg_index_device": (i32, [vp]),
         "slg_coalescer_create": (vp, [vp, u32, u32]),
         "slg_coalescer_destroy": (None, [vp]),
         "slg_coalescer_search": (i32, [vp, vp, u32, i32, vp, vp, vp, vp, vp]),

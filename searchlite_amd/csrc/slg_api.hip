@@ -381,6 +381,8 @@ struct slg_batch {
   bool uniform = false;  // every sub-query fits the one-list-per-slot kernel
   bool plan_batch = false;  // some sub-query has a score plan (multi kernel only)
   bool nested = false;      // some sub-query has a two-level plan (groups of leaves)
+  bool deep = false;        // some sub-query has a score tree of more than two levels
+  const slg::PlanNode *d_nodes = nullptr;
   bool pruned = false;      // some sub-query has non-essential lists (MaxScore)
   bool multi = false;    // many-term form of it (slg_score_multi.hpp); else the packed kernel
   uint64_t n_postings = 0, n_postings_essential = 0, n_rounds = 0;
@@ -552,24 +554,11 @@ void validate_segment(const slg_segment_desc &d, uint32_t si, bool deep) {
   }
 }
 
-// Wait for a stream whose work is expected to finish within microseconds (a descriptor upload, a small
-// batch's kernels + result copy): poll it for up to kSpinWaitUs before falling back to the blocking wait.
-// hipStreamSynchronize sleeps on an interrupt; the sleep / wake-up cycle costs tens of microseconds,
-// which is the whole latency of a small batch (the request coalescer's batches: measured 0.41 ms in
-// fetch + destroy for a 23-query batch whose kernels take ~40 us).
-constexpr int kSpinWaitUs = 400;
-static inline hipError_t wait_stream(hipStream_t st) {
-  const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(kSpinWaitUs);
-  for (;;) {
-    const hipError_t e = hipStreamQuery(st);
-    if (e != hipErrorNotReady) return e;
-    if (std::chrono::steady_clock::now() >= until) break;
-#if defined(__x86_64__)
-    __builtin_ia32_pause();
-#endif
-  }
-  return hipStreamSynchronize(st);
-}
+// Waiting for a stream is the blocking hipStreamSynchronize.  (Polling hipStreamQuery first — to spare a
+// small batch the sleep / wake-up of the blocking wait — was built and measured: with 8 caller threads
+// polling, config 2's host-inclusive rate fell from 11M to 2.2M queries/s and fetch + destroy grew from
+// 0.28 to 1.36 ms per batch: the query takes a runtime lock the other threads' launches and copies need.)
+static inline hipError_t wait_stream(hipStream_t st) { return hipStreamSynchronize(st); }
 
 static inline hipStream_t batch_stream(const slg_batch *b) {
   return b->own_stream_set ? b->stream : b->idx->stream;
@@ -1210,6 +1199,15 @@ int slg_index_remove_segment(slg_index *ix, uint32_t seg) {
   });
 }
 
+int slg_index_device(const slg_index *ix) {
+  if (!ix) {
+    g_last_error = "index is NULL";
+    g_last_code = SLG_ERR_INVALID;
+    return SLG_ERR_INVALID;
+  }
+  return ix->device;
+}
+
 uint64_t slg_index_generation(const slg_index *ix) {
   return ix ? ix->generation.load(std::memory_order_acquire) : 0;  // (no lock: callers poll it per request)
 }
@@ -1294,6 +1292,7 @@ slg_batch *slg_batch_prepare_plans(slg_index *ix, uint32_t nq, const uint32_t *q
     b->multi = plan.multi;
     b->plan_batch = plan.plan_batch;
     b->nested = plan.nested;
+    b->deep = plan.deep;
     b->pruned = plan.pruned;
     b->cand_mode = plan.cand_mode;
     b->n_sq = (uint32_t)plan.sqs.size();
@@ -1335,6 +1334,7 @@ slg_batch *slg_batch_prepare_plans(slg_index *ix, uint32_t nq, const uint32_t *q
     b->d_slice_order = reinterpret_cast<const uint32_t *>(db + plan.o_sord);
     b->d_queries = reinterpret_cast<const slg::QueryRef *>(db + plan.o_q);
     b->d_bnd_coarse = reinterpret_cast<const uint32_t *>(db + plan.o_bc);
+    b->d_nodes = reinterpret_cast<const slg::PlanNode *>(db + plan.o_nodes);
     b->d_bounds.alloc_pooled(&ix->pool, (size_t)plan.n_bounds * 4);
     b->d_rdoc.alloc_pooled(&ix->pool, (size_t)plan.n_bnd * 4);
     b->d_slice_desc.alloc_pooled(&ix->pool, (size_t)b->n_slices * sizeof(slg::SliceDesc));
@@ -1438,7 +1438,8 @@ int slg_batch_run(slg_batch *b) {
       sp.slice_desc = b->d_slice_desc.as<slg::SliceDesc>();
       sp.reject_table = S.d_reject_table.as<const uint32_t *>();
       sp.n_segs = (uint32_t)S.segs.size();
-      sp.plan_batch = b->plan_batch ? (b->nested ? 2u : 1u) : 0u;
+      sp.plan_batch = b->plan_batch ? (b->deep ? 4u : (b->nested ? 2u : 1u)) : 0u;
+      sp.plan_nodes = b->d_nodes;
       sp.cand = b->d_cand.as<uint2>();
       sp.slice_cbeg = b->d_slice_cbeg.as<uint64_t>();
       sp.slice_ccnt = b->d_slice_ccnt.as<uint32_t>();

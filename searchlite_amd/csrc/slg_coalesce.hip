@@ -8,21 +8,19 @@
 // thread blocks in slg_coalescer_search with ITS query; concurrent callers are collected into one
 // slg_batch_prepare / run / fetch and each gets its own row back.
 //
-// Mechanism: leader / followers.  The first caller to find no open batch opens one and becomes its
-// leader; callers that arrive while it is open append their query (same k, strategy and segment
-// count: a "kind"; other kinds collect in batches of their own).  The leader closes the batch when it
-// is full (max_batch) or max_wait_us after opening it — right away if the device is idle, i.e. no
-// other batch of this coalescer is in flight (a lone request never waits) — then plans, runs and
-// fetches it on a HIP stream of its own while the NEXT batch is already collecting behind a new
-// leader: several batches are in flight at once, which is what keeps the device fed.  Followers spin
-// briefly, then sleep on the batch's condition variable, and copy their row out after the leader's fetch.
-//
-// Joining a batch takes no lock: a row is ONE fetch_add on the batch's ticket counter (the first
-// version took a mutex per request: with 256 caller threads the leaders spent 0.4 ms of every batch
-// queueing for it); the query is written into the row's fixed-size slot, `ready` counts the rows
-// written.  Closing = setting the counter's top bit (later tickets bounce and open the next batch).
-// Batch objects are recycled per kind, so a caller that still holds the pointer of a batch that has
-// been recycled meanwhile joins a batch of its own kind or bounces — never a foreign one.
+// Mechanism.  A caller takes a ROW of the batch that is collecting: ONE fetch_add on the batch's ticket
+// counter, no lock (a mutex per request made 256 callers queue for 0.4 ms per batch), writes its query
+// into the row's fixed-size slot and sleeps (a short spin first) until the batch's results are in.  Two
+// threads of the coalescer own every HIP call: the SUBMITTER closes the collecting batch — when it is
+// full (max_batch), max_wait_us after its first row, or at once if nothing else is in flight (a lone
+// request never waits) —, swaps a fresh batch in for the callers that keep arriving, plans and launches
+// the closed one on a stream of its own; the COLLECTOR fetches the launched batches in order and wakes
+// their callers.  (Letting one of a batch's callers do the planning, launching and fetching — leader /
+// followers — was built first: with a dozen leaders inside the HIP runtime at once, prepare took 0.24 ms
+// and fetch 0.41 ms for 23-query batches whose kernels take ~40 us; polling the stream instead of the
+// blocking wait made it worse.)  Batches of different kinds — (k, strategy, segment count) — collect
+// side by side.  Batch objects are recycled per kind, so a caller that still holds the pointer of a
+// batch that has been closed and reopened meanwhile joins a batch of its own kind or bounces.
 //
 // Host code on top of the public ABI (no kernels here; HIP only for the leaders' streams); part of
 // libsearchlite_gpu.so.
@@ -32,6 +30,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -44,6 +43,7 @@ namespace {
 
 constexpr uint32_t kClosed = 0x80000000u;  // ticket counter: top bit = the batch takes no more rows
 constexpr int kMaxKinds = 8;               // (k, strategy, segment count) combinations collecting at once
+using Clock = std::chrono::steady_clock;
 
 inline void cpu_relax() {
 #if defined(__x86_64__)
@@ -60,9 +60,11 @@ struct CoBatch {
   int strategy = 0;
   uint32_t n_segs = 0, slot_terms = 0, cap = 0;
   std::atomic<uint32_t> tickets{kClosed};  // rows handed out; >= kClosed: closed
-  uint32_t nq = 0;                         // rows of the closed batch (set by its leader)
+  uint32_t nq = 0;                         // rows of the closed batch (set by the submitter)
   std::atomic<uint32_t> ready{0};          // rows written
   std::atomic<uint32_t> leaving{0};        // callers that have copied their result out
+  Clock::time_point first_seen{};          // when the submitter first saw a row in it
+  bool seen = false;
   std::vector<uint32_t> slot_ids, slot_nt;
   std::vector<float> slot_w;
   // per-row score plan and doc filter (slg_coalescer_search_plan); plain rows: leaf i = term i, Sum, no filter
@@ -70,7 +72,7 @@ struct CoBatch {
   std::vector<int32_t> slot_plan, slot_filter;
   std::vector<float> slot_tie;
   std::atomic<bool> want_stats{false}, any_plan{false}, any_filter{false};
-  // the closed batch as CSR (built by the leader), and its results
+  // the closed batch as CSR (built by the submitter), and its results
   std::vector<uint32_t> offs, term_ids, leaves;
   std::vector<float> weights;
   std::vector<uint32_t> doc, seg, count;
@@ -80,8 +82,7 @@ struct CoBatch {
   std::string error;
   std::mutex mu;
   std::condition_variable cv;
-  std::atomic<bool> done{false};  // results are in (followers spin on it, then sleep on cv)
-  std::atomic<bool> full{false};  // the leader's wake-up: max_batch reached
+  std::atomic<bool> done{false};  // results are in (callers spin on it, then sleep on cv)
   int kind = 0;
 };
 
@@ -89,10 +90,17 @@ struct Kind {
   std::atomic<bool> used{false};
   uint32_t k = 0, n_segs = 0;
   int strategy = 0;
-  std::atomic<CoBatch *> cur{nullptr};  // the batch that is collecting, or null
+  std::atomic<CoBatch *> cur{nullptr};  // the batch that is collecting (never null once the kind is used)
   std::mutex mu;                        // spare list
   std::vector<CoBatch *> spare;
   std::vector<CoBatch *> all;           // every batch object of the kind (destroy)
+};
+
+struct Flight {  // a launched batch on its way to the collector
+  CoBatch *b;
+  slg_batch *sb;
+  void *stream;
+  Clock::time_point launched;
 };
 
 }  // namespace
@@ -100,10 +108,19 @@ struct Kind {
 struct slg_coalescer {
   slg_index *index = nullptr;
   uint32_t max_batch = 1024, max_wait_us = 50;
+  int device = 0;
   Kind kinds[kMaxKinds];
-  std::mutex mu;                       // kind registration, stream free list
-  std::atomic<uint32_t> in_flight{0};  // batches closed and not yet fetched
-  std::vector<void *> free_streams;    // HIP streams for the leaders' batches
+  std::mutex mu;  // kind registration, stream free list
+  std::vector<void *> free_streams;
+  std::atomic<uint32_t> in_flight{0};     // batches launched and not yet fetched
+  std::atomic<uint32_t> rows_waiting{0};  // rows in collecting batches
+  std::atomic<bool> stop{false};
+  std::thread submitter, collector;
+  std::mutex wake_mu;  // the submitter sleeps here while no row is waiting
+  std::condition_variable wake_cv;
+  std::mutex q_mu;     // submitter -> collector
+  std::condition_variable q_cv;
+  std::deque<Flight> flights;
   // the index's segment count, cached per generation (slg_index_info takes the index mutex)
   std::atomic<uint64_t> seen_generation{~0ull};
   std::atomic<uint32_t> seen_n_segs{0};
@@ -115,6 +132,10 @@ struct slg_coalescer {
 namespace {
 
 thread_local std::string g_co_error;
+
+uint64_t nanos(Clock::time_point a, Clock::time_point z) {
+  return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(z - a).count();
+}
 
 void *take_stream(slg_coalescer *c) {
   {
@@ -134,29 +155,6 @@ void give_stream(slg_coalescer *c, void *s) {
   if (!s) return;
   std::lock_guard<std::mutex> lk(c->mu);
   c->free_streams.push_back(s);
-}
-
-Kind *find_kind(slg_coalescer *c, uint32_t k, int strategy, uint32_t n_segs) {
-  for (int i = 0; i < kMaxKinds; i++) {
-    Kind &kd = c->kinds[i];
-    if (kd.used.load(std::memory_order_acquire) && kd.k == k && kd.strategy == strategy && kd.n_segs == n_segs) return &kd;
-  }
-  std::lock_guard<std::mutex> lk(c->mu);
-  for (int i = 0; i < kMaxKinds; i++) {
-    Kind &kd = c->kinds[i];
-    if (kd.used.load() && kd.k == k && kd.strategy == strategy && kd.n_segs == n_segs) return &kd;
-  }
-  for (int i = 0; i < kMaxKinds; i++) {
-    Kind &kd = c->kinds[i];
-    if (!kd.used.load()) {
-      kd.k = k;
-      kd.strategy = strategy;
-      kd.n_segs = n_segs;
-      kd.used.store(true, std::memory_order_release);
-      return &kd;
-    }
-  }
-  return nullptr;
 }
 
 // a closed, reset batch object of the kind (recycled or new)
@@ -191,20 +189,55 @@ CoBatch *fresh_batch(slg_coalescer *c, Kind &kd) {
   b->nq = 0;
   b->ready.store(0);
   b->leaving.store(0);
+  b->seen = false;
   b->want_stats.store(false);
   b->any_plan.store(false);
   b->any_filter.store(false);
   b->done.store(false);
-  b->full.store(false);
   b->rc = SLG_OK;
   b->error.clear();
   return b;
 }
 
-// the leader's part: plan + run + fetch the closed batch, publish the results
-void run_batch(slg_coalescer *c, CoBatch &b) {
-  // every reserved row has been written?  (writers are a few stores behind their ticket)
-  while (b.ready.load(std::memory_order_acquire) < b.nq) cpu_relax();
+Kind *find_kind(slg_coalescer *c, uint32_t k, int strategy, uint32_t n_segs) {
+  for (int i = 0; i < kMaxKinds; i++) {
+    Kind &kd = c->kinds[i];
+    if (kd.used.load(std::memory_order_acquire) && kd.k == k && kd.strategy == strategy && kd.n_segs == n_segs) return &kd;
+  }
+  std::lock_guard<std::mutex> lk(c->mu);
+  for (int i = 0; i < kMaxKinds; i++) {
+    Kind &kd = c->kinds[i];
+    if (kd.used.load() && kd.k == k && kd.strategy == strategy && kd.n_segs == n_segs) return &kd;
+  }
+  for (int i = 0; i < kMaxKinds; i++) {
+    Kind &kd = c->kinds[i];
+    if (!kd.used.load()) {
+      kd.k = k;
+      kd.strategy = strategy;
+      kd.n_segs = n_segs;
+      CoBatch *nb = fresh_batch(c, kd);
+      nb->tickets.store(0, std::memory_order_release);  // open
+      kd.cur.store(nb, std::memory_order_release);
+      kd.used.store(true, std::memory_order_release);
+      return &kd;
+    }
+  }
+  return nullptr;
+}
+
+void publish(CoBatch &b, int rc, const char *err) {
+  b.rc = rc;
+  if (err) b.error = err;
+  {
+    std::lock_guard<std::mutex> lk(b.mu);
+    b.done.store(true, std::memory_order_release);
+  }
+  b.cv.notify_all();
+}
+
+// the submitter's part for one closed batch: CSR, plan, launch
+void launch_batch(slg_coalescer *c, CoBatch &b) {
+  while (b.ready.load(std::memory_order_acquire) < b.nq) cpu_relax();  // (writers are a few stores behind their ticket)
   const uint32_t nq = b.nq, ns = b.n_segs;
   b.offs.resize((size_t)nq + 1);
   b.offs[0] = 0;
@@ -225,43 +258,100 @@ void run_batch(slg_coalescer *c, CoBatch &b) {
   b.seg.resize(n ? n : 1);
   b.score.resize(n ? n : 1);
   b.count.resize(nq);
-  const bool want_stats = b.want_stats.load();
-  if (want_stats) b.stats.assign(nq, slg_stats{});
+  if (b.want_stats.load()) b.stats.assign(nq, slg_stats{});
   void *stream = take_stream(c);
-  const auto t0 = std::chrono::steady_clock::now();
+  const auto t0 = Clock::now();
   slg_batch *sb = slg_batch_prepare_plan(c->index, nq, b.offs.data(), b.term_ids.data(), b.weights.data(),
                                          plans ? b.leaves.data() : nullptr, plans ? b.slot_plan.data() : nullptr,
                                          plans ? b.slot_tie.data() : nullptr, plans ? b.slot_nleaves.data() : nullptr,
                                          filters ? b.slot_filter.data() : nullptr, b.k, b.strategy);
-  const auto t1 = std::chrono::steady_clock::now();
+  const auto t1 = Clock::now();
   int rc = sb ? SLG_OK : slg_last_error_code();
   if (sb && stream) rc = slg_batch_set_stream(sb, stream);
   if (sb && rc == SLG_OK) rc = slg_batch_run(sb);
-  const auto t2 = std::chrono::steady_clock::now();
-  // the leader polls for the batch's kernels (a blocking stream wait costs a sleep / wake-up of tens of
-  // microseconds on a batch that takes about as long): a batch has ONE leader, the followers sleep
-  if (sb && rc == SLG_OK && stream)
-    while (hipStreamQuery((hipStream_t)stream) == hipErrorNotReady) cpu_relax();
-  if (sb && rc == SLG_OK)
-    rc = slg_batch_fetch(sb, b.doc.data(), b.seg.data(), b.score.data(), b.count.data(),
-                         want_stats ? b.stats.data() : nullptr);
-  if (rc != SLG_OK) b.error = slg_last_error();
-  if (sb) slg_batch_destroy(sb);
-  const auto t3 = std::chrono::steady_clock::now();
-  auto nanos = [](auto a, auto z) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(z - a).count(); };
+  const auto t2 = Clock::now();
   c->ns_prepare += nanos(t0, t1);
   c->ns_run += nanos(t1, t2);
-  c->ns_fetch += nanos(t2, t3);
-  give_stream(c, stream);
-  c->in_flight.fetch_sub(1);
-  c->n_batches.fetch_add(1);
-  c->n_queries.fetch_add(nq);
-  b.rc = rc;
-  {
-    std::lock_guard<std::mutex> lk(b.mu);
-    b.done.store(true, std::memory_order_release);
+  if (rc != SLG_OK) {
+    const std::string err = slg_last_error();
+    if (sb) slg_batch_destroy(sb);
+    give_stream(c, stream);
+    c->n_batches.fetch_add(1);
+    publish(b, rc, err.c_str());
+    return;
   }
-  b.cv.notify_all();
+  c->in_flight.fetch_add(1);
+  {
+    std::lock_guard<std::mutex> lk(c->q_mu);
+    c->flights.push_back(Flight{&b, sb, stream, t2});
+  }
+  c->q_cv.notify_one();
+}
+
+void submitter_main(slg_coalescer *c) {
+  (void)hipSetDevice(c->device);
+  while (!c->stop.load(std::memory_order_acquire)) {
+    if (c->rows_waiting.load(std::memory_order_acquire) == 0) {  // nothing collecting: sleep until a first row arrives
+      std::unique_lock<std::mutex> lk(c->wake_mu);
+      c->wake_cv.wait_for(lk, std::chrono::milliseconds(2), [&] {
+        return c->rows_waiting.load(std::memory_order_acquire) != 0 || c->stop.load(std::memory_order_acquire);
+      });
+      continue;
+    }
+    const auto now = Clock::now();
+    for (int i = 0; i < kMaxKinds; i++) {
+      Kind &kd = c->kinds[i];
+      if (!kd.used.load(std::memory_order_acquire)) continue;
+      CoBatch *b = kd.cur.load(std::memory_order_acquire);
+      const uint32_t t = b->tickets.load(std::memory_order_acquire);
+      if (t == 0u || (t & kClosed)) continue;
+      if (!b->seen) {
+        b->seen = true;
+        b->first_seen = now;
+      }
+      // close: full, or max_wait_us after its first row — at once if nothing else is in flight (an idle
+      // device: waiting would only add latency; under load the batches in flight give it time to fill)
+      const bool full = t >= c->max_batch;
+      const bool idle = c->in_flight.load(std::memory_order_acquire) == 0;
+      const bool aged = nanos(b->first_seen, now) >= (uint64_t)c->max_wait_us * 1000ull;
+      if (!(full || idle || aged)) continue;
+      CoBatch *nb = fresh_batch(c, kd);
+      nb->tickets.store(0, std::memory_order_release);  // open
+      kd.cur.store(nb, std::memory_order_release);      // arriving callers go there from now on
+      const uint32_t had = b->tickets.fetch_or(kClosed, std::memory_order_acq_rel);
+      b->nq = had < c->max_batch ? had : c->max_batch;
+      c->rows_waiting.fetch_sub(b->nq, std::memory_order_acq_rel);
+      c->ns_collect += nanos(b->first_seen, Clock::now());
+      launch_batch(c, *b);
+    }
+    cpu_relax();
+  }
+}
+
+void collector_main(slg_coalescer *c) {
+  (void)hipSetDevice(c->device);
+  for (;;) {
+    Flight f{};
+    {
+      std::unique_lock<std::mutex> lk(c->q_mu);
+      c->q_cv.wait(lk, [&] { return !c->flights.empty() || c->stop.load(std::memory_order_acquire); });
+      if (c->flights.empty()) return;  // stop, and nothing left to collect
+      f = c->flights.front();
+      c->flights.pop_front();
+    }
+    CoBatch &b = *f.b;
+    const auto t0 = Clock::now();
+    int rc = slg_batch_fetch(f.sb, b.doc.data(), b.seg.data(), b.score.data(), b.count.data(),
+                             b.want_stats.load() ? b.stats.data() : nullptr);
+    const std::string err = rc != SLG_OK ? slg_last_error() : "";
+    slg_batch_destroy(f.sb);
+    give_stream(c, f.stream);
+    c->ns_fetch += nanos(t0, Clock::now());
+    c->in_flight.fetch_sub(1);
+    c->n_batches.fetch_add(1);
+    c->n_queries.fetch_add(b.nq);
+    publish(b, rc, rc != SLG_OK ? err.c_str() : nullptr);
+  }
 }
 
 }  // namespace
@@ -270,16 +360,29 @@ extern "C" {
 
 slg_coalescer *slg_coalescer_create(slg_index *index, uint32_t max_batch, uint32_t max_wait_us) {
   if (!index) return nullptr;
+  const int dev = slg_index_device(index);
+  if (dev < 0) return nullptr;
   auto *c = new slg_coalescer();
   c->index = index;
+  c->device = dev;
   c->max_batch = max_batch ? (max_batch < kClosed / 2 ? max_batch : 1024u) : 1024u;
   c->max_wait_us = max_wait_us;
+  c->submitter = std::thread(submitter_main, c);
+  c->collector = std::thread(collector_main, c);
   return c;
 }
 
 // (no caller may be inside slg_coalescer_search)
 void slg_coalescer_destroy(slg_coalescer *c) {
   if (!c) return;
+  c->stop.store(true, std::memory_order_release);
+  c->wake_cv.notify_all();
+  if (c->submitter.joinable()) c->submitter.join();
+  {
+    std::lock_guard<std::mutex> lk(c->q_mu);
+  }
+  c->q_cv.notify_all();
+  if (c->collector.joinable()) c->collector.join();
   for (void *s : c->free_streams) (void)hipStreamDestroy((hipStream_t)s);
   for (Kind &kd : c->kinds)
     for (CoBatch *b : kd.all) delete b;
@@ -340,39 +443,22 @@ int slg_coalescer_search_plan(slg_coalescer *c, const slg_query *query, const ui
     g_co_error = "too many (k, strategy) combinations collecting at once";
     return SLG_ERR_UNSUPPORTED;
   }
-  // ---- a row: one fetch_add on the collecting batch's ticket counter, or a batch of my own ----
+  // ---- a row: one fetch_add on the collecting batch's ticket counter ----
   CoBatch *b = nullptr;
   uint32_t row = 0;
-  bool leader = false;
   for (;;) {
     b = kd->cur.load(std::memory_order_acquire);
-    if (b) {
-      const uint32_t t = b->tickets.fetch_add(1, std::memory_order_acq_rel);
-      if (t < c->max_batch) {  // (closed: t >= kClosed; full: t >= max_batch)
-        row = t;
-        break;
-      }
-      if (kd->cur.load(std::memory_order_acquire) != b) continue;  // the next batch is already collecting
+    const uint32_t t = b->tickets.fetch_add(1, std::memory_order_acq_rel);
+    if (t < c->max_batch) {  // (closed: t >= kClosed; full: t >= max_batch)
+      row = t;
+      break;
     }
-    // no batch is collecting: open one (row 0 is mine) and publish it
-    CoBatch *nb = fresh_batch(c, *kd);
-    nb->tickets.store(1, std::memory_order_release);
-    CoBatch *expect = b;
-    if (!kd->cur.compare_exchange_strong(expect, nb, std::memory_order_acq_rel)) {
-      // another caller published its batch first: join that one — unless somebody already joined mine
-      // (a caller that still held the pointer of this recycled object), then it runs as it is
-      const uint32_t had = nb->tickets.exchange(kClosed, std::memory_order_acq_rel);
-      if (had == 1u) {
-        std::lock_guard<std::mutex> lk(kd->mu);
-        kd->spare.push_back(nb);
-        continue;
-      }
-      nb->tickets.store(had, std::memory_order_release);  // (reopen: rows 1 .. had-1 are real callers)
+    // closed or full: the submitter swaps the next batch in within microseconds
+    if (c->stop.load(std::memory_order_acquire)) {
+      g_co_error = "coalescer is being destroyed";
+      return SLG_ERR_INVALID;
     }
-    b = nb;
-    row = 0;
-    leader = true;
-    break;
+    while (kd->cur.load(std::memory_order_acquire) == b && !c->stop.load(std::memory_order_relaxed)) cpu_relax();
   }
   // ---- my row ----
   b->slot_nt[row] = query->n_terms;
@@ -396,40 +482,16 @@ int slg_coalescer_search_plan(slg_coalescer *c, const slg_query *query, const ui
   if (filter_id >= 0) b->any_filter.store(true);
   if (stats_or_null) b->want_stats.store(true);
   b->ready.fetch_add(1, std::memory_order_release);
-  if (!leader && row + 1 == c->max_batch) {  // the row that filled the batch wakes its leader
+  if (c->rows_waiting.fetch_add(1, std::memory_order_acq_rel) == 0) {  // the first waiting row wakes the submitter
     {
-      std::lock_guard<std::mutex> bl(b->mu);
-      b->full.store(true);
+      std::lock_guard<std::mutex> lk(c->wake_mu);
     }
-    b->cv.notify_all();
+    c->wake_cv.notify_one();
   }
-  if (leader) {
-    const auto tc0 = std::chrono::steady_clock::now();
-    // collect: until full, or max_wait_us — unless nothing else is in flight (an idle device: waiting
-    // would only add latency; under load the batches in flight give the next one time to fill)
-    if (c->max_wait_us != 0 && c->in_flight.load() != 0 && c->max_batch > 1) {
-      const auto until = tc0 + std::chrono::microseconds(c->max_wait_us);
-      if (c->max_wait_us <= 200) {  // short waits: poll (a timed sleep overshoots by more than the wait)
-        while (!b->full.load() && b->tickets.load(std::memory_order_relaxed) < c->max_batch &&
-               std::chrono::steady_clock::now() < until)
-          cpu_relax();
-      } else {
-        std::unique_lock<std::mutex> bl(b->mu);
-        b->cv.wait_until(bl, until, [&] { return b->full.load(); });
-      }
-    }
-    // close: later tickets bounce (and open the next batch); rows = the tickets handed out so far
-    const uint32_t t = b->tickets.fetch_or(kClosed, std::memory_order_acq_rel);
-    b->nq = t < c->max_batch ? t : c->max_batch;
-    CoBatch *expect = b;
-    (void)kd->cur.compare_exchange_strong(expect, nullptr, std::memory_order_acq_rel);
-    c->in_flight.fetch_add(1);
-    c->ns_collect += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tc0).count();
-    run_batch(c, *b);
-  } else {
-    // a short spin (the batch is usually a few tens of microseconds from done once it is full), then sleep
-    const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(20);
-    while (!b->done.load(std::memory_order_acquire) && std::chrono::steady_clock::now() < spin_until) cpu_relax();
+  // ---- wait: a short spin (a batch is tens of microseconds from done once launched), then sleep ----
+  {
+    const auto spin_until = Clock::now() + std::chrono::microseconds(20);
+    while (!b->done.load(std::memory_order_acquire) && Clock::now() < spin_until) cpu_relax();
     if (!b->done.load(std::memory_order_acquire)) {
       std::unique_lock<std::mutex> bl(b->mu);
       b->cv.wait(bl, [&] { return b->done.load(std::memory_order_acquire); });

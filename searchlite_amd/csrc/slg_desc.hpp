@@ -88,6 +88,21 @@ struct RoundQuery {  // sub-query = (query, segment) pair with >= 1 non-empty te
   // Set by the host planner from its mirror of the champion table; never with a doc filter (it
   // may reject the champions) or a negative weight.
   float theta0;
+  // deep score trees (slg_score_plans::q_node_offsets, > 2 levels): depth = levels of Sum / DisMax nodes
+  // above the leaves (0: not a deep tree), node_begin = the query's first PlanNode in the image
+  uint32_t depth, node_begin;
+};
+
+// One Sum / DisMax node of a deep score tree, in the CANONICAL form the planner builds: every leaf hangs
+// at the same depth (a leaf higher up gets a chain of one-child Sum nodes: Sum of one child is the
+// child, bit for bit), so level l of the tree = the nodes at distance l from the root.  TermRef::gmeta
+// of a term = the node its leaf hangs off (level depth - 1).
+constexpr uint32_t kMaxPlanDepth = 4;  // = SLG_MAX_PLAN_DEPTH (searchlite_gpu.h; checked in slg_plan.cpp)
+struct PlanNode {
+  uint32_t parent;      // node index inside the query's table (the root: itself)
+  uint32_t n_children;  // children the plan gives the node (present in this segment or not)
+  uint32_t kind;        // 0 Sum, 1 DisMax
+  float tie;
 };
 
 // What a scoring wave needs to start its slice, gathered in one record per launch position by

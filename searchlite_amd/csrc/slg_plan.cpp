@@ -17,6 +17,7 @@ namespace {
   } while (0)
 
 inline uint32_t full_mask(uint32_t n) { return n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u); }
+static_assert(slg::kMaxPlanDepth == SLG_MAX_PLAN_DEPTH, "the kernels' level arrays and the ABI's depth limit");
 constexpr uint32_t kMaxPlanNodes = 255;  // leaves / groups of a two-level plan (8-bit fields of TermRef::gmeta)
 
 // ---- validation of the caller's arrays (cheap, before anything indexes through them) ------------
@@ -47,6 +48,54 @@ BatchFacts validate_batch(const BatchIn &in, uint32_t n_segs) {
     f.max_nt = std::max(f.max_nt, nt);
   }
   const slg_score_plans &pl = in.plans;
+  const bool trees = pl.q_node_offsets != nullptr;
+  PLAN_REQUIRE(!trees || (pl.node_kind && pl.node_tie && pl.node_parent), "score trees need node_kind, node_tie and node_parent");
+  if (trees) {
+    for (uint32_t q = 0; q < in.nq; q++) {
+      PLAN_REQUIRE(pl.q_node_offsets[q + 1] >= pl.q_node_offsets[q], "q_node_offsets not monotone");
+      const uint32_t n0 = pl.q_node_offsets[q], nn = pl.q_node_offsets[q + 1] - n0;
+      PLAN_REQUIRE(nn >= 1, "a score tree has no node in query " + std::to_string(q));
+      if (nn > 2 * kMaxPlanNodes)
+        throw SlgError(SLG_ERR_UNSUPPORTED, "score tree of query " + std::to_string(q) + " has too many nodes");
+      uint32_t depth_of[2 * kMaxPlanNodes + 1], kids[2 * kMaxPlanNodes + 1];
+      uint32_t n_leaf = 0, deepest = 0;
+      for (uint32_t i = 0; i < nn; i++) {
+        const int kd = pl.node_kind[n0 + i];
+        PLAN_REQUIRE(kd == SLG_PLAN_SUM || kd == SLG_PLAN_DISMAX || kd == SLG_PLAN_LEAF, "unknown node kind in query " + std::to_string(q));
+        kids[i] = 0;
+        if (i == 0) {
+          depth_of[0] = 0;
+        } else {
+          const uint32_t pa = pl.node_parent[n0 + i];
+          PLAN_REQUIRE(pa < i, "node_parent must name an earlier node (pre-order) in query " + std::to_string(q));
+          PLAN_REQUIRE(pl.node_kind[n0 + pa] != SLG_PLAN_LEAF, "a leaf node has a child in query " + std::to_string(q));
+          // pre-order: the parent is the last node before i whose depth is smaller
+          depth_of[i] = depth_of[pa] + 1;
+          PLAN_REQUIRE(pa == i - 1 || depth_of[i - 1] >= depth_of[i], "nodes are not in pre-order in query " + std::to_string(q));
+          kids[pa]++;
+        }
+        if (kd == SLG_PLAN_LEAF) {
+          n_leaf++;
+          deepest = std::max(deepest, depth_of[i]);
+        } else if (kd == SLG_PLAN_DISMAX) {
+          const float t = pl.node_tie[n0 + i];
+          PLAN_REQUIRE(t >= 0.0f && t <= 1.0f, "tie breaker outside [0, 1] in query " + std::to_string(q));
+        }
+      }
+      for (uint32_t i = 0; i < nn; i++)
+        if (pl.node_kind[n0 + i] != SLG_PLAN_LEAF && kids[i] == 0)
+          throw SlgError(SLG_ERR_UNSUPPORTED, "a Sum / DisMax node without children in query " + std::to_string(q));
+      if (n_leaf > kMaxPlanNodes) throw SlgError(SLG_ERR_UNSUPPORTED, "score tree of query " + std::to_string(q) + " has too many leaves");
+      if (deepest > SLG_MAX_PLAN_DEPTH)
+        throw SlgError(SLG_ERR_UNSUPPORTED, "score tree of query " + std::to_string(q) + " is deeper than SLG_MAX_PLAN_DEPTH");
+      const uint32_t t0 = in.q_offsets[q], nt = in.q_offsets[q + 1] - t0;
+      for (uint32_t i = 0; i < nt; i++)
+        PLAN_REQUIRE((pl.q_leaf ? pl.q_leaf[t0 + i] : i) < n_leaf, "a term names a leaf the tree does not have in query " + std::to_string(q));
+      f.plans_requested = true;  // (resolved per query: a one-level tree of single-term leaves still is the flat sum)
+      if (deepest >= 2) f.nested_requested = true;
+    }
+    return f;
+  }
   const bool groups = pl.leaf_group != nullptr;
   PLAN_REQUIRE(!groups || (pl.q_leaf_offsets && pl.q_group_offsets && pl.group_plan && pl.group_tie && pl.q_nleaves),
                "two-level plans need q_nleaves, q_leaf_offsets, q_group_offsets, group_plan and group_tie");
@@ -108,7 +157,8 @@ struct Pass1Out {
   double skip_est = 0.0;                 // postings block skipping is expected to leave unread
   uint64_t n_postings = 0, n_ess = 0, n_noness = 0;
   uint32_t max_terms = 0;
-  bool any_plan = false, any_filter = false, any_nested = false;
+  bool any_plan = false, any_filter = false, any_nested = false, any_deep = false;
+  std::vector<slg::PlanNode> nodes;  // canonical node tables of this part's deep trees
   std::exception_ptr err;
 };
 
@@ -197,32 +247,116 @@ void plan_queries(const Pass1Ctx &c, const uint32_t q_lo, const uint32_t q_hi, P
       fq = (uint32_t)in.q_filter[q] + 1u;
       o.any_filter = true;
     }
-    // score plan of the query (query/planner.rs:113-153)
-    const int plan_kind = pl.q_plan ? pl.q_plan[q] : SLG_PLAN_SUM;
-    PLAN_REQUIRE(plan_kind == SLG_PLAN_SUM || plan_kind == SLG_PLAN_DISMAX,
-                 "unknown score plan in query " + std::to_string(q));
-    const float tie = pl.q_tie ? pl.q_tie[q] : 0.0f;
-    // validate_tie_breaker (query/planner.rs:850-856); the threshold seed and the pruning bounds
-    // also rely on it: with tie in [0, 1] a DisMax is >= each of its non-negative leaves
-    PLAN_REQUIRE(tie >= 0.0f && tie <= 1.0f, "tie breaker outside [0, 1] in query " + std::to_string(q));
+    // score plan of the query (query/planner.rs:113-153): root over leaves, root over groups of leaves,
+    // or (slg_score_plans::q_node_offsets) a tree given node by node, which is resolved here into one
+    // of the first two when it has one or two levels, and into a canonical node table otherwise
+    int plan_kind = pl.q_plan ? pl.q_plan[q] : SLG_PLAN_SUM;
+    float tie = pl.q_tie ? pl.q_tie[q] : 0.0f;
     uint32_t n_leaves = pl.q_nleaves ? pl.q_nleaves[q] : 0;
+    bool groups = pl.leaf_group != nullptr && pl.q_node_offsets == nullptr;
+    const uint32_t *lgroup = groups ? pl.leaf_group + pl.q_leaf_offsets[q] : nullptr;
+    uint32_t n_groups = groups ? pl.q_group_offsets[q + 1] - pl.q_group_offsets[q] : 0u;
+    const int32_t *gplan = groups ? pl.group_plan + pl.q_group_offsets[q] : nullptr;
+    const float *gtie = groups ? pl.group_tie + pl.q_group_offsets[q] : nullptr;
+    uint32_t tree_lgroup[kMaxPlanNodes + 1];
+    int32_t tree_gplan[kMaxPlanNodes + 1];
+    float tree_gtie[kMaxPlanNodes + 1];
+    uint32_t depth = 0, node_begin = 0;        // deep tree: levels of internal nodes, first canonical node
+    uint32_t leaf_node[kMaxPlanNodes + 1];     // deep tree: canonical node every leaf hangs off
+    if (pl.q_node_offsets) {
+      const uint32_t n0 = pl.q_node_offsets[q], nn = pl.q_node_offsets[q + 1] - n0;
+      const int32_t *kind = pl.node_kind + n0;
+      const float *ntie = pl.node_tie + n0;
+      const uint32_t *par = pl.node_parent + n0;
+      uint32_t dep[2 * kMaxPlanNodes + 1];
+      uint32_t deepest = 0;
+      n_leaves = 0;
+      for (uint32_t i = 0; i < nn; i++) {
+        dep[i] = i == 0 ? 0u : dep[par[i]] + 1u;
+        if (kind[i] == SLG_PLAN_LEAF) {
+          n_leaves++;
+          deepest = std::max(deepest, dep[i]);
+        }
+      }
+      if (kind[0] == SLG_PLAN_LEAF) {  // the plan is one leaf: Sum of one leaf
+        plan_kind = SLG_PLAN_SUM;
+        tie = 0.0f;
+      } else if (deepest <= 2) {  // root over leaves, or root over groups: the forms above
+        plan_kind = kind[0];
+        tie = kind[0] == SLG_PLAN_DISMAX ? ntie[0] : 0.0f;
+        if (deepest == 2) {
+          groups = true;
+          n_groups = 0;
+          uint32_t lf = 0;
+          for (uint32_t i = 1; i < nn; i++) {
+            if (dep[i] == 1) {  // a child of the root: a group (a bare leaf = a Sum group of one leaf)
+              tree_gplan[n_groups] = kind[i] == SLG_PLAN_DISMAX ? SLG_PLAN_DISMAX : SLG_PLAN_SUM;
+              tree_gtie[n_groups] = kind[i] == SLG_PLAN_DISMAX ? ntie[i] : 0.0f;
+              n_groups++;
+            }
+            if (kind[i] == SLG_PLAN_LEAF) tree_lgroup[lf++] = n_groups - 1u;
+          }
+          lgroup = tree_lgroup;
+          gplan = tree_gplan;
+          gtie = tree_gtie;
+        }
+      } else {
+        // deep tree: canonical node table — the internal nodes in pre-order, and under every leaf that
+        // hangs above the deepest level a chain of one-child Sum nodes down to it
+        depth = deepest;
+        plan_kind = kind[0];
+        tie = kind[0] == SLG_PLAN_DISMAX ? ntie[0] : 0.0f;
+        node_begin = (uint32_t)o.nodes.size();
+        uint32_t canon[2 * kMaxPlanNodes + 1];  // original internal node -> canonical index
+        uint32_t lf = 0;
+        for (uint32_t i = 0; i < nn; i++) {
+          if (kind[i] != SLG_PLAN_LEAF) {
+            canon[i] = (uint32_t)o.nodes.size() - node_begin;
+            slg::PlanNode pn{};
+            pn.parent = i == 0 ? 0u : canon[par[i]];
+            pn.n_children = 0;
+            pn.kind = kind[i] == SLG_PLAN_DISMAX ? 1u : 0u;
+            pn.tie = kind[i] == SLG_PLAN_DISMAX ? ntie[i] : 0.0f;
+            o.nodes.push_back(pn);
+            if (i != 0) o.nodes[node_begin + canon[par[i]]].n_children++;
+          } else {
+            uint32_t above = canon[par[i]];
+            o.nodes[node_begin + above].n_children++;
+            for (uint32_t d = dep[i]; d < deepest; d++) {  // pad: Sum of one child
+              slg::PlanNode pn{};
+              pn.parent = above;
+              pn.n_children = 1;
+              pn.kind = 0u;
+              pn.tie = 0.0f;
+              above = (uint32_t)o.nodes.size() - node_begin;
+              o.nodes.push_back(pn);
+            }
+            leaf_node[lf++] = above;
+          }
+        }
+      }
+    } else {
+      PLAN_REQUIRE(plan_kind == SLG_PLAN_SUM || plan_kind == SLG_PLAN_DISMAX,
+                   "unknown score plan in query " + std::to_string(q));
+      // validate_tie_breaker (query/planner.rs:850-856); the threshold seed and the pruning bounds
+      // also rely on it: with tie in [0, 1] a DisMax is >= each of its non-negative leaves
+      PLAN_REQUIRE(tie >= 0.0f && tie <= 1.0f, "tie breaker outside [0, 1] in query " + std::to_string(q));
+    }
     for (uint32_t i = 0; i < nt; i++) {
       const uint32_t lf = pl.q_leaf ? pl.q_leaf[t0 + i] : i;
       PLAN_REQUIRE(lf < 0x80000000u, "leaf index >= 2^31 in query " + std::to_string(q));
       n_leaves = std::max(n_leaves, lf + 1u);
     }
     // two-level plan: group of every leaf, leaves per group
-    const bool groups = pl.leaf_group != nullptr;
-    const uint32_t *lgroup = groups ? pl.leaf_group + pl.q_leaf_offsets[q] : nullptr;
-    const uint32_t n_groups = groups ? pl.q_group_offsets[q + 1] - pl.q_group_offsets[q] : 0u;
     uint32_t leaves_in_group[kMaxPlanNodes + 1];  // (zeroed only for queries with groups: 1 KB per query otherwise)
     bool nested = false;
     if (groups) {
       std::memset(leaves_in_group, 0, sizeof(leaves_in_group));
-      PLAN_REQUIRE(n_leaves == pl.q_nleaves[q], "a term names a leaf beyond q_nleaves in query " + std::to_string(q));
+      if (!pl.q_node_offsets)
+        PLAN_REQUIRE(n_leaves == pl.q_nleaves[q], "a term names a leaf beyond q_nleaves in query " + std::to_string(q));
       for (uint32_t l = 0; l < n_leaves; l++) leaves_in_group[lgroup[l]]++;
       for (uint32_t g = 0; g < n_groups; g++)
-        if (leaves_in_group[g] != 1 || pl.group_plan[pl.q_group_offsets[q] + g] == SLG_PLAN_DISMAX) nested = true;
+        if (leaves_in_group[g] != 1 || gplan[g] == SLG_PLAN_DISMAX) nested = true;
     }
     if (k == 0) continue;  // wand.rs:413-416: k == 0 and no collector => no work
     for (uint32_t s = 0; s < n_segs; s++) {
@@ -247,11 +381,12 @@ void plan_queries(const Pass1Ctx &c, const uint32_t q_lo, const uint32_t q_hi, P
         tr.weight = w;
         tr.term = tid;
         tr.leaf = pl.q_leaf ? pl.q_leaf[t0 + i] : i;
-        if (nested) {
+        if (depth) {
+          tr.gmeta = leaf_node[tr.leaf];  // the canonical node the leaf hangs off
+        } else if (nested) {
           const uint32_t g = lgroup[tr.leaf];
-          const uint32_t go = pl.q_group_offsets[q] + g;
-          tr.gmeta = g | (leaves_in_group[g] << 8) | ((pl.group_plan[go] == SLG_PLAN_DISMAX ? 1u : 0u) << 16);
-          tr.gtie = pl.group_tie[go];
+          tr.gmeta = g | (leaves_in_group[g] << 8) | ((gplan[g] == SLG_PLAN_DISMAX ? 1u : 0u) << 16);
+          tr.gtie = gtie[g];
         }
         terms.push_back(tr);
       }
@@ -273,13 +408,16 @@ void plan_queries(const Pass1Ctx &c, const uint32_t q_lo, const uint32_t q_hi, P
           present += fresh ? 1u : 0u;
           shared = shared || !fresh;
         }
-        sq.plan = plan_kind == SLG_PLAN_DISMAX ? 2u : ((shared || nested) ? 1u : 0u);
+        sq.plan = plan_kind == SLG_PLAN_DISMAX ? 2u : ((shared || nested || depth) ? 1u : 0u);
         sq.tie = tie;
         sq.max_init = present < n_leaves ? 0.0f : -INFINITY;
         sq.n_leaves = n_leaves;
         sq.n_groups = nested ? n_groups : 0u;
+        sq.depth = depth;
+        sq.node_begin = node_begin;
         if (sq.plan) o.any_plan = true;
         if (nested) o.any_nested = true;
+        if (depth) o.any_deep = true;
       }
       sq.theta0 = threshold_seed(sh, first, sq.n_terms, k, fq);
       // MaxScore: by default for batches with a query of >= 5 terms (plan_batch drops the
@@ -551,6 +689,7 @@ void Plan::layout() {
   o_sord = place<uint32_t>(cur, slice_order.size());
   o_q = place<slg::QueryRef>(cur, qrefs.size());
   o_bc = place<uint32_t>(cur, bnd_coarse.size());
+  o_nodes = place<slg::PlanNode>(cur, nodes.size());
   image_bytes = (cur + 15) & ~(size_t)15;
 }
 
@@ -562,6 +701,7 @@ void Plan::pack(unsigned char *hb) const {
   if (!slice_order.empty()) std::memcpy(hb + o_sord, slice_order.data(), slice_order.size() * 4);
   if (!qrefs.empty()) std::memcpy(hb + o_q, qrefs.data(), qrefs.size() * sizeof(slg::QueryRef));
   if (!bnd_coarse.empty()) std::memcpy(hb + o_bc, bnd_coarse.data(), bnd_coarse.size() * 4);
+  if (!nodes.empty()) std::memcpy(hb + o_nodes, nodes.data(), nodes.size() * sizeof(slg::PlanNode));
 }
 
 void plan_batch(const std::vector<SegView> &segs, const slg_tuning &tn, const BatchIn &in, Plan &out) {
@@ -612,6 +752,13 @@ void plan_batch(const std::vector<SegView> &segs, const slg_tuning &tn, const Ba
       const uint32_t sq_base = (uint32_t)out.sqs.size(), term_base = (uint32_t)out.terms.size();
       const uint32_t q_lo = lo_of(t), q_hi = t + 1 == n_thr ? nq : lo_of(t + 1);
       for (uint32_t q = q_lo; q < q_hi; q++) q_sq_begin[q] += sq_base;
+      {
+        const uint32_t node_base = (uint32_t)out.nodes.size();
+        if (node_base)
+          for (auto &sq : pt.sqs)
+            if (sq.depth) sq.node_begin += node_base;
+        out.nodes.insert(out.nodes.end(), pt.nodes.begin(), pt.nodes.end());
+      }
       if (n_thr == 1) {
         out.sqs.swap(pt.sqs);
         out.terms.swap(pt.terms);
@@ -634,6 +781,7 @@ void plan_batch(const std::vector<SegView> &segs, const slg_tuning &tn, const Ba
       any_plan = any_plan || pt.any_plan;
       any_filter = any_filter || pt.any_filter;
       out.nested = out.nested || pt.any_nested;
+      out.deep = out.deep || pt.any_deep;
     }
   }
   q_sq_begin[nq] = (uint32_t)out.sqs.size();
@@ -661,7 +809,7 @@ void plan_batch(const std::vector<SegView> &segs, const slg_tuning &tn, const Ba
   // plans: Sum / DisMax over leaves of one or more terms, i.e. every multi-field query string
   // (api/reader.rs:2576-2586: `fields: None` = all text fields).  Two-level plans, more lists and
   // classified batches run on the many-term kernel
-  const bool plans_fit = !any_plan || (tn.uniform_kernel >= 4 && !out.nested && tn.uniform_plans != 0);
+  const bool plans_fit = !any_plan || (tn.uniform_kernel >= 4 && !out.nested && !out.deep && tn.uniform_plans != 0);
   out.uniform = out.max_terms <= tn.uniform_max_terms && plans_fit;
   for (const slg::RoundQuery &sq : out.sqs)
     if (sq.ess_mask != full_mask(sq.n_terms)) {

@@ -55,6 +55,7 @@ struct Plan {
   std::vector<uint32_t> slice_sq, slice_seg, slice_order;
   std::vector<slg::QueryRef> qrefs;
   std::vector<uint32_t> bnd_coarse;  // sub-query of every 32nd round boundary
+  std::vector<slg::PlanNode> nodes;  // canonical node tables of the queries with deep score trees
   std::vector<uint32_t> q_filter;    // [nq] 0 = none, f + 1 (empty when no query is filtered)
   // ---- accounting ----
   std::vector<uint64_t> q_postings;  // per query (stats.postings_advanced)
@@ -66,10 +67,11 @@ struct Plan {
   bool multi = false;       // many-term kernel
   bool plan_batch = false;  // some sub-query has a score plan
   bool nested = false;      // some sub-query has a two-level plan (groups of leaves)
+  bool deep = false;        // some sub-query has a score tree of more than two levels
   bool pruned = false;      // some sub-query has non-essential lists (MaxScore)
   bool cand_mode = false;   // k > 256 on candidates + select
   // ---- packed image layout (pack()) ----
-  size_t o_sq = 0, o_terms = 0, o_slice = 0, o_sseg = 0, o_sord = 0, o_q = 0, o_bc = 0, image_bytes = 0;
+  size_t o_sq = 0, o_terms = 0, o_slice = 0, o_sseg = 0, o_sord = 0, o_q = 0, o_bc = 0, o_nodes = 0, image_bytes = 0;
   void layout();
   void pack(unsigned char *dst) const;  // dst: image_bytes bytes
 };

@@ -21,6 +21,7 @@ struct slgp_facts {
   uint32_t n_sq, n_terms, n_slices, max_terms;
   uint32_t uniform, multi, plan_batch, nested, pruned, cand_mode;
   uint32_t sizeof_round_query, sizeof_term_ref;
+  uint32_t deep;
 };
 
 // -> opaque plan or NULL (err / code filled)
@@ -94,10 +95,11 @@ void slgp_facts_of(const void *plan, slgp_facts *f) {
   f->cand_mode = p.cand_mode;
   f->sizeof_round_query = (uint32_t)sizeof(slg::RoundQuery);
   f->sizeof_term_ref = (uint32_t)sizeof(slg::TermRef);
+  f->deep = p.deep;
 }
 
 // what: 0 sub-queries (RoundQuery), 1 terms (TermRef), 2 slice_sq, 3 slice_seg, 4 slice_order,
-// 5 query refs (2 x u32), 6 bnd_coarse, 7 q_postings (u64), 8 the packed image
+// 5 query refs (2 x u32), 6 bnd_coarse, 7 q_postings (u64), 8 the packed image, 9 deep-tree nodes (PlanNode)
 uint64_t slgp_bytes(const void *plan, int what) {
   const auto &p = *static_cast<const slgplan::Plan *>(plan);
   switch (what) {
@@ -110,6 +112,7 @@ uint64_t slgp_bytes(const void *plan, int what) {
     case 6: return p.bnd_coarse.size() * 4;
     case 7: return p.q_postings.size() * 8;
     case 8: return p.image_bytes;
+    case 9: return p.nodes.size() * sizeof(slg::PlanNode);
   }
   return 0;
 }
@@ -127,6 +130,7 @@ void slgp_copy(const void *plan, int what, void *dst) {
     case 6: src = p.bnd_coarse.data(); break;
     case 7: src = p.q_postings.data(); break;
     case 8: p.pack(static_cast<unsigned char *>(dst)); return;
+    case 9: src = p.nodes.data(); break;
   }
   const uint64_t n = slgp_bytes(plan, what);
   if (n && src) std::memcpy(dst, src, n);

@@ -216,8 +216,9 @@ struct RoundScoreParams {
   uint32_t *q_scored;   // [nq] or null
   const uint32_t *const *reject_table;  // [n_filters * n_segs] reject bitmaps (doc filters)
   uint32_t n_segs;
-  uint32_t plan_batch;  // multi kernel: 1 = some sub-query has a score plan, 2 = a two-level one
-                        // (acc / max arrays in LDS: one set, or one per level)
+  uint32_t plan_batch;  // multi kernel: 1 = some sub-query has a score plan, 2 = a two-level one, 4 = a deeper
+                        // tree (acc / max arrays in LDS: this many sets of kMultiPlanLds bytes)
+  const PlanNode *plan_nodes;  // canonical node tables of the deep trees (RoundQuery::node_begin)
   // large-k mode of the uniform kernel (k > 256): candidates instead of per-slice top-k lists
   uint2 *cand;            // {ordered score, doc}; sub-query region + posting offset of the slice
   uint64_t *slice_cbeg;   // [n_slices] first candidate slot of the slice

@@ -73,7 +73,9 @@ void launch_score_kregs<SLG_INST_KREGS>(const RoundScoreParams &sp, int kind, hi
   }
   // many lists: slots of one list each, 8 at a time (slg_score_multi.hpp)
   const size_t lds = (size_t)multi_wave_lds(SLG_INST_KREGS) + (size_t)sp.plan_batch * kMultiPlanLds;
-  if (sp.plan_batch == 2)  // two-level score plans
+  if (sp.plan_batch == 4)  // score trees of more than two levels
+    hipLaunchKernelGGL((score_multi_kernel<SLG_INST_KREGS, 4>), dim3(sp.n_slices), dim3(64), lds, st, sp);
+  else if (sp.plan_batch == 2)  // two-level score plans
     hipLaunchKernelGGL((score_multi_kernel<SLG_INST_KREGS, 3>), dim3(sp.n_slices), dim3(64), lds, st, sp);
   else if (sp.plan_batch)  // score plans (never together with pruning)
     hipLaunchKernelGGL((score_multi_kernel<SLG_INST_KREGS, 2>), dim3(sp.n_slices), dim3(64), lds, st, sp);

@@ -53,13 +53,17 @@ constexpr int multi_wave_lds(int kregs) {
 constexpr int kMultiPlanLds = 2 * kMultiCap * 4;  // acc[] and max[] of the leaf close (x2 for two-level plans)
 
 // MODE 0: flat sums; 1: the batch has MaxScore-classified sub-queries (non-essential lists are
-// only probed); 2: the batch has score plans (leaf close); 3: some of them two-level (group close).
+// only probed); 2: the batch has score plans (leaf close); 3: some of them two-level (group close);
+// 4: some of them deeper trees (a close per level, slg_desc.hpp: PlanNode).
 // Separate instantiations: the extra code of one mode costs the others registers.
+// (the tree modes hold 18 / 26 KB of LDS per wave — 2 / 1.5 waves per SIMD — so they may as well have
+//  the registers of 2 waves per SIMD: no spills)
 template <int KREGS, int MODE>
-__global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) {
+__global__ void __launch_bounds__(64, (MODE >= 3 ? 2 : 4)) score_multi_kernel(RoundScoreParams p) {
   constexpr bool MS = MODE == 1;
   constexpr bool PL = MODE >= 2;
-  constexpr bool NE = MODE == 3;  // two-level plans (its own instantiation: the group close costs registers)
+  constexpr bool NE = MODE >= 3;  // two-level plans (its own instantiation: the group close costs registers)
+  constexpr bool DEEP = MODE == 4;  // trees of 3 .. SLG_MAX_PLAN_DEPTH levels
   constexpr int NS = kUniSlots;
   constexpr bool BUF = uni_buffered(KREGS);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -120,6 +124,12 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
   const bool nested = n_groups != 0u;
   float *racc = mxv + kMultiCap;
   float *rmx = racc + kMultiCap;
+  // deep trees: level l of the canonical tree (0 = the root) accumulates in lacc(l) / lmx(l); the
+  // deepest level shares acc / mxv's place in the numbering: level l at acc + 2 * l * kMultiCap
+  const uint32_t depth = DEEP ? rfl(s.depth) : 0u;
+  const PlanNode *const nodes = DEEP ? p.plan_nodes + rfl(s.node_begin) : nullptr;
+  auto lacc = [&](const uint32_t l) { return acc + 2u * l * (uint32_t)kMultiCap; };
+  auto lmx = [&](const uint32_t l) { return acc + (2u * l + 1u) * (uint32_t)kMultiCap; };
   const gu32_t gbounds = (gu32_t)p.bounds + s.bounds_begin + (size_t)r0 * T;
   const gu32_t grdoc = (gu32_t)p.rdoc + s.rdoc_begin + r0;
 
@@ -419,6 +429,94 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
         }
         wave_fence();
       };
+      // Deeper trees (slg_score_plans::q_node_offsets; canonical form: slg_desc.hpp PlanNode): level l
+      // of the tree (0 = the root, depth - 1 = the nodes the leaves hang off) has one OPEN node at a time
+      // — the lists arrive in leaf = traversal order — with its (sum, max) of the children closed so far
+      // in lacc(l) / lmx(l).  A leaf change closes the leaf into level depth - 1, then every level whose
+      // node changes, bottom up, into the level above (Sum: the sum; DisMax: max + tie * (sum - max), a
+      // child without a posting in this chunk counting as 0.0: closed children < the node's n_children),
+      // and opens the new path's nodes from the first level that differs.
+      // (every loop over the levels is unrolled with constant indices: d_path / d_closed stay in scalar
+      //  registers instead of scratch memory)
+      constexpr int MAXD = (int)kMaxPlanDepth;
+      uint32_t d_path[MAXD] = {0u, 0u, 0u, 0u}, d_closed[MAXD] = {0u, 0u, 0u, 0u};
+      auto deep_open = [&](const int l, const uint32_t node) {
+        const float a0 = rfl(nodes[node].kind) ? 0.0f : -0.0f;  // DisMax sums from 0.0, Sum from -0.0
+        float *A = lacc((uint32_t)l), *M = lmx((uint32_t)l);
+        for (uint32_t r = lane; r < ndocs; r += 64) {
+          A[r] = a0;
+          M[r] = -INFINITY;
+        }
+        d_path[l] = node;
+        d_closed[l] = 0u;
+        wave_fence();
+      };
+      auto deep_close_leaf = [&]() {  // the current leaf's sums -> level depth - 1
+        float *A = lacc(depth - 1u), *M = lmx(depth - 1u);
+        for (uint32_t r = lane; r < ndocs; r += 64) {
+          const float c = __uint_as_float(vals[r]);
+          A[r] = A[r] + c;
+          M[r] = fmaxf(M[r], c);
+          vals[r] = 0u;
+        }
+#pragma unroll
+        for (int l = 0; l < MAXD; l++) d_closed[l] += (uint32_t)l + 1u == depth ? 1u : 0u;
+        wave_fence();
+      };
+      // the open node of level l -> level l - 1 (l >= 1), or -> vals when l == 0 (the root, at the end)
+      auto deep_close_node = [&](const int l) {
+        const PlanNode nd = nodes[d_path[l]];
+        const bool dismax = rfl(nd.kind) != 0u;
+        const float ntie = __uint_as_float(rfl(__float_as_uint(nd.tie)));
+        const bool idle = d_closed[l] < rfl(nd.n_children);
+        float *A = lacc((uint32_t)l), *M = lmx((uint32_t)l);
+        float *PA = l ? lacc((uint32_t)l - 1u) : nullptr, *PM = l ? lmx((uint32_t)l - 1u) : nullptr;
+        for (uint32_t r = lane; r < ndocs; r += 64) {
+          const float a = A[r];
+          float m = M[r];
+          if (idle) m = fmaxf(m, 0.0f);
+          const float v = dismax ? m + ntie * (a - m) : a;
+          if (l) {
+            PA[r] = PA[r] + v;
+            PM[r] = fmaxf(PM[r], v);
+          } else {
+            vals[r] = __float_as_uint(v);
+          }
+        }
+        if (l) d_closed[l > 0 ? l - 1 : 0]++;
+        wave_fence();
+      };
+      auto deep_leaf_change = [&](const uint32_t leaf_parent, const bool had_leaf) {
+        uint32_t np[MAXD] = {0u, 0u, 0u, 0u};  // the new leaf's path, root first
+        uint32_t walk = leaf_parent;
+#pragma unroll
+        for (int l = MAXD - 1; l >= 0; l--)
+          if ((uint32_t)l < depth) {
+            np[l] = walk;
+            walk = rfl(nodes[walk].parent);
+          }
+        uint32_t div = 0u;  // first level whose node changes (all of them for the chunk's first leaf)
+        if (had_leaf) {
+          deep_close_leaf();
+          div = depth;
+#pragma unroll
+          for (int l = MAXD - 1; l >= 0; l--)
+            if ((uint32_t)l < depth && np[l] != d_path[l]) div = (uint32_t)l;
+#pragma unroll
+          for (int l = MAXD - 1; l >= 1; l--)
+            if ((uint32_t)l < depth && (uint32_t)l >= div) deep_close_node(l);
+        }
+#pragma unroll
+        for (int l = 0; l < MAXD; l++)
+          if ((uint32_t)l < depth && (uint32_t)l >= div) deep_open(l, np[l]);
+      };
+      auto deep_finish = [&]() {
+        deep_close_leaf();
+#pragma unroll
+        for (int l = MAXD - 1; l >= 1; l--)
+          if ((uint32_t)l < depth) deep_close_node(l);
+        deep_close_node(0);
+      };
       uint32_t cur_leaf = 0xFFFFFFFFu;
       uint32_t consumed = 0;  // what every list consumes: its postings below the cut
       if (skipping) {
@@ -505,7 +603,9 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
           if (plan) {
             const uint32_t lf = rl(my_leaf, lst);
             if (lf != cur_leaf) {
-              if (nested) {
+              if (DEEP && depth != 0u) {
+                deep_leaf_change(rl(my_gmeta, lst), cur_leaf != 0xFFFFFFFFu);
+              } else if (nested) {
                 const uint32_t gm = rl(my_gmeta, lst);
                 if (cur_leaf != 0xFFFFFFFFu) close_group_leaf();
                 if ((gm & 0xFFu) != cur_group) {
@@ -536,7 +636,9 @@ __global__ void __launch_bounds__(64, 4) score_multi_kernel(RoundScoreParams p) 
       wave_fence();
       SLG_STAMP(4);
       if (plan) {
-        if (nested) {
+        if (DEEP && depth != 0u) {
+          deep_finish();
+        } else if (nested) {
           close_group_leaf();
           close_group(true);
         } else {

@@ -354,6 +354,68 @@ def test_two_level_score_plans(gpu, oracle, k):
         assert_same_hits(ix.search_plan(offs, terms, w, k, **flat_tree), flat, 0.0, "flat plan as one-leaf groups")
 
 
+@pytest.mark.parametrize("k", [11, 400])
+def test_deep_score_trees(gpu, oracle, k):
+    """ScoreExpr::evaluate is recursive (planner.rs:122-153): trees given node by node
+    (slg_score_plans::q_node_offsets).  One batch mixes a one-level tree (-> the root form), a two-level
+    tree (-> the group form) and trees of three and four levels (-> the many-term kernel's tree mode:
+    a close per level, leaves that hang higher up under chains of one-child Sum nodes); two segments,
+    tombstones, a term missing from one segment, negative weights (a DisMax then needs the 0.0 of its
+    absent children).  Bit-exact against the oracle's recursive evaluation."""
+    from tests.test_oracle import deep_tree_shapes
+    from tests.util import random_multifield_segment
+    rng = np.random.default_rng(900 + k)
+    vocab, F = 12, 3
+    segs = [random_multifield_segment(rng, 3000 + 500 * i, vocab, F, 10) for i in range(2)]
+    segs[0].set_deleted(list(range(3, segs[0].n_docs, 13)))
+    S, D, L = 0, 1, 2
+    shapes = deep_tree_shapes() + [
+        ([D, L, L, L, L, L, L], [.4, 0, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0, 0]),                       # one level
+        ([S, D, L, L, L, D, L, L, L], [0, .5, 0, 0, 0, 1.0, 0, 0, 0], [0, 0, 1, 1, 0, 0, 5, 5, 5]),   # two levels
+    ]
+    leaf_of_term = np.array([0, 1, 1, 2, 3, 3, 4, 5, 5], dtype=np.uint32)  # 9 terms -> 6 leaves
+    offs, terms, w, leaf, nk, nt, npar, qno = [0], [], [], [], [], [], [], [0]
+    for q in range(20):
+        kind, tie, parent = shapes[q % len(shapes)]
+        words = rng.choice(vocab, size=3, replace=False)
+        for wi, wd in enumerate(words):
+            for f in range(F):
+                t = f * vocab + int(wd)
+                terms.append([t, gpu.NO_TERM if (q % 7 == 3 and wi == 1) else t])
+                w.append(np.float32(rng.random() * 2 - (0.5 if q % 3 == 0 else 0.0)))
+        leaf += leaf_of_term.tolist()
+        offs.append(len(terms))
+        nk += kind
+        nt += tie
+        npar += parent
+        qno.append(len(nk))
+    offs, terms, w = np.array(offs, np.uint32), np.array(terms, np.uint32), np.array(w, np.float32)
+    kw = dict(q_leaf=np.array(leaf, np.uint32), q_node_offsets=np.array(qno, np.uint32), node_kind=np.array(nk, np.int32),
+              node_tie=np.array(nt, np.float32), node_parent=np.array(npar, np.uint32))
+    want = oracle.search_batch(segs, offs, terms, w, k, strategy=oracle.BM25, **kw)
+    flat = oracle.search_batch(segs, offs, terms, w, k, strategy=oracle.BM25, q_leaf=kw["q_leaf"])
+    assert not np.array_equal(want[2].view(np.uint32), flat[2].view(np.uint32))  # the trees matter
+    with gpu.GpuIndex(segs) as ix:
+        for strat in (gpu.Bm25, gpu.Wand):
+            b = ix.prepare(offs, terms, w, k, strat, **kw)
+            b.run()
+            assert_same_hits(b.fetch(), want, 0.0, f"deep trees k={k} strategy {strat}")
+            b.close()
+        # a batch of shallow trees only still takes the few-term / group kernels: same results as the group form
+        sh = [i for i in range(20) if i % len(shapes) >= 3]
+        sel = np.concatenate([np.arange(offs[i], offs[i + 1]) for i in sh])
+        o2 = np.concatenate([[0], np.cumsum([offs[i + 1] - offs[i] for i in sh])]).astype(np.uint32)
+        n2 = np.concatenate([np.arange(qno[i], qno[i + 1]) for i in sh])
+        q2 = np.concatenate([[0], np.cumsum([qno[i + 1] - qno[i] for i in sh])]).astype(np.uint32)
+        kw2 = dict(q_leaf=kw["q_leaf"][sel], q_node_offsets=q2, node_kind=kw["node_kind"][n2],
+                   node_tie=kw["node_tie"][n2], node_parent=kw["node_parent"][n2])
+        b = ix.prepare(o2, terms[sel], w[sel], k, gpu.Wand, **kw2)
+        b.run()
+        got = b.fetch()
+        b.close()
+        assert_same_hits(got, tuple(x[sh] for x in want), 0.0, "shallow trees given as nodes")
+
+
 @pytest.mark.parametrize("k", [1025, 2049, 5000, 20001])
 def test_very_large_k_rank_ranges(gpu, oracle, k):
     """k up to the reference's 20 001 (api/reader.rs:2615-2619): the select kernel emits the result

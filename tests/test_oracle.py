@@ -499,6 +499,96 @@ def test_two_level_score_plans_against_numpy(oracle):
     assert np.array_equal(flat[0], tree[0]) and np.array_equal(flat[2].view(np.uint32), tree[2].view(np.uint32))
 
 
+def _eval_nodes_numpy(leaves, kind, tie, parent):
+    """Independent f32 evaluation of a pre-order node array (planner.rs:122-153)."""
+    f32 = np.float32
+    n = len(kind)
+    children = [[] for _ in range(n)]
+    for i in range(1, n):
+        children[parent[i]].append(i)
+    leaf_of, nl = {}, 0
+    for i in range(n):
+        if kind[i] == 2:
+            leaf_of[i] = nl
+            nl += 1
+
+    def ev(i):
+        if kind[i] == 2:
+            return f32(leaves[leaf_of[i]])
+        vals = [ev(c) for c in children[i]]
+        if kind[i] == 0:
+            s = f32(-0.0)
+            for v in vals:
+                s = f32(s + v)
+            return s
+        if not vals:
+            return f32(0.0)
+        mx, sm = f32(-np.inf), f32(0.0)
+        for v in vals:
+            mx = f32(max(mx, v))
+            sm = f32(sm + v)
+        return f32(mx + f32(f32(tie[i]) * f32(sm - mx)))
+    return ev(0)
+
+
+def deep_tree_shapes():
+    """Pre-order node arrays over 6 leaves: (kind, tie, parent).  0 Sum, 1 DisMax, 2 Leaf."""
+    S, D, L = 0, 1, 2
+    return [
+        # bool{should: [dis_max{queries: [multi_match(best_fields), term]}, term]}: 3 internal levels
+        ([S, D, D, L, L, L, L, D, L, L], [0, .3, .5, 0, 0, 0, 0, 1.0, 0, 0], [0, 0, 1, 2, 2, 2, 1, 0, 7, 7]),
+        # four internal levels, a leaf hanging off every level
+        ([D, L, S, L, D, L, S, L, L, L], [.25, 0, 0, 0, .75, 0, 0, 0, 0, 0], [0, 0, 0, 2, 2, 4, 4, 6, 6, 0]),
+        # a Sum of Sums of DisMax pairs
+        ([S, S, D, L, L, D, L, L, S, D, L, L], [0, 0, .1, 0, 0, .9, 0, 0, 0, 0, 0, 0], [0, 0, 1, 2, 2, 1, 5, 5, 0, 8, 9, 9]),
+    ]
+
+
+def test_deep_score_trees_against_numpy(oracle):
+    """ScoreExpr::evaluate is recursive (planner.rs:122-153): trees of three and four levels through
+    slo_search_batch_nodes, every scored doc checked against an independent numpy f32 recursion; a
+    two-level tree given as nodes equals the same tree given as groups."""
+    from tests.util import random_multifield_segment
+    rng = np.random.default_rng(29)
+    vocab, F = 9, 3
+    seg = random_multifield_segment(rng, 400, vocab, F, 8)
+    words = [0, 2, 5]
+    terms = np.array([[f * vocab + w_] for w_ in words for f in range(F)], dtype=np.uint32)
+    leaf = np.array([0, 1, 1, 2, 3, 3, 4, 5, 5], dtype=np.uint32)  # 6 leaves
+    w = (rng.random(len(terms)).astype(np.float32) * 2 - np.float32(0.4))  # some negative weights
+    offs = np.array([0, len(terms)], dtype=np.uint32)
+    leaves = np.zeros((400, 6), dtype=np.float32)
+    seen = np.zeros(400, dtype=bool)
+    for i, t in enumerate(terms[:, 0]):
+        a, b_ = int(seg.term_offsets[t]), int(seg.term_offsets[t + 1])
+        f = int(seg.term_field[t])
+        for d, tf in zip(seg.doc_ids[a:b_], seg.tfs[a:b_]):
+            x = oracle.score_tf(float(tf), float(b_ - a), float(seg.field_doc_len[f][d]),
+                                float(seg.field_avgdl[f]), seg.docs, seg.k1, seg.b, float(w[i]))
+            leaves[d, leaf[i]] = np.float32(leaves[d, leaf[i]] + np.float32(x))
+            seen[d] = True
+    for kind, tie, parent in deep_tree_shapes():
+        assert sum(1 for k_ in kind if k_ == 2) == 6
+        got = oracle.search_batch([seg], offs, terms, w, 400, strategy=oracle.BM25, q_leaf=leaf,
+                                  q_node_offsets=[0, len(kind)], node_kind=kind, node_tie=tie, node_parent=parent)
+        n = int(got[3][0])
+        assert n == int(seen.sum())
+        for i in range(n):
+            d = int(got[0][0, i])
+            want = _eval_nodes_numpy(leaves[d], kind, tie, parent)
+            assert np.float32(got[2][0, i]).view(np.uint32) == np.float32(want).view(np.uint32), (kind, d)
+    # the two-level form and the node form of one tree agree bit for bit
+    grp = oracle.search_batch([seg], offs, terms, w, 400, strategy=oracle.BM25, q_leaf=leaf, q_plan=[oracle.PLAN_SUM],
+                              q_tie=[0.0], q_nleaves=[6], q_leaf_offsets=[0, 6], leaf_group=[0, 0, 1, 2, 2, 2],
+                              q_group_offsets=[0, 3], group_plan=[oracle.PLAN_DISMAX, oracle.PLAN_SUM, oracle.PLAN_DISMAX],
+                              group_tie=[0.5, 0.0, 1.0])
+    S, D, L = 0, 1, 2
+    nod = oracle.search_batch([seg], offs, terms, w, 400, strategy=oracle.BM25, q_leaf=leaf,
+                              q_node_offsets=[0, 9], node_kind=[S, D, L, L, L, D, L, L, L],
+                              node_tie=[0, .5, 0, 0, 0, 1.0, 0, 0, 0], node_parent=[0, 0, 1, 1, 0, 0, 5, 5, 5])
+    assert np.array_equal(grp[0], nod[0]) and np.array_equal(grp[2].view(np.uint32), nod[2].view(np.uint32))
+
+
 def test_baseline_a_model_returns_the_scorer_results(oracle):
     """BASELINE.md "Baseline A" (scorer + per-query posting decode x2 + doc-length rebuild): the
     decode / rebuild round trip must not change a single hit."""

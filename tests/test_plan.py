@@ -17,7 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RQ = np.dtype([(n, "<u4") for n in ("q", "seg", "term_begin", "n_terms", "slice_begin", "n_slices", "n_rounds",
                                      "rounds_per_slice", "bounds_begin", "rdoc_begin", "bnd_begin", "longest",
                                      "ess_mask", "skip_mask", "filter", "cand_lo", "cand_hi", "plan")]
-              + [("tie", "<f4"), ("max_init", "<f4"), ("n_leaves", "<u4"), ("n_groups", "<u4"), ("theta0", "<f4")])
+              + [("tie", "<f4"), ("max_init", "<f4"), ("n_leaves", "<u4"), ("n_groups", "<u4"), ("theta0", "<f4"),
+                 ("depth", "<u4"), ("node_begin", "<u4")])
+PN = np.dtype([("parent", "<u4"), ("n_children", "<u4"), ("kind", "<u4"), ("tie", "<f4")])
 TR = np.dtype([("off", "<u8"), ("df", "<u4"), ("weight", "<f4"), ("term", "<u4"), ("leaf", "<u4"),
                ("gmeta", "<u4"), ("gtie", "<f4")])
 KCHAMP = 68
@@ -32,7 +34,7 @@ class Facts(C.Structure):
                                           "n_rounds", "n_bounds", "n_bnd", "cand_total", "image_bytes")] + \
                [(n, C.c_uint32) for n in ("n_sq", "n_terms", "n_slices", "max_terms", "uniform", "multi",
                                           "plan_batch", "nested", "pruned", "cand_mode", "sizeof_round_query",
-                                          "sizeof_term_ref")]
+                                          "sizeof_term_ref", "deep")]
 
 
 @pytest.fixture(scope="module")
@@ -417,6 +419,54 @@ def test_two_level_plans_are_validated_and_classified(lib):
         bad = Planned(lib, [seg], offs, terms, w, 11, plans=_plans(**base, leaf_group=(lg, "<u4"),
                                                                  group_plan=(gp, "<i4"), group_tie=(gt, "<f4")))
         assert not bad.h and bad.code == -1, (lg, bad.err)
+
+
+def test_score_trees_given_node_by_node(lib):
+    """slg_score_plans::q_node_offsets: trees of one and two levels resolve into the root / group forms;
+    deeper ones into the canonical node table (every leaf at the same depth, a chain of one-child Sum
+    nodes under a leaf that hangs higher up); malformed trees are rejected."""
+    rng = np.random.default_rng(12)
+    seg = random_segment(rng, 2000, 40, 15)
+    offs, terms, w = random_queries(rng, 3, 6, 40)
+    leaf = np.tile(np.array([0, 0, 1, 2, 2, 3], dtype=np.uint32), 3)  # 4 leaves per query
+    S, D, L = 0, 1, 2
+    trees = [  # query 0: one level; query 1: two levels; query 2: three levels with a leaf at every level
+        ([D, L, L, L, L], [.3, 0, 0, 0, 0], [0, 0, 0, 0, 0]),
+        ([S, D, L, L, L, D, L], [0, .5, 0, 0, 0, 1.0, 0], [0, 0, 1, 1, 0, 0, 5]),
+        ([S, L, D, L, S, L, L], [0, 0, .25, 0, 0, 0, 0], [0, 0, 0, 2, 2, 4, 4]),
+    ]
+    qno = np.cumsum([0] + [len(t[0]) for t in trees])
+    pl = _plans(q_leaf=(leaf, "<u4"), q_node_offsets=(qno, "<u4"), node_kind=(sum((t[0] for t in trees), []), "<i4"),
+                node_tie=(sum((t[1] for t in trees), []), "<f4"), node_parent=(sum((t[2] for t in trees), []), "<u4"))
+    p = Planned(lib, [seg], offs, terms, w, 11, plans=pl)
+    assert p.h, p.err
+    sqs, tr = check_structure(p, 11)
+    assert p.facts.plan_batch and p.facts.nested and p.facts.deep and not p.facts.uniform
+    assert [int(x) for x in sqs["plan"]] == [2, 1, 1] and abs(float(sqs["tie"][0]) - 0.3) < 1e-7
+    assert [int(x) for x in sqs["n_groups"]] == [0, 3, 0] and [int(x) for x in sqs["depth"]] == [0, 0, 3]
+    # query 1 as groups: leaves 0,1 -> DisMax group 0 (tie .5), leaf 2 -> bare leaf = Sum group 1, leaf 3 -> DisMax group 2
+    t1 = tr[int(sqs[1]["term_begin"]):int(sqs[1]["term_begin"]) + 6]
+    assert [int(g) & 0xFF for g in t1["gmeta"]] == [0, 0, 0, 1, 1, 2]
+    assert [(int(g) >> 16) & 1 for g in t1["gmeta"]] == [1, 1, 1, 0, 0, 1]
+    # query 2, canonical nodes: 0 root Sum (2 children) | 1,2 pads under leaf 0 (levels 1, 2) | 3 DisMax (2 children)
+    # | 4 pad under leaf 1 (level 2) | 5 Sum (2 children, level 2)
+    nodes = p.array(9, PN)
+    nb = int(sqs[2]["node_begin"])
+    got = [(int(n["parent"]), int(n["n_children"]), int(n["kind"])) for n in nodes[nb:nb + 6]]
+    assert got == [(0, 2, 0), (0, 1, 0), (1, 1, 0), (0, 2, 1), (3, 1, 0), (3, 2, 0)], got
+    t2 = tr[int(sqs[2]["term_begin"]):int(sqs[2]["term_begin"]) + 6]
+    assert [int(g) for g in t2["gmeta"]] == [2, 2, 4, 5, 5, 5]   # the level-2 node every list's leaf hangs off
+    p.close()
+    # malformed: a parent that comes later, a childless Sum, a tie outside [0, 1], too deep, a leaf with a child
+    for kind, tie, parent in (([S, L, L, L, L], [0] * 5, [0, 2, 0, 0, 0]),
+                              ([S, L, L, L, L, S], [0] * 6, [0, 0, 0, 0, 0, 0]),
+                              ([D, L, L, L, L], [1.5, 0, 0, 0, 0], [0] * 5),
+                              ([S, S, S, S, S, L, L, L, L], [0] * 9, [0, 0, 1, 2, 3, 4, 4, 4, 4]),
+                              ([S, L, L, L, L], [0] * 5, [0, 0, 1, 0, 0])):
+        bad = _plans(q_leaf=(leaf[:6], "<u4"), q_node_offsets=([0, len(kind)], "<u4"), node_kind=(kind, "<i4"),
+                     node_tie=(tie, "<f4"), node_parent=(parent, "<u4"))
+        b = Planned(lib, [seg], offs[:2], terms[:6], w[:6], 11, plans=bad)
+        assert not b.h and b.code in (-1, -4), (kind, b.err)
 
 
 def test_large_batches_plan_identically_on_several_threads(lib):
