@@ -754,7 +754,14 @@ def main():
         e_doc, e_score, e_cnt = (np.ascontiguousarray(exp[0], np.uint32), np.ascontiguousarray(exp[2], np.float32),
                                  np.ascontiguousarray(exp[3], np.uint32))
         legs = []
-        for thr, wait_us in ((args.coalesce_threads, 30), (4 * args.coalesce_threads, 30)):
+        cpu_quota = None
+        try:  # the cores this process may actually use (a cgroup quota below the visible CPU count bounds any
+            # leg with hundreds of caller threads)
+            q_, p_ = open("/sys/fs/cgroup/cpu.max").read().split()
+            cpu_quota = None if q_ == "max" else round(int(q_) / int(p_), 1)
+        except Exception:  # noqa: BLE001
+            pass
+        for thr, wait_us in ((16, 30), (64, 30), (args.coalesce_threads, 30), (4 * args.coalesce_threads, 30)):
             bad, nb = C.c_int64(0), C.c_uint64(0)
             ph = (C.c_double * 4)()
             total = 64 * nq
@@ -778,6 +785,9 @@ def main():
             "is": "slg_coalescer_search: every caller thread blocks with ONE query (the reference serves a request "
                   "per blocking thread, searchlite-http/src/lib.rs:628-652); concurrent callers are collected into "
                   "batches behind the C ABI; every row compared bit for bit with the batch API's",
+            "visible_cpus": host_cores, "cgroup_cpu_quota": cpu_quota,
+            "bound": "T blocking callers = T queries outstanding: rate <= T / (latency of a batch from its first row "
+                     "to its callers' wake-up) (Little's law)",
             "legs": legs}
 
     for b in batches:

@@ -10,7 +10,7 @@
 //
 // Mechanism.  A caller takes a ROW of the batch that is collecting: ONE fetch_add on the batch's ticket
 // counter, no lock (a mutex per request made 256 callers queue for 0.4 ms per batch), writes its query
-// into the row's fixed-size slot and sleeps (a short spin first) until the batch's results are in.  Two
+// into the row's fixed-size slot and sleeps until the batch's results are in.  Two
 // threads of the coalescer own every HIP call: the SUBMITTER closes the collecting batch — when it is
 // full (max_batch), max_wait_us after its first row, or at once if nothing else is in flight (a lone
 // request never waits) —, swaps a fresh batch in for the callers that keep arriving, plans and launches
@@ -488,14 +488,11 @@ int slg_coalescer_search_plan(slg_coalescer *c, const slg_query *query, const ui
     }
     c->wake_cv.notify_one();
   }
-  // ---- wait: a short spin (a batch is tens of microseconds from done once launched), then sleep ----
-  {
-    const auto spin_until = Clock::now() + std::chrono::microseconds(20);
-    while (!b->done.load(std::memory_order_acquire) && Clock::now() < spin_until) cpu_relax();
-    if (!b->done.load(std::memory_order_acquire)) {
-      std::unique_lock<std::mutex> bl(b->mu);
-      b->cv.wait(bl, [&] { return b->done.load(std::memory_order_acquire); });
-    }
+  // ---- wait (asleep: hundreds of callers spinning would take the cores the two dispatcher threads and
+  //      the callers that are being woken need) ----
+  if (!b->done.load(std::memory_order_acquire)) {
+    std::unique_lock<std::mutex> bl(b->mu);
+    b->cv.wait(bl, [&] { return b->done.load(std::memory_order_acquire); });
   }
   const int rc = b->rc;
   if (rc != SLG_OK) {

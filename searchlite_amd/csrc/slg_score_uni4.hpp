@@ -865,6 +865,19 @@ score_uniform4_kernel(RoundScoreParams p_arg) {
     p.slice_cbeg[slice] = cbeg;
     p.slice_ccnt[slice] = ccur;
   }
+#ifdef SLG_FOLD_PROBE
+  // Experiment (tools/ab_tags.sh, -DSLG_FOLD_PROBE): what folding merge_topk_kernel into the last-arriving
+  // slice of a query would pay per slice BEFORE any merging — an agent-scope release of this slice's
+  // candidate list (the slices of a query run on different XCDs, whose L2s are not coherent with each
+  // other for plain stores) and an arrival ticket on a per-query counter.  q_scored doubles as the counter
+  // (its value is not read in this build).
+  if constexpr (BUF) {
+    __atomic_thread_fence(__ATOMIC_RELEASE);  // (HIP: agent scope) buffer_wbl2 + waits
+    uint32_t prev = 0;
+    if (lane == 0) prev = atomicAdd(&p.q_scored[rfl(sl.q)], 1u);
+    if (rfl(prev) == 0xFFFFFFF0u) __atomic_thread_fence(__ATOMIC_ACQUIRE);  // (the merging wave would acquire here)
+  }
+#endif
   if (p.q_scored && lane == 0 && n_scored) atomicAdd(&p.q_scored[rfl(sl.q)], n_scored);
 #ifdef SLG_STAMPS
   const unsigned long long st_extra = st_ins | (st_queued << 32);
