@@ -148,6 +148,16 @@ def main():
     from searchlite_amd import corpus, searcher
 
     host_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    visible_cpus = host_cores
+    cpu_quota = None
+    try:  # a cgroup quota below the visible CPU count is what the process really has (GPU boxes of this pool:
+        # 256 CPUs visible, cpu.max = 16 CPUs): the CPU baseline runs on that many threads and says so
+        q_, p_ = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q_ != "max":
+            cpu_quota = int(q_) / int(p_)
+            host_cores = max(1, min(host_cores, int(cpu_quota + 0.5)))
+    except Exception:  # noqa: BLE001
+        pass
     gen_threads = max(1, min(32, host_cores // max(1, world)))
     strategy = {"bm25": searcher.Bm25, "wand": searcher.Wand, "bmw": searcher.Bmw}[args.strategy]
     stream = torch.cuda.current_stream()
@@ -725,6 +735,7 @@ def main():
             other_rate = ncpu * reps_o / t_o
             out["cpu_baseline"] = {
                 "value": round(strict, 1), "unit": "queries/s", "cores": cores, "kind": "port",
+                "visible_cpus": visible_cpus, "cgroup_cpu_quota": cpu_quota,
                 ("bmw_block128_value" if other == O.BMW else "wand_value"): round(other_rate, 1),
                 "sample": f"{ncpu} queries of query set 0 x {reps_c} reps, oracle "
                           f"{args.strategy} (C restatement of searchlite-core's scorer, "
@@ -754,13 +765,6 @@ def main():
         e_doc, e_score, e_cnt = (np.ascontiguousarray(exp[0], np.uint32), np.ascontiguousarray(exp[2], np.float32),
                                  np.ascontiguousarray(exp[3], np.uint32))
         legs = []
-        cpu_quota = None
-        try:  # the cores this process may actually use (a cgroup quota below the visible CPU count bounds any
-            # leg with hundreds of caller threads)
-            q_, p_ = open("/sys/fs/cgroup/cpu.max").read().split()
-            cpu_quota = None if q_ == "max" else round(int(q_) / int(p_), 1)
-        except Exception:  # noqa: BLE001
-            pass
         for thr, wait_us in ((16, 30), (64, 30), (args.coalesce_threads, 30), (4 * args.coalesce_threads, 30)):
             bad, nb = C.c_int64(0), C.c_uint64(0)
             ph = (C.c_double * 4)()
@@ -785,7 +789,7 @@ def main():
             "is": "slg_coalescer_search: every caller thread blocks with ONE query (the reference serves a request "
                   "per blocking thread, searchlite-http/src/lib.rs:628-652); concurrent callers are collected into "
                   "batches behind the C ABI; every row compared bit for bit with the batch API's",
-            "visible_cpus": host_cores, "cgroup_cpu_quota": cpu_quota,
+            "visible_cpus": visible_cpus, "cgroup_cpu_quota": cpu_quota,
             "bound": "T blocking callers = T queries outstanding: rate <= T / (latency of a batch from its first row "
                      "to its callers' wake-up) (Little's law)",
             "legs": legs}
