@@ -578,11 +578,15 @@ void plan_rounds(const std::vector<SegView> &segs, const slg_tuning &tn, uint32_
                                                                  : (uint32_t)slg::kDefaultRoundsPerSlice),
                             (uint32_t)slg::kMaxRoundsPerSlice));
   // longest slices: 8 rounds on the few-term kernel (measured on config 2: the heaviest
-  // sub-queries' 16-round slices were the tail of the launch), 16 on the many-term kernel
+  // sub-queries' 16-round slices were the tail of the launch), 16 on the many-term kernel and on the
+  // 5..8-list form for large k (config 3, k = 101: 5.03 ms at 16, 5.11 at 8), 6 on that form for
+  // k <= 64 (multi-field workload, k = 11: the 15-round slices of the dense sub-queries ran 125 us
+  // of a 144-us launch; 0.165 ms at 15, 0.124 at 6, 0.135 at 4)
   const bool blocked8 = out.uniform && tn.uniform_kernel >= 4 && out.max_terms > (uint32_t)slg::kUniMaxLists;
   const uint32_t rps_cap = std::max<uint32_t>(
       max_rps, tn.max_rounds_per_slice ? tn.max_rounds_per_slice
-                                       : (out.uniform && !blocked8 ? 8u : (uint32_t)slg::kMaxRoundsPerSlice));
+                                       : (out.uniform && !blocked8 ? 8u
+                                          : (blocked8 && k <= 64 ? 6u : (uint32_t)slg::kMaxRoundsPerSlice)));
   const uint32_t slices_per_sq = tn.slices_per_subquery;
   const bool slice_lists = !out.cand_mode;
   // the round targets are independent per sub-query: large batches (config 4: 65 536 sub-queries)
