@@ -758,25 +758,28 @@ def main():
         Lh.slh_coalesce_bench.restype = C.c_double
         Lh.slh_coalesce_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32,
-                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         offs, terms, w = (np.ascontiguousarray(x) for x in qs[0])
         batches[0].run()
         exp = batches[0].fetch()
         e_doc, e_score, e_cnt = (np.ascontiguousarray(exp[0], np.uint32), np.ascontiguousarray(exp[2], np.float32),
                                  np.ascontiguousarray(exp[3], np.uint32))
         legs = []
-        for thr, wait_us in ((16, 30), (64, 30), (args.coalesce_threads, 30), (4 * args.coalesce_threads, 30)):
+        # (threads, requests in flight per thread): blocking callers, then callers that pipeline (submit / wait)
+        for thr, depth, wait_us in ((16, 1, 30), (64, 1, 30), (args.coalesce_threads, 1, 30),
+                                    (4 * args.coalesce_threads, 1, 30), (16, 64, 30), (16, 256, 30), (8, 256, 30)):
             bad, nb = C.c_int64(0), C.c_uint64(0)
             ph = (C.c_double * 4)()
             total = 64 * nq
             Lh.slh_coalesce_bench(index._h, local_rank, thr, 8 * nq, offs.ctypes.data, terms.ctypes.data, w.ctypes.data,
-                                  nq, 1, k, strategy, 1024, wait_us, None, None, None, None, None, None)  # warm-up
+                                  nq, 1, k, strategy, 1024, wait_us, None, None, None, None, None, None, depth)  # warm-up
             secs = Lh.slh_coalesce_bench(index._h, local_rank, thr, total, offs.ctypes.data, terms.ctypes.data,
                                          w.ctypes.data, nq, 1, k, strategy, 1024, wait_us, e_doc.ctypes.data,
-                                         e_score.ctypes.data, e_cnt.ctypes.data, C.addressof(bad), C.addressof(nb), ph)
+                                         e_score.ctypes.data, e_cnt.ctypes.data, C.addressof(bad), C.addressof(nb), ph,
+                                         depth)
             if secs <= 0:
                 raise SystemExit("bench.py: the coalescer leg failed")
-            legs.append({"caller_threads": thr, "max_wait_us": wait_us, "queries": total,
+            legs.append({"caller_threads": thr, "in_flight_per_thread": depth, "max_wait_us": wait_us, "queries": total,
                          "queries_per_s": round(total / secs, 1), "batches": int(nb.value),
                          "mean_batch": round(total / max(1, nb.value), 1),
                          "leader_ms_per_batch": {"collect": round(ph[0], 3), "prepare": round(ph[1], 3),
@@ -786,9 +789,10 @@ def main():
                 print(json.dumps(legs))
                 raise SystemExit("bench.py: coalescer results differ from the batch API")
         out["config"]["coalescer"] = {
-            "is": "slg_coalescer_search: every caller thread blocks with ONE query (the reference serves a request "
-                  "per blocking thread, searchlite-http/src/lib.rs:628-652); concurrent callers are collected into "
-                  "batches behind the C ABI; every row compared bit for bit with the batch API's",
+            "is": "in_flight_per_thread 1: slg_coalescer_search, every caller thread blocks with ONE query (the reference "
+                  "serves a request per blocking thread, searchlite-http/src/lib.rs:628-652); > 1: slg_coalescer_submit / "
+                  "_wait, a thread keeps that many requests in flight; concurrent requests are collected into batches "
+                  "behind the C ABI; every row compared bit for bit with the batch API's",
             "visible_cpus": visible_cpus, "cgroup_cpu_quota": cpu_quota,
             "bound": "T blocking callers = T queries outstanding: rate <= T / (latency of a batch from its first row "
                      "to its callers' wake-up) (Little's law)",

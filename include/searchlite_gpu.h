@@ -413,9 +413,9 @@ void slg_batch_destroy(slg_batch *batch);
  * searchlite has no batch API: IndexReader::search takes one request (api/reader.rs:2539) and the HTTP
  * server gives every request its own blocking thread (searchlite-http/src/lib.rs:628-652).  The
  * coalescer turns concurrent single-query callers into batches: slg_coalescer_search blocks its caller
- * thread, the query joins the batch that is collecting (same k, strategy and segment count), one of
- * the callers plans / runs / fetches the batch on a HIP stream of its own while the next batch already
- * collects, and every caller returns with its own row — bit-identical to the same query in
+ * thread, the query joins the batch that is collecting (same k, strategy and segment count), the
+ * coalescer's two dispatcher threads plan / run / fetch the batch on a HIP stream of its own while the next
+ * batch already collects, and every caller returns with its own row — bit-identical to the same query in
  * slg_search_batch.  A batch closes when it holds max_batch queries, or max_wait_us after its first
  * query arrived; a query that finds the coalescer idle (nothing in flight) does not wait at all.
  * Thread-safe; out_doc / out_seg / out_score hold k entries, out_count one. */
@@ -435,6 +435,24 @@ int slg_coalescer_search_plan(slg_coalescer *coalescer, const slg_query *query, 
                               float tie, uint32_t n_leaves, int32_t filter_id, uint32_t k, int strategy,
                               uint32_t *out_doc, uint32_t *out_seg, float *out_score, uint32_t *out_count,
                               slg_stats *stats_or_null);
+/* The two halves of slg_coalescer_search_plan, for callers that keep SEVERAL requests in flight per thread
+ * (an async server task, a client that pipelines): slg_coalescer_submit puts the query into the collecting
+ * batch and returns at once with a ticket; slg_coalescer_wait blocks until that batch's results are in,
+ * copies the ticket's row out and gives the row back (every ticket must be waited for exactly once, by any
+ * thread; the ticket is cleared).  slg_coalescer_poll: 1 if slg_coalescer_wait would not block, else 0.
+ * The query's arrays may be reused as soon as submit returns.  A thread-per-request caller pays a sleep and
+ * a wake-up per query — what bounds slg_coalescer_search on a host with few cores; with D tickets per
+ * thread a thread sleeps at most once per D queries. */
+typedef struct slg_ticket {
+  void *batch;   /* opaque; NULL once waited for */
+  uint32_t row, k, kind;
+} slg_ticket;
+int slg_coalescer_submit(slg_coalescer *coalescer, const slg_query *query, const uint32_t *leaf, int plan, float tie,
+                         uint32_t n_leaves, int32_t filter_id, uint32_t k, int strategy, int want_stats,
+                         slg_ticket *ticket);
+int slg_coalescer_poll(const slg_coalescer *coalescer, const slg_ticket *ticket);
+int slg_coalescer_wait(slg_coalescer *coalescer, slg_ticket *ticket, uint32_t *out_doc, uint32_t *out_seg,
+                       float *out_score, uint32_t *out_count, slg_stats *stats_or_null);
 /* Thread-local text of the last failure of slg_coalescer_search on this thread. */
 const char *slg_coalescer_last_error(void);
 /* Mean time (ms) a batch's leader spent collecting / in slg_batch_prepare / in set_stream + run / in

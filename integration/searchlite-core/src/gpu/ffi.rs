@@ -10,6 +10,8 @@ use std::os::raw::{c_char, c_float, c_int, c_void};
 #[repr(C)] pub struct slg_batch { _p: [u8; 0] }
 #[repr(C)] pub struct slg_shard_group { _p: [u8; 0] }
 #[repr(C)] pub struct slg_coalescer { _p: [u8; 0] }
+/// slg_coalescer_submit / _wait: one request in flight (good for one wait).
+#[repr(C)] #[derive(Clone, Copy)] pub struct slg_ticket { pub batch: *mut c_void, pub row: u32, pub k: u32, pub kind: u32 }
 
 #[repr(C)]
 pub struct slg_segment_desc {
@@ -72,6 +74,13 @@ extern "C" {
     pub fn slg_coalescer_search_plan(coalescer: *mut slg_coalescer, query: *const slg_query, leaf: *const u32,
         plan: c_int, tie: c_float, n_leaves: u32, filter_id: i32, k: u32, strategy: c_int, out_doc: *mut u32,
         out_seg: *mut u32, out_score: *mut c_float, out_count: *mut u32, stats_or_null: *mut slg_stats) -> c_int;
+    pub fn slg_coalescer_submit(coalescer: *mut slg_coalescer, query: *const slg_query, leaf: *const u32, plan: c_int,
+                                tie: f32, n_leaves: u32, filter_id: i32, k: u32, strategy: c_int, want_stats: c_int,
+                                ticket: *mut slg_ticket) -> c_int;
+    pub fn slg_coalescer_poll(coalescer: *const slg_coalescer, ticket: *const slg_ticket) -> c_int;
+    pub fn slg_coalescer_wait(coalescer: *mut slg_coalescer, ticket: *mut slg_ticket, out_doc: *mut u32,
+                              out_seg: *mut u32, out_score: *mut f32, out_count: *mut u32,
+                              stats_or_null: *mut slg_stats) -> c_int;
     pub fn slg_coalescer_last_error() -> *const c_char;
     pub fn slg_coalescer_phase_ms(coalescer: *const slg_coalescer, collect: *mut f64, prepare: *mut f64, run: *mut f64,
         fetch: *mut f64) -> c_int;

@@ -76,6 +76,11 @@ class ScorePlans(C.Structure):
                 ("node_parent", C.c_void_p)]
 
 
+class Ticket(C.Structure):
+    """slg_ticket (slg_coalescer_submit / _wait)."""
+    _fields_ = [("batch", C.c_void_p), ("row", C.c_uint32), ("k", C.c_uint32), ("kind", C.c_uint32)]
+
+
 class Query(C.Structure):
     _fields_ = [("n_terms", C.c_uint32), ("term_ids", C.c_void_p), ("weights", C.c_void_p)]
 
@@ -136,6 +141,9 @@ def load():
         "slg_coalescer_destroy": (None, [vp]),
         "slg_coalescer_search": (i32, [vp, vp, u32, i32, vp, vp, vp, vp, vp]),
         "slg_coalescer_search_plan": (i32, [vp, vp, vp, i32, f32, u32, C.c_int32, u32, i32, vp, vp, vp, vp, vp]),
+        "slg_coalescer_submit": (i32, [vp, vp, vp, i32, f32, u32, C.c_int32, u32, i32, i32, vp]),
+        "slg_coalescer_poll": (i32, [vp, vp]),
+        "slg_coalescer_wait": (i32, [vp, vp, vp, vp, vp, vp, vp]),
         "slg_coalescer_last_error": (C.c_char_p, []),
         "slg_coalescer_stats": (i32, [vp, vp, vp]),
         "slg_coalescer_phase_ms": (i32, [vp, vp, vp, vp, vp]),

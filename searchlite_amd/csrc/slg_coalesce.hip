@@ -10,12 +10,13 @@
 //
 // Mechanism.  A caller takes a ROW of the batch that is collecting: ONE fetch_add on the batch's ticket
 // counter, no lock (a mutex per request made 256 callers queue for 0.4 ms per batch), writes its query
-// into the row's fixed-size slot and sleeps until the batch's results are in.  Two
-// threads of the coalescer own every HIP call: the SUBMITTER closes the collecting batch — when it is
+// into the row's fixed-size slot and sleeps (a futex on the batch's `done` word) until the batch's results
+// are in — or, with slg_coalescer_submit / _wait, goes on to submit more and collects its rows later.  A few
+// threads of the coalescer own every HIP call: a SUBMITTER closes the collecting batch — when it is
 // full (max_batch), max_wait_us after its first row, or at once if nothing else is in flight (a lone
 // request never waits) —, swaps a fresh batch in for the callers that keep arriving, plans and launches
-// the closed one on a stream of its own; the COLLECTOR fetches the launched batches in order and wakes
-// their callers.  (Letting one of a batch's callers do the planning, launching and fetching — leader /
+// the closed one on a stream of its own; a COLLECTOR fetches a launched batch and wakes
+// its callers.  (Letting one of a batch's callers do the planning, launching and fetching — leader /
 // followers — was built first: with a dozen leaders inside the HIP runtime at once, prepare took 0.24 ms
 // and fetch 0.41 ms for 23-query batches whose kernels take ~40 us; polling the stream instead of the
 // blocking wait made it worse.)  Batches of different kinds — (k, strategy, segment count) — collect
@@ -25,8 +26,13 @@
 // Host code on top of the public ABI (no kernels here; HIP only for the leaders' streams); part of
 // libsearchlite_gpu.so.
 #include <hip/hip_runtime.h>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <atomic>
+#include <climits>
+#include <cstdlib>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -44,6 +50,16 @@ namespace {
 constexpr uint32_t kClosed = 0x80000000u;  // ticket counter: top bit = the batch takes no more rows
 constexpr int kMaxKinds = 8;               // (k, strategy, segment count) combinations collecting at once
 using Clock = std::chrono::steady_clock;
+
+// Callers sleep on the batch's `done` word itself (futex): waking a batch's callers is one system call
+// and none of them takes a lock on the way out.  (A condition variable was built first: notify_all
+// hands every woken caller the batch mutex in turn — 200 callers per batch queued for it.)
+inline void futex_wait(std::atomic<uint32_t> *w, uint32_t seen) {
+  (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0);
+}
+inline void futex_wake_all(std::atomic<uint32_t> *w) {
+  (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+}
 
 inline void cpu_relax() {
 #if defined(__x86_64__)
@@ -80,9 +96,7 @@ struct CoBatch {
   std::vector<slg_stats> stats;
   int rc = SLG_OK;
   std::string error;
-  std::mutex mu;
-  std::condition_variable cv;
-  std::atomic<bool> done{false};  // results are in (callers spin on it, then sleep on cv)
+  std::atomic<uint32_t> done{0};  // 1: results are in (callers sleep on this word: futex)
   int kind = 0;
 };
 
@@ -115,8 +129,9 @@ struct slg_coalescer {
   std::atomic<uint32_t> in_flight{0};     // batches launched and not yet fetched
   std::atomic<uint32_t> rows_waiting{0};  // rows in collecting batches
   std::atomic<bool> stop{false};
-  std::thread submitter, collector;
-  std::mutex wake_mu;  // the submitter sleeps here while no row is waiting
+  std::vector<std::thread> submitters, collectors;
+  std::mutex close_mu;  // one submitter at a time looks for a batch to close (planning and launching run outside it)
+  std::mutex wake_mu;   // the submitters sleep here while no row is waiting
   std::condition_variable wake_cv;
   std::mutex q_mu;     // submitter -> collector
   std::condition_variable q_cv;
@@ -193,7 +208,7 @@ CoBatch *fresh_batch(slg_coalescer *c, Kind &kd) {
   b->want_stats.store(false);
   b->any_plan.store(false);
   b->any_filter.store(false);
-  b->done.store(false);
+  b->done.store(0);
   b->rc = SLG_OK;
   b->error.clear();
   return b;
@@ -228,11 +243,8 @@ Kind *find_kind(slg_coalescer *c, uint32_t k, int strategy, uint32_t n_segs) {
 void publish(CoBatch &b, int rc, const char *err) {
   b.rc = rc;
   if (err) b.error = err;
-  {
-    std::lock_guard<std::mutex> lk(b.mu);
-    b.done.store(true, std::memory_order_release);
-  }
-  b.cv.notify_all();
+  b.done.store(1, std::memory_order_release);
+  futex_wake_all(&b.done);
 }
 
 // the submitter's part for one closed batch: CSR, plan, launch
@@ -277,10 +289,10 @@ void launch_batch(slg_coalescer *c, CoBatch &b) {
     if (sb) slg_batch_destroy(sb);
     give_stream(c, stream);
     c->n_batches.fetch_add(1);
+    c->in_flight.fetch_sub(1);
     publish(b, rc, err.c_str());
     return;
   }
-  c->in_flight.fetch_add(1);
   {
     std::lock_guard<std::mutex> lk(c->q_mu);
     c->flights.push_back(Flight{&b, sb, stream, t2});
@@ -288,6 +300,9 @@ void launch_batch(slg_coalescer *c, CoBatch &b) {
   c->q_cv.notify_one();
 }
 
+// Several submitters (SLG_COALESCER_THREADS, 2): planning a batch is ~0.2 us of host time per query, one
+// thread's worth of it caps the coalescer near 3.4M queries/s.  Closing is serialised (close_mu); the
+// closed batch is planned and launched outside the lock while another submitter closes the next one.
 void submitter_main(slg_coalescer *c) {
   (void)hipSetDevice(c->device);
   while (!c->stop.load(std::memory_order_acquire)) {
@@ -298,33 +313,44 @@ void submitter_main(slg_coalescer *c) {
       });
       continue;
     }
-    const auto now = Clock::now();
-    for (int i = 0; i < kMaxKinds; i++) {
-      Kind &kd = c->kinds[i];
-      if (!kd.used.load(std::memory_order_acquire)) continue;
-      CoBatch *b = kd.cur.load(std::memory_order_acquire);
-      const uint32_t t = b->tickets.load(std::memory_order_acquire);
-      if (t == 0u || (t & kClosed)) continue;
-      if (!b->seen) {
-        b->seen = true;
-        b->first_seen = now;
+    CoBatch *closed = nullptr;
+    {
+      std::unique_lock<std::mutex> cl(c->close_mu, std::try_to_lock);
+      if (cl.owns_lock()) {
+        const auto now = Clock::now();
+        for (int i = 0; i < kMaxKinds && !closed; i++) {
+          Kind &kd = c->kinds[i];
+          if (!kd.used.load(std::memory_order_acquire)) continue;
+          CoBatch *b = kd.cur.load(std::memory_order_acquire);
+          const uint32_t t = b->tickets.load(std::memory_order_acquire);
+          if (t == 0u || (t & kClosed)) continue;
+          if (!b->seen) {
+            b->seen = true;
+            b->first_seen = now;
+          }
+          // close: full, or max_wait_us after its first row — at once if nothing else is in flight (an idle
+          // device: waiting would only add latency; under load the batches in flight give it time to fill).
+          // A batch counts as in flight from here on (while it is being planned too).
+          const bool full = t >= c->max_batch;
+          const bool idle = c->in_flight.load(std::memory_order_acquire) == 0;
+          const bool aged = nanos(b->first_seen, now) >= (uint64_t)c->max_wait_us * 1000ull;
+          if (!(full || idle || aged)) continue;
+          CoBatch *nb = fresh_batch(c, kd);
+          nb->tickets.store(0, std::memory_order_release);  // open
+          kd.cur.store(nb, std::memory_order_release);      // arriving callers go there from now on
+          const uint32_t had = b->tickets.fetch_or(kClosed, std::memory_order_acq_rel);
+          b->nq = had < c->max_batch ? had : c->max_batch;
+          c->rows_waiting.fetch_sub(b->nq, std::memory_order_acq_rel);
+          c->in_flight.fetch_add(1);
+          c->ns_collect += nanos(b->first_seen, Clock::now());
+          closed = b;
+        }
       }
-      // close: full, or max_wait_us after its first row — at once if nothing else is in flight (an idle
-      // device: waiting would only add latency; under load the batches in flight give it time to fill)
-      const bool full = t >= c->max_batch;
-      const bool idle = c->in_flight.load(std::memory_order_acquire) == 0;
-      const bool aged = nanos(b->first_seen, now) >= (uint64_t)c->max_wait_us * 1000ull;
-      if (!(full || idle || aged)) continue;
-      CoBatch *nb = fresh_batch(c, kd);
-      nb->tickets.store(0, std::memory_order_release);  // open
-      kd.cur.store(nb, std::memory_order_release);      // arriving callers go there from now on
-      const uint32_t had = b->tickets.fetch_or(kClosed, std::memory_order_acq_rel);
-      b->nq = had < c->max_batch ? had : c->max_batch;
-      c->rows_waiting.fetch_sub(b->nq, std::memory_order_acq_rel);
-      c->ns_collect += nanos(b->first_seen, Clock::now());
-      launch_batch(c, *b);
     }
-    cpu_relax();
+    if (closed)
+      launch_batch(c, *closed);
+    else
+      cpu_relax();
   }
 }
 
@@ -367,8 +393,11 @@ slg_coalescer *slg_coalescer_create(slg_index *index, uint32_t max_batch, uint32
   c->device = dev;
   c->max_batch = max_batch ? (max_batch < kClosed / 2 ? max_batch : 1024u) : 1024u;
   c->max_wait_us = max_wait_us;
-  c->submitter = std::thread(submitter_main, c);
-  c->collector = std::thread(collector_main, c);
+  uint32_t n_thr = 2;
+  if (const char *e = getenv("SLG_COALESCER_THREADS")) n_thr = (uint32_t)strtoul(e, nullptr, 10);
+  n_thr = n_thr < 1u ? 1u : (n_thr > 8u ? 8u : n_thr);
+  for (uint32_t i = 0; i < n_thr; i++) c->submitters.emplace_back(submitter_main, c);
+  for (uint32_t i = 0; i < n_thr; i++) c->collectors.emplace_back(collector_main, c);
   return c;
 }
 
@@ -377,12 +406,12 @@ void slg_coalescer_destroy(slg_coalescer *c) {
   if (!c) return;
   c->stop.store(true, std::memory_order_release);
   c->wake_cv.notify_all();
-  if (c->submitter.joinable()) c->submitter.join();
+  for (auto &t : c->submitters) t.join();
   {
     std::lock_guard<std::mutex> lk(c->q_mu);
   }
   c->q_cv.notify_all();
-  if (c->collector.joinable()) c->collector.join();
+  for (auto &t : c->collectors) t.join();
   for (void *s : c->free_streams) (void)hipStreamDestroy((hipStream_t)s);
   for (Kind &kd : c->kinds)
     for (CoBatch *b : kd.all) delete b;
@@ -417,10 +446,23 @@ int slg_coalescer_search(slg_coalescer *c, const slg_query *query, uint32_t k, i
 int slg_coalescer_search_plan(slg_coalescer *c, const slg_query *query, const uint32_t *leaf, int plan, float tie,
                               uint32_t n_leaves, int32_t filter_id, uint32_t k, int strategy, uint32_t *out_doc,
                               uint32_t *out_seg, float *out_score, uint32_t *out_count, slg_stats *stats_or_null) {
+  if (!out_count || (k && (!out_doc || !out_seg || !out_score))) {
+    g_co_error = "output array is NULL";
+    return SLG_ERR_INVALID;
+  }
+  slg_ticket t;
+  const int rc = slg_coalescer_submit(c, query, leaf, plan, tie, n_leaves, filter_id, k, strategy,
+                                      stats_or_null ? 1 : 0, &t);
+  if (rc != SLG_OK) return rc;
+  return slg_coalescer_wait(c, &t, out_doc, out_seg, out_score, out_count, stats_or_null);
+}
+
+int slg_coalescer_submit(slg_coalescer *c, const slg_query *query, const uint32_t *leaf, int plan, float tie,
+                         uint32_t n_leaves, int32_t filter_id, uint32_t k, int strategy, int want_stats,
+                         slg_ticket *ticket) {
   g_co_error.clear();
-  if (!c || !query || !out_count || (k && (!out_doc || !out_seg || !out_score)) ||
-      (query->n_terms && (!query->term_ids || !query->weights))) {
-    g_co_error = "coalescer, query or output array is NULL";
+  if (!c || !query || !ticket || (query->n_terms && (!query->term_ids || !query->weights))) {
+    g_co_error = "coalescer, query or ticket is NULL";
     return SLG_ERR_INVALID;
   }
   if (query->n_terms > SLG_MAX_QUERY_TERMS) {
@@ -480,7 +522,7 @@ int slg_coalescer_search_plan(slg_coalescer *c, const slg_query *query, const ui
   b->slot_filter[row] = filter_id;
   if (planned) b->any_plan.store(true);
   if (filter_id >= 0) b->any_filter.store(true);
-  if (stats_or_null) b->want_stats.store(true);
+  if (want_stats) b->want_stats.store(true);
   b->ready.fetch_add(1, std::memory_order_release);
   if (c->rows_waiting.fetch_add(1, std::memory_order_acq_rel) == 0) {  // the first waiting row wakes the submitter
     {
@@ -488,15 +530,36 @@ int slg_coalescer_search_plan(slg_coalescer *c, const slg_query *query, const ui
     }
     c->wake_cv.notify_one();
   }
+  ticket->batch = b;
+  ticket->row = row;
+  ticket->k = k;
+  ticket->kind = (uint32_t)(kd - c->kinds);
+  return SLG_OK;
+}
+
+int slg_coalescer_poll(const slg_coalescer *c, const slg_ticket *ticket) {
+  if (!c || !ticket || !ticket->batch) return SLG_ERR_INVALID;
+  return static_cast<const CoBatch *>(ticket->batch)->done.load(std::memory_order_acquire) != 0u ? 1 : 0;
+}
+
+int slg_coalescer_wait(slg_coalescer *c, slg_ticket *ticket, uint32_t *out_doc, uint32_t *out_seg, float *out_score,
+                       uint32_t *out_count, slg_stats *stats_or_null) {
+  g_co_error.clear();
+  if (!c || !ticket || !ticket->batch || ticket->kind >= (uint32_t)kMaxKinds) {
+    g_co_error = "coalescer or ticket is NULL (a ticket is good for one wait)";
+    return SLG_ERR_INVALID;
+  }
+  CoBatch *b = static_cast<CoBatch *>(ticket->batch);
+  const uint32_t row = ticket->row, k = ticket->k;
+  Kind *kd = &c->kinds[ticket->kind];
   // ---- wait (asleep: hundreds of callers spinning would take the cores the two dispatcher threads and
   //      the callers that are being woken need) ----
-  if (!b->done.load(std::memory_order_acquire)) {
-    std::unique_lock<std::mutex> bl(b->mu);
-    b->cv.wait(bl, [&] { return b->done.load(std::memory_order_acquire); });
-  }
+  while (b->done.load(std::memory_order_acquire) == 0u) futex_wait(&b->done, 0u);
   const int rc = b->rc;
   if (rc != SLG_OK) {
     g_co_error = b->error;
+  } else if (!out_count || (k && (!out_doc || !out_seg || !out_score))) {
+    g_co_error = "output array is NULL";
   } else {
     *out_count = b->count[row];
     if (k) {
@@ -504,14 +567,16 @@ int slg_coalescer_search_plan(slg_coalescer *c, const slg_query *query, const ui
       std::memcpy(out_seg, b->seg.data() + (size_t)row * k, (size_t)k * 4);
       std::memcpy(out_score, b->score.data() + (size_t)row * k, (size_t)k * 4);
     }
-    if (stats_or_null) *stats_or_null = b->stats[row];
+    if (stats_or_null && !b->stats.empty()) *stats_or_null = b->stats[row];
   }
+  const bool args_ok = rc != SLG_OK || (out_count && (!k || (out_doc && out_seg && out_score)));
   // the last caller to leave hands the batch object back to its kind (b->nq is final: done was seen)
+  ticket->batch = nullptr;
   if (b->leaving.fetch_add(1) + 1 == b->nq) {
     std::lock_guard<std::mutex> lk(kd->mu);
     kd->spare.push_back(b);
   }
-  return rc;
+  return args_ok ? rc : SLG_ERR_INVALID;
 }
 
 }  // extern "C"

@@ -242,7 +242,7 @@ double slh_coalesce_bench(slg_index *ix, int device, int n_threads, int64_t tota
                           const uint32_t *terms, const float *w, uint32_t nq, uint32_t n_segs, uint32_t k,
                           int strategy, uint32_t max_batch, uint32_t max_wait_us, const uint32_t *exp_doc,
                           const float *exp_score, const uint32_t *exp_count, int64_t *mismatches,
-                          uint64_t *n_batches, double *phase_ms4) {
+                          uint64_t *n_batches, double *phase_ms4, int depth) {
   slg_coalescer *co = slg_coalescer_create(ix, max_batch, max_wait_us);
   if (!co) return -1.0;
   std::atomic<int64_t> next{0}, bad{0}, failed{0};
@@ -257,24 +257,64 @@ double slh_coalesce_bench(slg_index *ix, int device, int n_threads, int64_t tota
       uint32_t count = 0;
       ready.fetch_add(1);
       while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
-      for (;;) {
-        const int64_t i = next.fetch_add(1);
-        if (i >= total_queries) break;
-        const uint32_t q = (uint32_t)(i % (int64_t)nq);
+      auto check = [&](const uint32_t q) {
+        if (!exp_count) return;
+        bool same = count == exp_count[q];
+        for (uint32_t j = 0; same && j < count; j++)
+          same = doc[j] == exp_doc[(size_t)q * k + j] && std::memcmp(&score[j], &exp_score[(size_t)q * k + j], 4) == 0;
+        if (!same) bad.fetch_add(1);
+      };
+      auto query_of = [&](const uint32_t q) {
         slg_query qq;
         qq.n_terms = offs[q + 1] - offs[q];
         qq.term_ids = terms + (size_t)offs[q] * n_segs;
         qq.weights = w + offs[q];
-        if (slg_coalescer_search(co, &qq, k, strategy, doc.data(), seg.data(), score.data(), &count, nullptr) != SLG_OK) {
-          failed.fetch_add(1);
-          continue;
+        return qq;
+      };
+      if (depth <= 1) {  // one blocking call per query (a thread per request)
+        for (;;) {
+          const int64_t i = next.fetch_add(1);
+          if (i >= total_queries) break;
+          const uint32_t q = (uint32_t)(i % (int64_t)nq);
+          const slg_query qq = query_of(q);
+          if (slg_coalescer_search(co, &qq, k, strategy, doc.data(), seg.data(), score.data(), &count, nullptr) != SLG_OK) {
+            failed.fetch_add(1);
+            continue;
+          }
+          check(q);
         }
-        if (exp_count) {
-          bool same = count == exp_count[q];
-          for (uint32_t j = 0; same && j < count; j++)
-            same = doc[j] == exp_doc[(size_t)q * k + j] &&
-                   std::memcmp(&score[j], &exp_score[(size_t)q * k + j], 4) == 0;
-          if (!same) bad.fetch_add(1);
+        return;
+      }
+      // `depth` requests in flight per thread (slg_coalescer_submit / _wait): a ring of tickets, the oldest
+      // is waited for and its place taken by a new query
+      std::vector<slg_ticket> ring((size_t)depth);
+      std::vector<uint32_t> ring_q((size_t)depth);
+      int64_t head = 0, tail = 0;  // tickets [tail, head) are in flight
+      bool more = true;
+      while (more || tail < head) {
+        while (more && head - tail < depth) {
+          const int64_t i = next.fetch_add(1);
+          if (i >= total_queries) {
+            more = false;
+            break;
+          }
+          const uint32_t q = (uint32_t)(i % (int64_t)nq);
+          const slg_query qq = query_of(q);
+          if (slg_coalescer_submit(co, &qq, nullptr, SLG_PLAN_SUM, 0.0f, 0, -1, k, strategy, 0,
+                                   &ring[(size_t)(head % depth)]) != SLG_OK) {
+            failed.fetch_add(1);
+            continue;
+          }
+          ring_q[(size_t)(head % depth)] = q;
+          head++;
+        }
+        if (tail < head) {
+          if (slg_coalescer_wait(co, &ring[(size_t)(tail % depth)], doc.data(), seg.data(), score.data(), &count,
+                                 nullptr) != SLG_OK)
+            failed.fetch_add(1);
+          else
+            check(ring_q[(size_t)(tail % depth)]);
+          tail++;
         }
       }
     });

@@ -27,12 +27,15 @@ def harness():
     L.slh_coalesce_bench.restype = C.c_double
     L.slh_coalesce_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32,
-                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     return L
 
 
-@pytest.mark.parametrize("k,threads,max_batch", [(11, 64, 1024), (11, 7, 4), (300, 32, 16)])
-def test_concurrent_callers_get_the_batch_api_rows(gpu, oracle, k, threads, max_batch):
+@pytest.mark.parametrize("k,threads,max_batch,depth", [(11, 64, 1024, 1), (11, 7, 4, 1), (300, 32, 16, 1),
+                                                        (11, 4, 1024, 32), (11, 3, 8, 5)])
+def test_concurrent_callers_get_the_batch_api_rows(gpu, oracle, k, threads, max_batch, depth):
+    """depth 1: blocking callers (slg_coalescer_search); depth > 1: every thread keeps that many tickets in
+    flight (slg_coalescer_submit / slg_coalescer_wait)."""
     rng = np.random.default_rng(40 + k + threads)
     segs = [random_segment(rng, 4000, 80, 25, k1=0.9, b=0.4), random_segment(rng, 2500, 80, 25, k1=0.9, b=0.4)]
     nq = 96
@@ -49,7 +52,7 @@ def test_concurrent_callers_get_the_batch_api_rows(gpu, oracle, k, threads, max_
         bad, nb = C.c_int64(-1), C.c_uint64(0)
         secs = L.slh_coalesce_bench(ix._h, 0, threads, 20 * nq, offs_c.ctypes.data, terms_c.ctypes.data,
                                     w_c.ctypes.data, nq, 2, k, gpu.Wand, max_batch, 50, e_doc.ctypes.data,
-                                    e_score.ctypes.data, e_cnt.ctypes.data, C.addressof(bad), C.addressof(nb), None)
+                                    e_score.ctypes.data, e_cnt.ctypes.data, C.addressof(bad), C.addressof(nb), None, depth)
         assert secs > 0 and bad.value == 0
         assert 1 <= nb.value <= 20 * nq
         if threads >= 32 and max_batch >= threads:
