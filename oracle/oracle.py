@@ -299,6 +299,11 @@ def search_batch_filtered(segments, q_offsets, q_terms, q_weights, k, q_filter, 
             kq["group_tie"] = np.asarray(kw["group_tie"])[ga:gb]
             kq["q_leaf_offsets"] = np.array([0, lb - la], dtype=np.uint32)
             kq["q_group_offsets"] = np.array([0, gb - ga], dtype=np.uint32)
+        if kq.get("q_node_offsets") is not None:  # trees given node by node: this query's nodes
+            na, nb = int(kw["q_node_offsets"][q]), int(kw["q_node_offsets"][q + 1])
+            for name in ("node_kind", "node_tie", "node_parent"):
+                kq[name] = np.asarray(kw[name])[na:nb]
+            kq["q_node_offsets"] = np.array([0, nb - na], dtype=np.uint32)
         r = search_batch(segs, np.array([0, b - a], dtype=np.uint32), q_terms[a:b], q_weights[a:b], k,
                          strategy=strategy, **kq)
         if out is None:

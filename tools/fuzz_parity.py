@@ -3,7 +3,8 @@ tombstones, doc filters, score plans and strategies, each batch compared bit for
 oracle.  usage: python tools/fuzz_parity.py [iterations] [seed]
 (SLG_MAXSCORE=1 / SLG_UNIFORM_MAX_TERMS=0 in the environment force pruning / the many-term kernel;
 FUZZ_MANY_LISTS=1 draws MaxScore-classified queries of 14..32 lists instead; FUZZ_TREES=1 turns the
-score plans of the standard cases into random two-level trees; FUZZ_FEW_LISTS=1 keeps every query at
+score plans of the standard cases into random two-level trees, FUZZ_DEEP=1 into random trees of up to
+four levels given node by node; FUZZ_FEW_LISTS=1 keeps every query at
 <= 8 lists without plans, so every batch runs on the few-term kernel.)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -92,7 +93,39 @@ def run_case(seed0, it, tuning=None):
           kw.update(q_leaf_offsets=np.array(qlo, dtype=np.uint32), leaf_group=np.array(lg, dtype=np.uint32),
                     q_group_offsets=np.array(qgo, dtype=np.uint32), group_plan=np.array(gp, dtype=np.int32),
                     group_tie=np.array(gt, dtype=np.float32))
+      if use_plan and os.environ.get("FUZZ_DEEP", "0") != "0":
+          # trees of up to four levels of Sum / DisMax given node by node (pre-order; the leaves in leaf order)
+          trng = np.random.default_rng(seed0 * 1000003 + it + 177)
+          qno, nk, nt, npar = [0], [], [], []
+          for q in range(nq):
+              base = len(nk)
+
+              def node(par, n_leaves, depth):
+                  me = len(nk) - base
+                  dm = trng.random() < 0.5
+                  nk.append(sa.PLAN_DISMAX if dm else sa.PLAN_SUM)
+                  nt.append(float(trng.choice([0.0, 0.5, 1.0])) if dm else 0.0)
+                  npar.append(par)
+                  i = 0
+                  while i < n_leaves:
+                      take = int(trng.integers(1, n_leaves - i + 1))
+                      if depth < 4 and trng.random() < 0.6:
+                          node(me, take, depth + 1)
+                      else:
+                          for _ in range(take):
+                              nk.append(2)  # SLG_PLAN_LEAF
+                              nt.append(0.0)
+                              npar.append(me)
+                      i += take
+              nl[q] = max(int(nl[q]), 1)  # (a tree has at least one leaf; one without terms scores 0.0)
+              node(0, int(nl[q]), 1)
+              qno.append(len(nk))
+          kw["q_nleaves"] = np.array(nl, dtype=np.uint32)
+          kw.update(q_node_offsets=np.array(qno, dtype=np.uint32), node_kind=np.array(nk, dtype=np.int32),
+                    node_tie=np.array(nt, dtype=np.float32), node_parent=np.array(npar, dtype=np.uint32))
       use_filter = rng.random() < 0.4
+      if os.environ.get("FUZZ_NO_FILTER", "0") != "0":  # (debugging a keyed case: same draws, no filter)
+          use_filter = False
       masks = [rng.random(sg.n_docs) < rng.choice([0.05, 0.5, 0.95]) for sg in segs]
       with sa.GpuIndex(segs, tuning=tuning) as ix:
           qf = None
@@ -127,6 +160,10 @@ def run_case(seed0, it, tuning=None):
                     f"mask={bool(masks[gs][gd])} plan={plan[q]} tie={tie[q]} nl={nl[q]} "
                     f"leaves={leaf[int(offs[q]):int(offs[q + 1])]} w={w[int(offs[q]):int(offs[q + 1])]} "
                     f"terms={terms[int(offs[q]):int(offs[q + 1])].tolist()}")
+              if "q_node_offsets" in kw:
+                  a, b_ = int(kw["q_node_offsets"][q]), int(kw["q_node_offsets"][q + 1])
+                  print("  nodes kind", kw["node_kind"][a:b_].tolist(), "tie", kw["node_tie"][a:b_].tolist(),
+                        "parent", kw["node_parent"][a:b_].tolist())
               break
           raise
 
@@ -176,4 +213,8 @@ def run(iters, seed0, verbose=True, tuning=None):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 3:  # one keyed case: fuzz_parity.py 1 <seed> <iteration>
+        run_case(int(sys.argv[2]), int(sys.argv[3]), None)
+        print("case ok")
+        sys.exit(0)
     run(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
