@@ -611,9 +611,11 @@ def main():
             n_iso = max(4, min(16, args.steps))
             iso_a = [torch.cuda.Event(enable_timing=True) for _ in range(n_iso)]
             iso_b = [torch.cuda.Event(enable_timing=True) for _ in range(n_iso)]
+            for bj in batches:
+                bj.set_stream(st0.cuda_stream)  # (leg 3 put the batches back on the index stream)
             fence()
             for i in range(n_iso):
-                bj = batches[(i * inflight) % n_sets]  # (a batch whose rerank runs on st0)
+                bj = batches[i % n_sets]
                 iso_a[i].record(st0)
                 bj.rerank_device(1, qv.data_ptr(), alpha.data_ptr(), None, k_out, r_doc.data_ptr(), r_seg.data_ptr(),
                                  r_score.data_ptr(), r_vec.data_ptr(), r_count.data_ptr())
