@@ -709,37 +709,51 @@ static __global__ void __launch_bounds__(kSelectThreads) select_topk_kernel(Sele
   const uint32_t n_flat = table && nsl ? t_end[nsl - 1] : 0u;
   const bool anydel = sh_anydel != 0;
 
-  // visit every live candidate of the query: f(ordered score, ~seg, ~doc, slot); four
-  // independent loads in flight per thread
+  // visit every live candidate of the query: f(ordered score, ~seg, ~doc, slot)
   auto for_each = [&](auto &&f) {
     if (table) {
-      for (uint32_t i0 = tid; i0 < n_flat; i0 += 4 * NT) {
-        uint2 c[4];
-        uint64_t at[4];
-        uint32_t ns[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const uint32_t i = i0 + u * NT;
-          c[u] = make_uint2(0u, 0xFFFFFFFFu);
-          at[u] = 0;
-          ns[u] = 0;
-          if (i < n_flat) {
-            uint32_t lo = 0, hi = nsl - 1;  // first slice whose inclusive prefix exceeds i
-            while (lo < hi) {
-              const uint32_t mid = (lo + hi) >> 1;
-              if (t_end[mid] > i)
-                hi = mid;
-              else
-                lo = mid + 1;
-            }
-            at[u] = t_base[lo] + (i - (lo ? t_end[lo - 1] : 0u));
-            ns[u] = t_nseg[lo];
-            c[u] = p.cand[at[u]];
+      // (four named sets, not arrays: with arrays the compiler keeps the loop over them rolled around the
+      //  inlined callback and the arrays in scratch memory — a scratch round trip per candidate)
+      auto locate = [&](const uint32_t i, uint2 &c, uint64_t &at, uint32_t &ns) {
+        c = make_uint2(0u, 0xFFFFFFFFu);
+        at = 0;
+        ns = 0;
+        if (i < n_flat) {
+          uint32_t lo = 0, hi = nsl - 1;  // first slice whose inclusive prefix exceeds i
+          while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (t_end[mid] > i)
+              hi = mid;
+            else
+              lo = mid + 1;
           }
+          at = t_base[lo] + (i - (lo ? t_end[lo - 1] : 0u));
+          ns = t_nseg[lo];
+          c = p.cand[at];
         }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-          if (c[u].y != 0xFFFFFFFFu) f(c[u].x, ns[u], ~c[u].y, at[u]);
+      };
+      // eight independent loads in flight per thread: the kernel's time is the time of the query with the
+      // most candidates (all workgroups are resident at once), and its sweeps are latency-bound
+      for (uint32_t i0 = tid; i0 < n_flat; i0 += 8 * NT) {
+        uint2 c0, c1, c2, c3, c4, c5, c6, c7;
+        uint64_t a0, a1, a2, a3, a4, a5, a6, a7;
+        uint32_t n0, n1, n2, n3, n4, n5, n6, n7;
+        locate(i0, c0, a0, n0);
+        locate(i0 + NT, c1, a1, n1);
+        locate(i0 + 2 * NT, c2, a2, n2);
+        locate(i0 + 3 * NT, c3, a3, n3);
+        locate(i0 + 4 * NT, c4, a4, n4);
+        locate(i0 + 5 * NT, c5, a5, n5);
+        locate(i0 + 6 * NT, c6, a6, n6);
+        locate(i0 + 7 * NT, c7, a7, n7);
+        if (c0.y != 0xFFFFFFFFu) f(c0.x, n0, ~c0.y, a0);
+        if (c1.y != 0xFFFFFFFFu) f(c1.x, n1, ~c1.y, a1);
+        if (c2.y != 0xFFFFFFFFu) f(c2.x, n2, ~c2.y, a2);
+        if (c3.y != 0xFFFFFFFFu) f(c3.x, n3, ~c3.y, a3);
+        if (c4.y != 0xFFFFFFFFu) f(c4.x, n4, ~c4.y, a4);
+        if (c5.y != 0xFFFFFFFFu) f(c5.x, n5, ~c5.y, a5);
+        if (c6.y != 0xFFFFFFFFu) f(c6.x, n6, ~c6.y, a6);
+        if (c7.y != 0xFFFFFFFFu) f(c7.x, n7, ~c7.y, a7);
       }
     } else {
       for (uint32_t s = sb + wave; s < se; s += NT / 64) {
@@ -764,7 +778,18 @@ static __global__ void __launch_bounds__(kSelectThreads) select_topk_kernel(Sele
         return;
       }
     }
-    atomicAdd(&hist0[a >> 24], 1u);
+    // (scores of one query share their exponent: nearly all candidates fall into one or two bins, and LDS
+    //  atomics on one address are served one at a time — 2K of them were 27 us of this kernel.  The
+    //  lanes of a wave that hold the same bin add their count once.)
+    uint64_t todo = __ballot(true);  // the lanes that are here
+    const uint32_t bin = a >> 24;
+    while (todo) {
+      const uint32_t l = (uint32_t)__builtin_ctzll(todo);
+      const uint32_t b = rl(bin, l);
+      const uint64_t same = __ballot(bin == b) & todo;
+      if (lane == l) atomicAdd(&hist0[b], (uint32_t)__popcll(same));
+      todo &= ~same;
+    }
   });
   __syncthreads();
   if (tid == 0) {
@@ -798,7 +823,14 @@ static __global__ void __launch_bounds__(kSelectThreads) select_topk_kernel(Sele
   while (k_done < nout) {
     const uint32_t target = nout - k_done > kSelectCap ? k_done + kSelectCap : nout;
     const bool last = target == nout;
-    const bool all = last && nvalid - k_done <= kSelectCap;  // everything left fits: no select
+    // the final range may take more keys than it emits (dropped after the sort) as long as they fit the
+    // sort — whose size is the next power of two: no more than that of the keys still to emit (k = 1001:
+    // a 1024-key sort; up to 2048 keys were 66 stages x 2 passes against 55 x 1)
+    uint32_t cap_last = 64;
+    while (cap_last < nout - k_done) cap_last <<= 1;
+    cap_last = cap_last < kSelectCap ? cap_last : kSelectCap;
+    if (n_flat > 16u * NT) cap_last = kSelectCap;  // (many candidates: a further select level costs more than the larger sort)
+    const bool all = last && nvalid - k_done <= cap_last;  // everything left fits: no select
     __syncthreads();
     if (tid == 0) {
       sh_pre[0] = sh_pre[1] = sh_pre[2] = 0;
@@ -847,21 +879,28 @@ static __global__ void __launch_bounds__(kSelectThreads) select_topk_kernel(Sele
             const uint32_t taken = (target - (need - cum)) + h;  // keys with prefix >= the chosen one
             sh_taken = taken;
             // exact when the whole bucket is wanted; the final range may overshoot within the buffer
-            sh_done = (h == need - cum || level == 11 || (last && taken - k_done <= kSelectCap)) ? 1u : 0u;
+            sh_done = (h == need - cum || level == 11 || (last && taken - k_done <= cap_last)) ? 1u : 0u;
           }
         }
         __syncthreads();
         if (sh_done) break;
       }
     }
-    const uint32_t p0 = sh_pre[0], p1 = sh_pre[1], p2 = sh_pre[2];
+      const uint32_t p0 = sh_pre[0], p1 = sh_pre[1], p2 = sh_pre[2];
     const uint32_t count = (sh_taken - k_done) < kSelectCap ? (sh_taken - k_done) : kSelectCap;
     // ---- gather the keys of this range ----
     for_each([&](uint32_t a, uint32_t b, uint32_t c, uint64_t) {
       bool win = all || at_or_above(a, b, c, p0, p1, p2, level);
       if (win && have_prev) win = !at_or_above(a, b, c, q0, q1, q2, q_level);
+      const uint64_t wm = __ballot(win);  // (one add per wave: see the histogram above)
+      uint32_t wbase = 0;
+      if (wm != 0ull) {
+        const uint32_t l0 = (uint32_t)__builtin_ctzll(wm);
+        if (lane == l0) wbase = atomicAdd(&sh_nwin, (uint32_t)__popcll(wm));
+        wbase = rl(wbase, l0);
+      }
       if (win) {
-        const uint32_t at = atomicAdd(&sh_nwin, 1u);
+        const uint32_t at = wbase + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
         if (at < kSelectCap) {
           w_ok[at] = a;
           w_sg[at] = b;
@@ -870,7 +909,7 @@ static __global__ void __launch_bounds__(kSelectThreads) select_topk_kernel(Sele
       }
     });
     __syncthreads();
-    // ---- bitonic sort, descending 96-bit key ----
+      // ---- bitonic sort, descending 96-bit key ----
     uint32_t n2 = 1;
     while (n2 < count) n2 <<= 1;
     for (uint32_t i = count + tid; i < n2; i += NT) {
@@ -896,7 +935,7 @@ static __global__ void __launch_bounds__(kSelectThreads) select_topk_kernel(Sele
         __syncthreads();
       }
     }
-    const uint32_t emit = target - k_done;  // (the final range drops what it took beyond k)
+      const uint32_t emit = target - k_done;  // (the final range drops what it took beyond k)
     for (uint32_t i = tid; i < emit; i += NT) {
       const int32_t tk = (int32_t)(w_ok[i] ^ 0x80000000u);
       p.out_doc[(size_t)q * k + k_done + i] = ~w_dc[i];

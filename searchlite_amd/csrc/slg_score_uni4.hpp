@@ -59,7 +59,7 @@ constexpr int kU4JoinPairs = SLG_U4_JOIN_PAIRS;  // queues up to this many entri
 constexpr int u4_filter_words(int ml) { return ml <= 4 ? kJoinWords : SLG_U4_FW8; }
 // (k 129..256: LDS; the plan instantiation's leaf close needs a few registers more than 6 waves leave)
 constexpr int u4_waves(int kregs, int ml, bool plan = false, bool persist = false) {
-  return (ml > 4 || plan || persist) ? SLG_U4_WAVES8 : (kregs == 4 ? 5 : SLG_U4_WAVES);
+  return (ml > 4 || plan || persist) ? SLG_U4_WAVES8 : (kregs >= 4 ? 5 : SLG_U4_WAVES);  // (k > 256: the direct candidates of singles)
 }
 #ifndef SLG_U4_WPB
 #define SLG_U4_WPB 1  // waves per workgroup of the persistent launch (waves never synchronise with each other)
@@ -513,6 +513,18 @@ score_uniform4_kernel(RoundScoreParams p_arg) {
   // ---- score the postings of `e`: all postings with doc < end are this round's (or chunk's);
   //      the others (later postings of the same lists, sentinels) only ever add filter bits.
   //      bnd_*_v: the round's list boundaries (header words, uniform; for the dense join) ----
+  // score of a doc found in ONE list (w*impact = xs): its only leaf
+  auto single_score = [&](const float xs) {
+    float one = 0.0f + xs;  // Sum: -0.0 + one + 0.0 ... = one
+    if (PLAN && plan == 2u) {
+      // DisMax of a doc found in one list: that leaf = one, every other leaf of the plan = 0.0
+      // (planner.rs:138-150): max over all of them, sum = one
+      float m = fmaxf(plan_max0, one);
+      if (plan_leaves > 1u) m = fmaxf(m, 0.0f);
+      one = m + plan_tie * (one - m);
+    }
+    return one;
+  };
   auto accumulate = [&](const BRound &e, const uint32_t end, const uint32_t bnd_lo_v, const uint32_t bnd_hi_v) {
     SLG_STAMP(1);
     uint32_t x[NS];
@@ -542,8 +554,33 @@ score_uniform4_kernel(RoundScoreParams p_arg) {
     // postings whose score may reach the threshold are queued too: a single is a doc without a
     // partner (the exact compare happens once, at the join's candidate site)
     if (!hot_all) {
+      if constexpr (BUF) {
 #pragma unroll
-      for (int jj = 0; jj < NS; jj++) x[jj] |= __builtin_elementwise_sub_sat(__float_as_uint(e.sc[jj]), thr_m1);
+        for (int jj = 0; jj < NS; jj++) x[jj] |= __builtin_elementwise_sub_sat(__float_as_uint(e.sc[jj]), thr_m1);
+      } else {
+        // CANDIDATES mode (k > 256; BASELINE config 5: k = 1001): the threshold is the planner's seed and
+        // stays there — a bound on the 1024th best impact of a list, which a tenth of all postings reach.
+        // Queued, they made the join three times as long as config 2's (~65 entries per round: the dense
+        // path); a posting that is ALONE in its filter field needs no join: it is this round's candidate
+        // as it stands (score = 0.0 + w*impact, wand.rs:539).  Only shared docs and aliases are queued.
+        // (placed like the queue entries: the lanes' counts are prefix-summed over the wave)
+        uint32_t hcnt = 0;
+#pragma unroll
+        for (int jj = 0; jj < NS; jj++)
+          hcnt += (x[jj] == 0u && __float_as_uint(e.sc[jj]) > thr_m1 && e.doc[jj] < end) ? 1u : 0u;
+        if (__ballot(hcnt != 0u) != 0ull) {
+          const uint32_t hincl = wave_incl_scan(hcnt);
+          uint32_t at = ccur + hincl - hcnt;
+#pragma unroll
+          for (int jj = 0; jj < NS; jj++) {
+            const uint32_t ok = ordered_score(single_score(e.sc[jj]));
+            const bool h = x[jj] == 0u && __float_as_uint(e.sc[jj]) > thr_m1 && e.doc[jj] < end;
+            if (h) creg[at] = make_uint2(btop.passes(ok, ~e.doc[jj]) ? ok : 0u, btop.passes(ok, ~e.doc[jj]) ? e.doc[jj] : 0xFFFFFFFFu);
+            at += h ? 1u : 0u;
+          }
+          ccur += rl(hincl, 63);
+        }
+      }
     }
 #pragma unroll
     for (int jj = 0; jj < NS; jj++) accx |= x[jj];
@@ -570,15 +607,7 @@ score_uniform4_kernel(RoundScoreParams p_arg) {
           }
           const bool single = xf == 0u && dc < end;
           if (__ballot(single) == 0ull) continue;
-          float one = 0.0f + xs;  // the doc's only leaf; Sum: -0.0 + one + 0.0 ... = one
-          if (PLAN && plan == 2u) {
-            // DisMax of a doc found in one list: that leaf = one, every other leaf of the plan = 0.0
-            // (planner.rs:138-150): max over all of them, sum = one
-            float m = fmaxf(plan_max0, one);
-            if (plan_leaves > 1u) m = fmaxf(m, 0.0f);
-            one = m + plan_tie * (one - m);
-          }
-          take_checked(single, one, dc);
+          take_checked(single, single_score(xs), dc);
         }
       }
       // shared docs (and aliases), and hot singles, of THIS round are queued in position order =
