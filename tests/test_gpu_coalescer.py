@@ -99,3 +99,50 @@ def test_lone_caller_and_mixed_k(gpu, oracle):
                 assert rc == 0 and c == int(want[3][q])
                 assert np.array_equal(d[:c], want[0][q, :c])
                 assert np.array_equal(sc[:c].view(np.uint32), want[2][q, :c].view(np.uint32))
+
+
+def test_tickets_one_thread_many_requests(gpu, oracle):
+    """slg_coalescer_submit / _poll / _wait: ONE thread keeps 40 requests in flight, collects them in
+    another order than it submitted them; a ticket is good for one wait; a wait without output
+    arrays fails but gives its row back (the batch object is recycled: a second round works)."""
+    from searchlite_amd import _native as N
+    rng = np.random.default_rng(19)
+    seg = random_segment(rng, 5000, 60, 22, k1=0.9, b=0.4)
+    nq, k = 40, 11
+    offs, terms, w = random_queries(rng, nq, 3, 60, weights=True)
+    want = oracle.search_batch([seg], offs, terms, w, k, strategy=oracle.BM25)
+    lib = N.load()
+    with gpu.GpuIndex([seg]) as ix:
+        co = lib.slg_coalescer_create(ix._h, 16, 50)  # (batches of at most 16: the 40 requests span several)
+        assert co
+        for round_ in range(2):
+            keep, tickets = [], []
+            for q in range(nq):
+                tid = np.ascontiguousarray(terms[offs[q]:offs[q + 1]].reshape(-1), np.uint32)
+                ww = np.ascontiguousarray(w[offs[q]:offs[q + 1]], np.float32)
+                qq = N.Query(len(ww), tid.ctypes.data, ww.ctypes.data)
+                t = N.Ticket()
+                assert lib.slg_coalescer_submit(co, C.addressof(qq), None, 0, 0.0, 0, -1, k, gpu.Wand, 0,
+                                                C.addressof(t)) == 0
+                tickets.append(t)
+                del tid, ww  # (the query's arrays may be reused as soon as submit returns)
+            for q in reversed(range(nq)):
+                t = tickets[q]
+                d, s, sc, c = np.zeros(k, np.uint32), np.zeros(k, np.uint32), np.zeros(k, np.float32), C.c_uint32(0)
+                if q == 7 and round_ == 0:  # no output arrays: an error, and the row is given back
+                    assert lib.slg_coalescer_wait(co, C.addressof(t), None, None, None, None, None) == N.ERR_INVALID
+                    assert not t.batch
+                    continue
+                rc = lib.slg_coalescer_wait(co, C.addressof(t), d.ctypes.data, s.ctypes.data, sc.ctypes.data,
+                                            C.addressof(c), None)
+                assert rc == 0 and not t.batch
+                assert lib.slg_coalescer_poll(co, C.addressof(t)) == N.ERR_INVALID  # a ticket is good for one wait
+                assert lib.slg_coalescer_wait(co, C.addressof(t), d.ctypes.data, s.ctypes.data, sc.ctypes.data,
+                                              C.addressof(c), None) == N.ERR_INVALID
+                n = int(want[3][q])
+                assert c.value == n and np.array_equal(d[:n], want[0][q, :n])
+                assert np.array_equal(sc[:n].view(np.uint32), want[2][q, :n].view(np.uint32))
+        nb, nqs = C.c_uint64(0), C.c_uint64(0)
+        assert lib.slg_coalescer_stats(co, C.addressof(nb), C.addressof(nqs)) == 0
+        assert nqs.value == 2 * nq and nb.value >= 2 * 3  # 40 requests in batches of at most 16
+        lib.slg_coalescer_destroy(co)
