@@ -424,6 +424,10 @@ struct MergeParams {
   uint32_t *out_count;
   uint32_t nq;
   uint32_t k;
+  // the index's error word (a scoring wave that gave up on a round sets it) is copied behind the result
+  // block, so that slg_batch_fetch reads it with the results: ONE device-to-host copy per batch
+  const uint32_t *error_flag;
+  uint32_t *out_flag;
 };
 
 // One wave per query.  The query's slices occupy a contiguous range of the candidate arrays
@@ -434,6 +438,7 @@ __global__ void __launch_bounds__(256) merge_topk_kernel(MergeParams p) {
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t q = rfl(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
   if (q >= p.nq) return;
+  if (q == 0 && lane == 0 && p.out_flag) *p.out_flag = *p.error_flag;
   const uint32_t k = p.k;
   const QueryRef qr = p.queries[q];
   WaveTopK<KREGS, true> top;
@@ -653,6 +658,8 @@ struct SelectParams {
   float *out_score;
   uint32_t *out_count;
   uint32_t nq, k;
+  const uint32_t *error_flag;  // see MergeParams
+  uint32_t *out_flag;
 };
 
 constexpr uint32_t kSelectCap = 2048;      // keys sorted in LDS at a time (a rank range of the result)
@@ -670,6 +677,7 @@ static __global__ void __launch_bounds__(kSelectThreads) select_topk_kernel(Sele
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t q = blockIdx.x;
   if (q >= p.nq) return;
+  if (q == 0 && tid == 0 && p.out_flag) *p.out_flag = *p.error_flag;
   const uint32_t k = p.k;
   const QueryRef qr = p.queries[q];
   const uint32_t sb = qr.slice_begin, se = qr.slice_end, nsl = se - sb;
