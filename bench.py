@@ -284,6 +284,26 @@ def main():
         res = tuple(np.asarray(x).copy() for x in last_res[0])
         last_q = qs[0]  # (the harness keeps the first result of every query set: set 0)
         info = index.info()
+        # the scoring kernel alone (HIP events on its launch stream, one launch at a time, query sets rotating)
+        index.profile_read()
+        index.profile(True)
+        iso = [index.prepare(*qs[j], k, strategy) for j in range(min(2, len(qs)))]
+        for _ in range(2):
+            for bb in iso:
+                bb.run()
+        fence()
+        n_launch, kern_ms = index.profile_read()
+        index.profile(False)
+        iso_postings = float(np.mean([bb.info()["n_postings"] for bb in iso]))
+        for bb in iso:
+            bb.close()
+        kern_avg = kern_ms / max(n_launch, 1)
+        alg = 12.0 * iso_postings + 8.0 * k * nq * per_rank  # per posting, + a top-k row per sub-query
+        roof = {"bound": "hbm", "achieved": round(alg / (kern_avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(alg / (kern_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "score_uniform4_kernel", "kernel_ms": round(kern_avg, 4), "launches": n_launch,
+                "algorithmic_bytes_per_launch": int(alg),
+                "bytes_note": "this rank's shard: 12 B x postings scored + 8*k per sub-query (SURVEY 8d)"}
         group.close()
         index.close()
         out = {"workload": f"{C4_SEGMENTS} segments x {n_docs} synthetic Zipf docs (V={vocab}, seeds {cseed}.."
@@ -302,6 +322,7 @@ def main():
                             "merge_ms": round(gstats["merge_ms"], 3), "runs_timed": gstats["runs"]},
                "postings_per_batch_this_rank": int(np.mean([p["n_postings"] for p in postings])),
                "index_postings_this_rank": int(info["n_postings"]), "corpus_build_s": round(t_corpus, 1)}
+        out["roofline_this_rank"] = roof
         return out, res, last_q, (n_docs, vocab, cseed, nq, T, k)
 
     n_docs, vocab, cseed, nq, T, limit = CONFIGS[args.config]
@@ -319,7 +340,7 @@ def main():
                    "value": c4["queries_per_s"], "unit": "queries/s", "n_gpus": world, "steps": args.steps,
                    "warmup": args.warmup, "ms_per_step": c4["ms_per_step"], "higher_is_better": True,
                    "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                   "config": c4}
+                   "config": c4, "roofline": c4.pop("roofline_this_rank")}
             if world == 1 and args.check:
                 from oracle import oracle as O
                 segs = [corpus.zipf_segment(n_docs, vocab, seed=cseed + s, n_threads=gen_threads)
