@@ -800,10 +800,10 @@ static __global__ void __launch_bounds__(kSelectThreads) select_topk_kernel(Sele
     }
   });
   __syncthreads();
-  if (tid == 0) {
-    uint32_t nv = 0;
-    for (int i = 0; i < 256; i++) nv += hist0[i];
-    sh_nvalid = nv;
+  if (wave == 0) {  // (one wave adds the 256 bins: a single thread walking them was ~10 us of this kernel)
+    uint32_t nv = hist0[4 * lane] + hist0[4 * lane + 1] + hist0[4 * lane + 2] + hist0[4 * lane + 3];
+    for (int o = 32; o > 0; o >>= 1) nv += __shfl_xor(nv, o, 64);
+    if (lane == 0) sh_nvalid = nv;
   }
   __syncthreads();
   const uint32_t nvalid = sh_nvalid;
