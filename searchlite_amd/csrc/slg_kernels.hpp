@@ -666,7 +666,9 @@ constexpr uint32_t kSelectCap = 2048;      // keys sorted in LDS at a time (a ra
 constexpr uint32_t kSelectMaxSlices = 512;   // slice table in LDS; more: strided slice loops (34 KB of LDS per workgroup: 4 per CU)
 constexpr uint32_t kSelectThreads = 512;
 
-static __global__ void __launch_bounds__(kSelectThreads) select_topk_kernel(SelectParams p) {
+// (8 waves per SIMD: four 512-thread workgroups per CU, so that the 1024 queries of a batch are all resident at once)
+static __global__ void __launch_bounds__(kSelectThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))
+select_topk_kernel(SelectParams p) {
   constexpr uint32_t NT = kSelectThreads;
   __shared__ uint32_t hist[256], hist0[256];  // hist0: top score byte of all live candidates
   __shared__ uint32_t w_ok[kSelectCap], w_sg[kSelectCap], w_dc[kSelectCap];
