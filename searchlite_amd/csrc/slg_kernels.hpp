@@ -445,22 +445,38 @@ __global__ void __launch_bounds__(256) merge_topk_kernel(MergeParams p) {
   top.init();
   // candidate arrays are indexed slice*k + i; the host guarantees n_slices*k < 2^32
   const uint32_t f0 = qr.slice_begin * k, f1 = qr.slice_end * k;
-  for (uint32_t base = f0; base < f1; base += 64) {
-    const uint32_t f = base + lane;
-    int32_t ctk = kSentinelTk;
-    uint32_t cdoc = 0xFFFFFFFFu, cseg = 0xFFFFFFFFu;
-    if (f < f1) {
-      ctk = p.slice_tk[f];
-      cdoc = p.slice_doc[f];
-      cseg = p.slice_seg[f / k];
+  // Several groups of 64 entries (8; 4 in the wide instantiations) are loaded at once and then inserted one after the other: the loop is bound
+  // by the latency of its loads (a group's three loads, then a ballot that depends on them: 4.2 us per
+  // group with one group in flight — config 3's 110 groups per query made this kernel 0.74 ms, 0.48 of
+  // it without a single insert)
+  constexpr int G = KREGS <= 4 ? 8 : 4;
+  for (uint32_t base = f0; base < f1; base += 64 * G) {
+    int32_t gtk[G];
+    uint32_t gdoc[G], gseg[G];
+#pragma unroll
+    for (int u = 0; u < G; u++) {
+      const uint32_t f = base + 64u * u + lane;
+      gtk[u] = kSentinelTk;
+      gdoc[u] = 0xFFFFFFFFu;
+      gseg[u] = 0xFFFFFFFFu;
+      if (f < f1) {
+        gtk[u] = p.slice_tk[f];
+        gdoc[u] = p.slice_doc[f];
+        gseg[u] = p.slice_seg[f / k];
+      }
     }
-    const bool valid = !(ctk == kSentinelTk && cdoc == 0xFFFFFFFFu);
-    uint64_t m = __ballot(valid && top.passes(ctk, cseg, cdoc));
-    while (m) {
-      const uint32_t l = (uint32_t)__builtin_ctzll(m);
-      top.insert((int32_t)rl((uint32_t)ctk, l), rl(cseg, l), rl(cdoc, l), k, lane);
-      m &= m - 1;
-      m &= __ballot(top.passes(ctk, cseg, cdoc));
+#pragma unroll
+    for (int u = 0; u < G; u++) {
+      const int32_t ctk = gtk[u];
+      const uint32_t cdoc = gdoc[u], cseg = gseg[u];
+      const bool valid = !(ctk == kSentinelTk && cdoc == 0xFFFFFFFFu);
+      uint64_t m = __ballot(valid && top.passes(ctk, cseg, cdoc));
+      while (m) {
+        const uint32_t l = (uint32_t)__builtin_ctzll(m);
+        top.insert((int32_t)rl((uint32_t)ctk, l), rl(cseg, l), rl(cdoc, l), k, lane);
+        m &= m - 1;
+        m &= __ballot(top.passes(ctk, cseg, cdoc));
+      }
     }
   }
 #pragma unroll
