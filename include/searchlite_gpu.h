@@ -370,6 +370,12 @@ typedef struct {
   const int32_t *node_kind;
   const float *node_tie;
   const uint32_t *node_parent;
+  /* minimum_should_match of a query string (api/reader.rs:1509-1517: a doc matches if at least that many of
+   * the matcher's term groups hold it; a term group = a ScorePlan leaf, i.e. one query word over its
+   * fields).  [nq] or NULL; 0 and 1 = any doc of any list.  Batches with a value > 1 are accepted for flat
+   * plans (one level of Sum / DisMax over the leaves) of at most 8 scored lists per segment — what the
+   * few-term kernel's plan instantiation runs; other shapes: SLG_ERR_UNSUPPORTED (CPU scorer). */
+  const uint32_t *q_min_match;
 } slg_score_plans;
 #define SLG_PLAN_LEAF 2
 #define SLG_MAX_PLAN_DEPTH 4u

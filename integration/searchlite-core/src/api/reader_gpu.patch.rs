@@ -40,11 +40,11 @@ let gpu_hits: Option<Vec<RankedHit>> = (|| {
   let folded = crate::gpu::fold_terms(
     qualified_terms.iter().map(|t| (t.key.as_str(), t.weight, t.leaf)),
   );
-  let (score_plan, n_leaves) = crate::gpu::gpu_eligible(
+  let (score_plan, n_leaves, min_match) = crate::gpu::gpu_eligible(
     req, &sort_plan, &query_plan, needs_score_hook, top_k, folded.len(),
   )?;
   match crate::gpu::gpu_top_k(
-    gpu, &self.segments, &folded, &score_plan, n_leaves, req.filter.as_ref(), &req.execution, top_k,
+    gpu, &self.segments, &folded, &score_plan, n_leaves, min_match, req.filter.as_ref(), &req.execution, top_k,
   ) {
     Ok((rows, scored)) => {
       // total_hits_estimate: the CPU path counts the docs `accept` saw (pruning-dependent under

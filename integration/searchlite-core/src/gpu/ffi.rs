@@ -42,6 +42,7 @@ pub struct slg_tuning {
     pub group_plan: *const i32, pub group_tie: *const c_float,
     // trees of any shape: per query a node array in pre-order (SLG_PLAN_SUM | _DISMAX | _LEAF)
     pub q_node_offsets: *const u32, pub node_kind: *const i32, pub node_tie: *const c_float, pub node_parent: *const u32,
+    pub q_min_match: *const u32,
 }
 #[repr(C)] pub struct slg_stats { pub scored_docs: u64, pub candidates_examined: u64, pub postings_advanced: u64 }
 #[repr(C)] pub struct slg_query { pub n_terms: u32, pub term_ids: *const u32, pub weights: *const c_float }

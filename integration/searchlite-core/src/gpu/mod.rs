@@ -519,6 +519,7 @@ fn pure_disjunction(m: &QueryMatcher) -> bool {
   match m {
     QueryMatcher::Term(_) => true,
     QueryMatcher::QueryString(qs) => {
+      // (minimum_should_match > 1 only at the top of the matcher: see min_should_match below)
       !qs.term_groups.is_empty()
         && qs.phrase_groups.is_empty()
         && qs.not_term_groups.is_empty()
@@ -537,6 +538,22 @@ fn pure_disjunction(m: &QueryMatcher) -> bool {
   }
 }
 
+/// minimum_should_match of a request whose whole matcher is ONE query string of term groups
+/// (api/reader.rs:1509-1517: `matched_terms >= required`): the device counts, per doc, the ScorePlan leaves
+/// that hold it (slg_score_plans::q_min_match) — a term group is a leaf (query/planner.rs:354-360).
+/// Some(1) for every other pure disjunction; None: a shape the device does not count (CPU scorer).
+fn min_should_match(m: &QueryMatcher) -> Option<u32> {
+  match m {
+    QueryMatcher::QueryString(qs)
+      if !qs.term_groups.is_empty() && qs.phrase_groups.is_empty() && qs.not_term_groups.is_empty() =>
+    {
+      let need = qs.minimum_should_match.unwrap_or(1);
+      if need <= 255 { Some(need.max(1) as u32) } else { None }
+    }
+    other => if pure_disjunction(other) { Some(1) } else { None },
+  }
+}
+
 /// is this request one the GPU scorer reproduces exactly?
 /// `needs_score_hook` = has_custom_scoring(&compiled_score) (api/reader.rs:376-387, :2628).
 pub(crate) fn gpu_eligible(
@@ -546,7 +563,7 @@ pub(crate) fn gpu_eligible(
   needs_score_hook: bool,
   top_k: usize,
   n_folded_terms: usize,
-) -> Option<(GpuScorePlan, u32)> {
+) -> Option<(GpuScorePlan, u32, u32)> {
   // score_fast_path (api/reader.rs:2550-2551): sort = _score desc only => ScoreMode::Score and
   // the scorer is handed rank_limit = top_k (:2702-2703)
   let score_fast_path =
@@ -564,14 +581,22 @@ pub(crate) fn gpu_eligible(
   if n_folded_terms == 0 || n_folded_terms > MAX_QUERY_TERMS {
     return None;
   }
-  if !pure_disjunction(&plan.matcher) || !plan.phrase_specs.is_empty() {
+  let min_match = min_should_match(&plan.matcher)?;
+  if !plan.phrase_specs.is_empty() {
     return None;
   }
   // every matching term group must also score, else a doc could match without a scored posting
   if plan.term_groups.iter().any(|g| !g.score) {
     return None;
   }
-  plan_shape(plan)
+  let (shape, n_leaves) = plan_shape(plan)?;
+  // the device counts leaves in the few-term kernel's plan instantiation only: a flat plan, <= 8 scored lists
+  if min_match > 1
+    && !(matches!(shape, GpuScorePlan::Sum | GpuScorePlan::DisMax { .. }) && n_folded_terms <= 8)
+  {
+    return None;
+  }
+  Some((shape, n_leaves, min_match))
 }
 
 /// Replaces the per-segment loop + cross-segment sort of IndexReader::search
@@ -583,6 +608,7 @@ pub(crate) fn gpu_top_k(
   folded: &[FoldedTerm],
   score_plan: &GpuScorePlan,
   n_leaves: u32,
+  min_match: u32,
   filter: Option<&Filter>,
   execution: &ExecutionStrategy,
   top_k: usize,
@@ -657,6 +683,7 @@ pub(crate) fn gpu_top_k(
       GpuScorePlan::Nodes { parent, .. } => parent.as_ptr(),
       _ => std::ptr::null(),
     },
+    q_min_match: if min_match > 1 { &min_match } else { std::ptr::null() },
   };
   let filter_id = match filter {
     Some(f) => gpu.filter_id(segments, f)?,
@@ -671,7 +698,8 @@ pub(crate) fn gpu_top_k(
   // Flat plans (every query string, multi_match, dis_max of terms) go through the coalescer: the
   // reference has no batch API (api/reader.rs:2539) and serves a request per blocking thread
   // (searchlite-http/src/lib.rs:628-652), so concurrent requests share one prepare / run / fetch.
-  if matches!(score_plan, GpuScorePlan::Sum | GpuScorePlan::DisMax { .. }) {
+  // (a request with minimum_should_match > 1 is prepared on its own: the coalescer's rows carry no such count)
+  if min_match <= 1 && matches!(score_plan, GpuScorePlan::Sum | GpuScorePlan::DisMax { .. }) {
     let (mut doc, mut seg, mut score) = (vec![0u32; top_k], vec![0u32; top_k], vec![0f32; top_k]);
     let mut count = 0u32;
     let mut stats = ffi::slg_stats { scored_docs: 0, candidates_examined: 0, postings_advanced: 0 };

@@ -314,6 +314,50 @@ def search_batch_filtered(segments, q_offsets, q_terms, q_weights, k, q_filter, 
                                                            strategy=strategy, **kw)
 
 
+NO_TERM = 0xFFFFFFFF
+
+
+def search_batch_min_match(segments, q_offsets, q_terms, q_weights, k, q_min_match, strategy=WAND,
+                           q_filter=None, filters=None, **kw):
+    """search_batch with minimum_should_match per query.  The query-string matcher accepts a doc iff
+    at least `required` of its term groups hold it (api/reader.rs:1509-1517: `matched_terms >= required`,
+    term_group_matches = any list of the group holds the doc, :1571-1582), and the scorer's accept() is
+    `!deleted && matcher.matches(doc) && filter` (api/reader.rs:3009-3036): so a query with
+    minimum_should_match = m is the unfiltered scorer run with the tombstones OR-ed with the docs that
+    fewer than m LEAVES (term group = ScorePlan leaf, kw["q_leaf"]; default: term i = leaf i) hold.
+    Restated with numpy over the segments' posting arrays; q_filter / filters as in search_batch_filtered."""
+    q_offsets = np.ascontiguousarray(q_offsets, dtype=np.uint32)
+    nq = len(q_offsets) - 1
+    q_terms = np.ascontiguousarray(q_terms, dtype=np.uint32).reshape(-1, len(segments))
+    q_leaf = kw.get("q_leaf")
+    masks = []  # one filter per query: the docs the matcher accepts (None where minimum_should_match <= 1)
+    for q in range(nq):
+        m = int(q_min_match[q])
+        a, b = int(q_offsets[q]), int(q_offsets[q + 1])
+        per_seg = []
+        for s, seg in enumerate(segments):
+            if m <= 1:
+                per_seg.append(None)
+                continue
+            leaves = np.arange(b - a) if q_leaf is None else np.asarray(q_leaf)[a:b]
+            count = np.zeros(seg.n_docs, dtype=np.int32)
+            for lf in np.unique(leaves):
+                held = np.zeros(seg.n_docs, dtype=bool)
+                for i in np.nonzero(leaves == lf)[0]:
+                    t = int(q_terms[a + i, s])
+                    if t != NO_TERM:
+                        held[seg.doc_ids[int(seg.term_offsets[t]):int(seg.term_offsets[t + 1])]] = True
+                count += held
+            per_seg.append(count >= m)
+        f = int(q_filter[q]) if q_filter is not None else -1
+        if f >= 0:  # the request's own filter as well
+            per_seg = [fm if pm is None else (pm if fm is None else (pm & np.asarray(fm, dtype=bool)))
+                       for pm, fm in zip(per_seg, filters[f])]
+        masks.append(per_seg)
+    return search_batch_filtered(segments, q_offsets, q_terms, q_weights, k, np.arange(nq), masks,
+                                 strategy=strategy, **kw)
+
+
 def normalize_in_place(v):
     assert v.dtype == np.float32 and v.flags.c_contiguous
     lib().slo_normalize_in_place(_ptr(v), v.size)

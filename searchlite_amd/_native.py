@@ -73,7 +73,7 @@ class ScorePlans(C.Structure):
                 ("q_leaf_offsets", C.c_void_p), ("leaf_group", C.c_void_p), ("q_group_offsets", C.c_void_p),
                 ("group_plan", C.c_void_p), ("group_tie", C.c_void_p),
                 ("q_node_offsets", C.c_void_p), ("node_kind", C.c_void_p), ("node_tie", C.c_void_p),
-                ("node_parent", C.c_void_p)]
+                ("node_parent", C.c_void_p), ("q_min_match", C.c_void_p)]
 
 
 class Ticket(C.Structure):

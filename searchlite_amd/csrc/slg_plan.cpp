@@ -27,6 +27,7 @@ struct BatchFacts {
   uint32_t total_terms = 0;
   uint32_t max_nt = 0;           // most terms of any query
   bool plans_requested = false;  // some query can need a score plan (leaf close on the device)
+  bool min_match = false;        // some query has minimum_should_match > 1 (slg_score_plans::q_min_match)
   bool nested_requested = false; // some query names groups of leaves
 };
 
@@ -50,6 +51,13 @@ BatchFacts validate_batch(const BatchIn &in, uint32_t n_segs) {
     f.max_nt = std::max(f.max_nt, nt);
   }
   const slg_score_plans &pl = in.plans;
+  if (pl.q_min_match)
+    for (uint32_t q = 0; q < in.nq; q++)
+      if (pl.q_min_match[q] > 1u) {
+        if (pl.q_min_match[q] > 255u) throw SlgError(SLG_ERR_UNSUPPORTED, "minimum_should_match > 255 in query " + std::to_string(q));
+        f.min_match = true;
+        f.plans_requested = true;  // (counted per leaf in the plan kernel's join)
+      }
   const bool trees = pl.q_node_offsets != nullptr;
   PLAN_REQUIRE(!trees || (pl.node_kind && pl.node_tie && pl.node_parent), "score trees need node_kind, node_tie and node_parent");
   if (trees) {
@@ -254,6 +262,7 @@ void plan_queries(const Pass1Ctx &c, const uint32_t q_lo, const uint32_t q_hi, P
     // of the first two when it has one or two levels, and into a canonical node table otherwise
     int plan_kind = pl.q_plan ? pl.q_plan[q] : SLG_PLAN_SUM;
     float tie = pl.q_tie ? pl.q_tie[q] : 0.0f;
+    const uint32_t min_match = pl.q_min_match ? pl.q_min_match[q] : 0u;
     uint32_t n_leaves = pl.q_nleaves ? pl.q_nleaves[q] : 0;
     bool groups = pl.leaf_group != nullptr && pl.q_node_offsets == nullptr;
     const uint32_t *lgroup = groups ? pl.leaf_group + pl.q_leaf_offsets[q] : nullptr;
@@ -411,6 +420,10 @@ void plan_queries(const Pass1Ctx &c, const uint32_t q_lo, const uint32_t q_hi, P
           shared = shared || !fresh;
         }
         sq.plan = plan_kind == SLG_PLAN_DISMAX ? 2u : ((shared || nested || depth) ? 1u : 0u);
+        if (min_match > 1u) {  // leaves are counted in the plan kernel's leaf close: Sum of leaves, bits 8.. = the count asked for
+          if (sq.plan == 0u) sq.plan = 1u;
+          sq.plan |= min_match << 8;
+        }
         sq.tie = tie;
         sq.max_init = present < n_leaves ? 0.0f : -INFINITY;
         sq.n_leaves = n_leaves;
@@ -421,7 +434,8 @@ void plan_queries(const Pass1Ctx &c, const uint32_t q_lo, const uint32_t q_hi, P
         if (nested) o.any_nested = true;
         if (depth) o.any_deep = true;
       }
-      sq.theta0 = threshold_seed(sh, first, sq.n_terms, k, fq);
+      // (minimum_should_match > 1: the champions behind the seed are single postings — docs the matcher may reject)
+      sq.theta0 = min_match > 1u ? 0.0f : threshold_seed(sh, first, sq.n_terms, k, fq);
       // MaxScore: by default for batches with a query of >= 5 terms (plan_batch drops the
       // classification again when block skipping has nothing to gain);
       // slg_tuning.pruning = 1 / 0 forces it on / off.  Never with score plans in the batch (the
@@ -847,6 +861,10 @@ void plan_batch(const std::vector<SegView> &segs, const slg_tuning &tn, const Ba
   // classified batches run on the many-term kernel
   const bool plans_fit = !any_plan || (tn.uniform_kernel >= 4 && !out.nested && !out.deep && tn.uniform_plans != 0);
   out.uniform = out.max_terms <= tn.uniform_max_terms && plans_fit;
+  if (facts.min_match && !out.uniform)
+    throw SlgError(SLG_ERR_UNSUPPORTED,
+                   "minimum_should_match > 1 needs a flat score plan and at most 8 scored lists per segment in every query "
+                   "of the batch (the few-term kernel's plan instantiation)");
   for (const slg::RoundQuery &sq : out.sqs)
     if (sq.ess_mask != full_mask(sq.n_terms)) {
       out.pruned = true;

@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(64, (MODE >= 3 ? 2 : 4)) score_multi_kernel(Ro
   const uint32_t ess_mask = MS ? rfl(s.ess_mask) : 0xFFFFFFFFu;  // bit t: list t is essential
   const bool my_ess = lane < T && ((ess_mask >> lane) & 1u);
   // score plan: 0 flat sum, 1 Sum of multi-term leaves, 2 DisMax of leaves
-  const uint32_t plan = PL ? rfl(s.plan) : 0u;
+  const uint32_t plan = PL ? rfl(s.plan) & 0xFFu : 0u;  // (bits 8..: min_match, few-term plan kernel only)
   const float tie = __uint_as_float(rfl(__float_as_uint(s.tie)));
   const uint32_t max_init = rfl(__float_as_uint(s.max_init));
   const uint32_t n_leaves = rfl(s.n_leaves);

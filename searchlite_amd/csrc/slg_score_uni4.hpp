@@ -213,7 +213,13 @@ score_uniform4_kernel(RoundScoreParams p_arg) {
   if (lane < T) tr = p.terms[rfl(sl.term_begin) + lane];
   // score plan (PLAN instantiation): 0 = flat sum in term order; 1 = Sum of leaves; 2 = DisMax of leaves.
   // leaf_start: bit t = list t is the first list of its leaf (the lists are sorted by leaf)
-  const uint32_t plan = PLAN ? rfl(sl.plan) : 0u;
+  // min_match (bits 8.. of the plan word; RoundQuery::plan): a doc counts only if at least that many LEAVES
+  // hold it — the query-string matcher's minimum_should_match over its term groups (api/reader.rs:1509-1517:
+  // matched_terms >= required).  0 / 1: any doc of any list.
+  const uint32_t plan_word = PLAN ? rfl(sl.plan) : 0u;
+  const uint32_t plan = plan_word & 0xFFu;
+  const uint32_t min_match = PLAN ? plan_word >> 8 : 0u;
+  const bool need_many = PLAN && min_match > 1u;  // a doc found in ONE list is never accepted
   const float plan_tie = __uint_as_float(rfl(__float_as_uint(sl.tie)));
   const float plan_max0 = __uint_as_float(rfl(__float_as_uint(sl.max_init)));
   uint32_t leaf_start = 1u;
@@ -553,7 +559,7 @@ score_uniform4_kernel(RoundScoreParams p_arg) {
     }
     // postings whose score may reach the threshold are queued too: a single is a doc without a
     // partner (the exact compare happens once, at the join's candidate site)
-    if (!hot_all) {
+    if (!hot_all && !need_many) {
       if constexpr (BUF) {
 #pragma unroll
         for (int jj = 0; jj < NS; jj++) x[jj] |= __builtin_elementwise_sub_sat(__float_as_uint(e.sc[jj]), thr_m1);
@@ -590,7 +596,7 @@ score_uniform4_kernel(RoundScoreParams p_arg) {
     uint32_t qincl = 0;  // inclusive prefix sum of the lanes' queued postings
     bool touched = false;
     if (__ballot(accx != 0u) != 0ull) {
-      if (hot_all) {
+      if (hot_all && !need_many) {
         // no positive threshold yet (no seed; filtered query; candidates mode without a seed): every
         // single of the round is a candidate: score = 0.0 + w*impact (wand.rs:539).  One site; the
         // register is selected at run time
@@ -672,6 +678,7 @@ score_uniform4_kernel(RoundScoreParams p_arg) {
         float tot = plan == 2u ? 0.0f : -0.0f, mx = plan_max0;
         uint32_t lo = 0u, rest = leaf_start >> 1;  // bits of the leaf starts still ahead (bit 0 = list 1)
         uint32_t t_at = 0u;                        // first list of the current leaf
+        uint32_t present = 0u;                     // leaves that hold my doc (min_match)
         for (;;) {
           // next leaf start after t_at, or T
           const uint32_t skip = rest != 0u ? (uint32_t)__builtin_ctz(rest) + 1u : T - t_at;
@@ -682,6 +689,7 @@ score_uniform4_kernel(RoundScoreParams p_arg) {
             hi = f == 0u ? 0u : rl(qincl, (f < 64u ? f : 64u) - 1u);
           }
           float la = 0.0f;
+          uint32_t miss = ~0u;  // stays all ones while no sender of this leaf holds my doc
           // whole groups of 8 broadcast reads; the leaf's last group is predicated per sender (a uniform
           // compare) instead of a rolled loop over what remains: a rolled loop exposes the LDS latency of
           // every single sender (measured on the multi-field workload: the join was 54 % of the wave-cycles)
@@ -693,10 +701,12 @@ score_uniform4_kernel(RoundScoreParams p_arg) {
               const uint32_t diff = sq.x ^ me.x;
               const uint32_t nm = (0u - (diff < 1u ? diff : 1u)) | off;  // 0: same doc and inside the leaf
               la += __uint_as_float(sq.y & ~nm);
+              miss &= nm;
               const uint32_t cand = (g + l) | nm;
               first = cand < first ? cand : first;
             }
           }
+          present += miss == 0u ? 1u : 0u;
           tot += la;
           mx = fmaxf(mx, la);
           if (t2 >= T) break;
@@ -705,6 +715,7 @@ score_uniform4_kernel(RoundScoreParams p_arg) {
           lo = hi;
         }
         acc = plan == 2u ? mx + plan_tie * (tot - mx) : tot;
+        if (need_many && present < min_match) first = 64u;  // not accepted: nobody owns it
       } else {
         for (uint32_t g = 0; g < n; g += 8) {
 #pragma unroll
@@ -743,6 +754,8 @@ score_uniform4_kernel(RoundScoreParams p_arg) {
         float acc = 0.0f;
         bool lower = false;
         float tot = (PLAN && plan == 2u) ? 0.0f : -0.0f, mx = plan_max0;  // score plan: root sum / max (see the all-pairs join)
+        uint32_t present = 0u;  // leaves that hold my doc (min_match)
+        bool leaf_hit = false;
         // the searches in the lists' segments are independent: one LDS read of each per step, four
         // lists at a time (the sum stays in list order)
 #pragma unroll
@@ -777,7 +790,10 @@ score_uniform4_kernel(RoundScoreParams p_arg) {
               tot += acc;  // list h + u starts a new leaf: the one before it closes (acc = that leaf's sum)
               mx = fmaxf(mx, acc);
               acc = 0.0f;
+              present += leaf_hit ? 1u : 0u;
+              leaf_hit = false;
             }
+            leaf_hit = leaf_hit || hit;
             acc = hit ? acc + (mine ? __uint_as_float(me.y) : __uint_as_float(kk.y)) : acc;
             lower = lower || (hit && (uint32_t)(h + u) < ml);
           }
@@ -786,8 +802,9 @@ score_uniform4_kernel(RoundScoreParams p_arg) {
           tot += acc;
           mx = fmaxf(mx, acc);
           acc = plan == 2u ? mx + plan_tie * (tot - mx) : tot;
+          present += leaf_hit ? 1u : 0u;
         }
-        const bool own = have && !lower;
+        const bool own = have && !lower && !(need_many && present < min_match);
         n_scored += (uint32_t)__popcll(__ballot(own));
         if (__ballot(own && acc >= threshold_score()) != 0ull) {
           touched = true;

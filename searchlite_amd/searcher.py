@@ -185,13 +185,16 @@ class GpuIndex:
     def prepare(self, q_offsets, q_terms, q_weights, k: int, strategy: int = Wand,
                 q_filter=None, q_leaf=None, q_plan=None, q_tie=None, q_nleaves=None,
                 q_leaf_offsets=None, leaf_group=None, q_group_offsets=None, group_plan=None,
-                group_tie=None, q_node_offsets=None, node_kind=None, node_tie=None, node_parent=None) -> "PreparedBatch":
+                group_tie=None, q_node_offsets=None, node_kind=None, node_tie=None, node_parent=None,
+                q_min_match=None) -> "PreparedBatch":
         """q_leaf / q_plan / q_tie / q_nleaves: score plans; leaf_group / group_plan / group_tie with
         their per-query offsets: two-level plans; q_node_offsets / node_kind / node_tie / node_parent:
-        trees of any shape, node by node in pre-order (slg_batch_prepare_plans, slg_score_plans)."""
+        trees of any shape, node by node in pre-order (slg_batch_prepare_plans, slg_score_plans);
+        q_min_match: minimum_should_match per query (leaves that must hold a doc)."""
         return PreparedBatch(self, q_offsets, q_terms, q_weights, k, strategy, q_filter,
                              q_leaf, q_plan, q_tie, q_nleaves, q_leaf_offsets, leaf_group,
-                             q_group_offsets, group_plan, group_tie, q_node_offsets, node_kind, node_tie, node_parent)
+                             q_group_offsets, group_plan, group_tie, q_node_offsets, node_kind, node_tie, node_parent,
+                             q_min_match)
 
     def search_plan(self, q_offsets, q_terms, q_weights, k: int, q_leaf=None, q_plan=None,
                     q_tie=None, q_nleaves=None, strategy: int = Wand, q_filter=None, **tree):
@@ -448,7 +451,8 @@ class PreparedBatch:
     def __init__(self, index: GpuIndex, q_offsets, q_terms, q_weights, k: int, strategy: int,
                  q_filter=None, q_leaf=None, q_plan=None, q_tie=None, q_nleaves=None,
                  q_leaf_offsets=None, leaf_group=None, q_group_offsets=None, group_plan=None,
-                 group_tie=None, q_node_offsets=None, node_kind=None, node_tie=None, node_parent=None):
+                 group_tie=None, q_node_offsets=None, node_kind=None, node_tie=None, node_parent=None,
+                 q_min_match=None):
         self.index = index
         self._lib = index._lib
         q_offsets = np.ascontiguousarray(q_offsets, dtype=np.uint32)
@@ -472,8 +476,10 @@ class PreparedBatch:
         qno, npar = u32(q_node_offsets), u32(node_parent)
         nk = None if node_kind is None else np.ascontiguousarray(node_kind, dtype=np.int32)
         ntie = None if node_tie is None else np.ascontiguousarray(node_tie, dtype=np.float32)
+        qmm = u32(q_min_match)
+        assert qmm is None or len(qmm) == self.nq
         plans = N.ScorePlans(opt(ql), opt(qp), opt(qt), opt(qn), opt(qlo), opt(lg), opt(qgo), opt(gp), opt(gt),
-                             opt(qno), opt(nk), opt(ntie), opt(npar))
+                             opt(qno), opt(nk), opt(ntie), opt(npar), opt(qmm))
         self._h = self._lib.slg_batch_prepare_plans(
             index._h, self.nq, _ptr(q_offsets), _ptr(q_terms), _ptr(q_weights), C.addressof(plans),
             opt(qf), k, strategy)

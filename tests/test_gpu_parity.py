@@ -684,6 +684,81 @@ def test_dismax_counts_leaves_without_postings_in_a_round(gpu, oracle):
             assert_same_hits(ix.search_plan(offs, terms, w, k, **kw), want, 0.0, f"dismax idle leaf k={k}")
 
 
+@pytest.mark.parametrize("k", [11, 64, 400])
+def test_minimum_should_match(gpu, oracle, k):
+    """slg_score_plans::q_min_match: a doc counts only if at least m term groups (leaves) hold it
+    (api/reader.rs:1509-1517), as part of accept() (api/reader.rs:3009-3036).  Query strings of 1-3 words
+    over 2 fields (<= 6 lists), Sum and DisMax roots, plain disjunctions (a term = a leaf), m = 0..3 mixed in
+    one batch, two segments, tombstones, a doc filter; dense lists (the binary-search join) and sparse ones."""
+    from tests.util import random_multifield_segment
+    rng = np.random.default_rng(4200 + k)
+    vocab, F = 10, 2
+    segs = [random_multifield_segment(rng, 9000 + 2000 * i, vocab, F, 10) for i in range(2)]
+    segs[0].set_deleted(list(range(3, segs[0].n_docs, 7)))
+    offs, terms, w, leaf, plan, tie, nl, mm = [0], [], [], [], [], [], [], []
+    nq = 36
+    for q in range(nq):
+        words = rng.choice(vocab, size=int(rng.integers(1, 4)), replace=False)
+        kind = q % 3  # 0: query string (leaf per word), 1: the same under a DisMax root, 2: single-field disjunction
+        for wi, wd in enumerate(words):
+            for f in range(F):
+                if kind == 2 and f > 0:
+                    continue
+                terms.append([f * vocab + int(wd)] * 2)
+                w.append(np.float32(0.5 + rng.random() * 2))
+                leaf.append(wi)
+        offs.append(len(terms))
+        plan.append(gpu.PLAN_DISMAX if kind == 1 else gpu.PLAN_SUM)
+        tie.append(0.4 if kind == 1 else 0.0)
+        nl.append(len(words))
+        mm.append(int(rng.integers(0, 4)))  # (may exceed the number of words: nothing matches)
+    offs = np.array(offs, dtype=np.uint32)
+    terms = np.array(terms, dtype=np.uint32)
+    w = np.array(w, dtype=np.float32)
+    mm = np.array(mm, dtype=np.uint32)
+    kw = dict(q_leaf=np.array(leaf, dtype=np.uint32), q_plan=np.array(plan, dtype=np.int32),
+              q_tie=np.array(tie, dtype=np.float32), q_nleaves=np.array(nl, dtype=np.uint32))
+    want = oracle.search_batch_min_match(segs, offs, terms, w, k, mm, strategy=oracle.BM25, **kw)
+    loose = oracle.search_batch(segs, offs, terms, w, k, strategy=oracle.BM25, **kw)
+    assert not np.array_equal(want[0], loose[0])  # the minimum matters
+    with gpu.GpuIndex(segs) as ix:
+        for strat in (gpu.Bm25, gpu.Wand):
+            got = ix.search_plan(offs, terms, w, k, strategy=strat, q_min_match=mm, **kw)
+            assert_same_hits(got, want, 0.0, f"minimum_should_match k={k}")
+        masks = [rng.random(sg.n_docs) < 0.6 for sg in segs]
+        fid = ix.add_filter(masks)
+        qf = np.array([fid if q % 2 else -1 for q in range(nq)], dtype=np.int32)
+        got = ix.search_plan(offs, terms, w, k, q_filter=qf, q_min_match=mm, **kw)
+    want_f = oracle.search_batch_min_match(segs, offs, terms, w, k, mm, strategy=oracle.BM25,
+                                           q_filter=np.where(qf >= 0, 0, -1), filters=[masks], **kw)
+    assert_same_hits(got, want_f, 0.0, "minimum_should_match + filter")
+
+
+def test_minimum_should_match_shapes_the_device_does_not_take(gpu, oracle):
+    """More than 8 scored lists in a segment, or a two-level plan: SLG_ERR_UNSUPPORTED (the shim's CPU path)."""
+    from searchlite_amd import _native as N
+    rng = np.random.default_rng(43)
+    seg = random_segment(rng, 3000, 40, 20)
+    offs = np.array([0, 9], dtype=np.uint32)
+    terms = np.arange(9, dtype=np.uint32).reshape(-1, 1)
+    w = np.ones(9, dtype=np.float32)
+    with gpu.GpuIndex([seg]) as ix:
+        with pytest.raises(N.SlgError) as e:
+            ix.search_plan(offs, terms, w, 11, q_min_match=np.array([2], np.uint32))
+        assert e.value.code == N.ERR_UNSUPPORTED
+        # nine lists without a minimum are fine
+        ix.search_plan(offs, terms, w, 11, q_min_match=np.array([1], np.uint32))
+        o4 = np.array([0, 4], dtype=np.uint32)
+        tree = dict(q_leaf=np.arange(4, dtype=np.uint32), q_nleaves=np.array([4], np.uint32),
+                    q_plan=np.array([gpu.PLAN_SUM], np.int32), q_tie=np.array([0.0], np.float32),
+                    q_leaf_offsets=np.array([0, 4], np.uint32), leaf_group=np.array([0, 0, 1, 1], np.uint32),
+                    q_group_offsets=np.array([0, 2], np.uint32), group_plan=np.array([gpu.PLAN_DISMAX] * 2, np.int32),
+                    group_tie=np.array([0.5, 0.5], np.float32))
+        with pytest.raises(N.SlgError) as e:
+            ix.search_plan(o4, terms[:4], w[:4], 11, q_min_match=np.array([2], np.uint32), **tree)
+        assert e.value.code == N.ERR_UNSUPPORTED
+
+
 def test_three_tiny_lists_share_one_slot(gpu, oracle):
     """Three lists inside one 64-posting slot with common docs: the strictly ordered claim path
     (sum order (a+b)+c matters in f32)."""

@@ -601,3 +601,31 @@ def test_baseline_a_model_returns_the_scorer_results(oracle):
     for a, b in zip(got, want):
         assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
                               b.view(np.uint32) if b.dtype == np.float32 else b)
+
+
+def test_minimum_should_match_wrapper_against_numpy(oracle):
+    """oracle.search_batch_min_match (the matcher's `matched_terms >= required`, api/reader.rs:1509-1517,
+    folded into accept()): every returned doc is held by at least m term groups, and every doc that is
+    held by at least m groups, is live and scores is returned when k covers them all."""
+    from tests.util import random_multifield_segment
+    rng = np.random.default_rng(31)
+    vocab, F = 9, 3
+    seg = random_multifield_segment(rng, 500, vocab, F, 8)
+    seg.set_deleted(list(range(0, 500, 9)))
+    words = [1, 4, 6]
+    terms = np.array([[f * vocab + w_] for w_ in words for f in range(F)], dtype=np.uint32)
+    leaf = np.repeat(np.arange(3, dtype=np.uint32), F)
+    w = np.ones(len(terms), dtype=np.float32)
+    offs = np.array([0, len(terms)], dtype=np.uint32)
+    held = np.zeros((3, 500), dtype=bool)
+    for i, t in enumerate(terms[:, 0]):
+        held[leaf[i], seg.doc_ids[int(seg.term_offsets[t]):int(seg.term_offsets[t + 1])]] = True
+    dead = np.unpackbits(seg.deleted, bitorder="little")[:500].astype(bool)
+    sizes = []
+    for m in (1, 2, 3, 4):
+        got = oracle.search_batch_min_match([seg], offs, terms, w, 500, [m], strategy=oracle.BM25, q_leaf=leaf)
+        n = int(got[3][0])
+        expect = np.nonzero((held.sum(axis=0) >= m) & ~dead)[0]
+        assert sorted(got[0][0, :n].tolist()) == expect.tolist()
+        sizes.append(n)
+    assert sizes[0] > sizes[1] > sizes[2] > 0 and sizes[3] == 0

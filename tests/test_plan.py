@@ -421,6 +421,38 @@ def test_two_level_plans_are_validated_and_classified(lib):
         assert not bad.h and bad.code == -1, (lg, bad.err)
 
 
+def test_minimum_should_match_in_the_plan_word(lib):
+    """slg_score_plans::q_min_match > 1: the sub-query runs as a plan (Sum of leaves at least), the count asked
+    for rides in bits 8.. of RoundQuery::plan, the threshold seed is off (its champions are single postings,
+    which the matcher may reject); such a batch must fit the few-term kernel's plan instantiation."""
+    rng = np.random.default_rng(12)
+    seg = random_segment(rng, 4000, 40, 15)
+    offs, terms, w = random_queries(rng, 3, 4, 40)
+    pl = _plans(q_min_match=([2, 1, 3], "<u4"))
+    p = Planned(lib, [seg], offs, terms, w, 11, plans=pl)
+    assert p.h, p.err
+    sqs, _ = check_structure(p, 11)
+    assert p.facts.plan_batch and p.facts.uniform and not p.facts.nested
+    assert [int(x) & 0xFF for x in sqs["plan"]] == [1, 0, 1]
+    assert [int(x) >> 8 for x in sqs["plan"]] == [2, 0, 3]
+    assert float(sqs[0]["theta0"]) == 0.0 and float(sqs[2]["theta0"]) == 0.0
+    p.close()
+    # DisMax root keeps its kind
+    pd = Planned(lib, [seg], offs, terms, w, 11,
+                 plans=_plans(q_min_match=([2, 2, 2], "<u4"), q_plan=([1, 1, 1], "<i4"), q_tie=([0.5] * 3, "<f4")))
+    assert pd.h and [int(x) & 0xFF for x in pd.array(0, RQ)["plan"]] == [2, 2, 2]
+    pd.close()
+    # nine lists: no kernel counts leaves there
+    o9 = np.array([0, 9], dtype=np.uint32)
+    bad = Planned(lib, [seg], o9, np.arange(9, dtype=np.uint32), np.ones(9, np.float32), 11,
+                  plans=_plans(q_min_match=([2], "<u4")))
+    assert not bad.h and bad.code == -4
+    ok = Planned(lib, [seg], o9, np.arange(9, dtype=np.uint32), np.ones(9, np.float32), 11,
+                 plans=_plans(q_min_match=([1], "<u4")))
+    assert ok.h
+    ok.close()
+
+
 def test_score_trees_given_node_by_node(lib):
     """slg_score_plans::q_node_offsets: trees of one and two levels resolve into the root / group forms;
     deeper ones into the canonical node table (every leaf at the same depth, a chain of one-child Sum

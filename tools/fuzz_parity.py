@@ -4,7 +4,8 @@ oracle.  usage: python tools/fuzz_parity.py [iterations] [seed]
 (SLG_MAXSCORE=1 / SLG_UNIFORM_MAX_TERMS=0 in the environment force pruning / the many-term kernel;
 FUZZ_MANY_LISTS=1 draws MaxScore-classified queries of 14..32 lists instead; FUZZ_TREES=1 turns the
 score plans of the standard cases into random two-level trees, FUZZ_DEEP=1 into random trees of up to
-four levels given node by node; FUZZ_FEW_LISTS=1 keeps every query at
+four levels given node by node, FUZZ_MIN_MATCH=1 gives every query <= 8 lists, a flat plan and a
+minimum_should_match of 0..3; FUZZ_FEW_LISTS=1 keeps every query at
 <= 8 lists without plans, so every batch runs on the few-term kernel.)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -40,7 +41,8 @@ def run_case(seed0, it, tuning=None):
           segs.append(sg)
       nq = int(rng.integers(1, 24))
       k = int(rng.choice([1, 2, 11, 64, 65, 101, 256, 257, 600, 1024, 1025, 3000]))
-      FEW = os.environ.get("FUZZ_FEW_LISTS", "0") != "0"
+      MM = os.environ.get("FUZZ_MIN_MATCH", "0") != "0"  # <= 8 lists, flat plans, minimum_should_match 0..3 per query
+      FEW = os.environ.get("FUZZ_FEW_LISTS", "0") != "0" or MM
       frng = np.random.default_rng(seed0 * 1000033 + it + 5)
       offs, terms, w, leaf, plan, tie, nl = [0], [], [], [], [], [], []
       V = vocab * F
@@ -69,7 +71,7 @@ def run_case(seed0, it, tuning=None):
       offs = np.array(offs, dtype=np.uint32)
       terms = np.array(terms, dtype=np.uint32).reshape(-1, n_segs)
       w = np.array(w, dtype=np.float32)
-      use_plan = rng.random() < 0.6 and not FEW
+      use_plan = (rng.random() < 0.6 and not FEW) or MM
       kw = dict(q_leaf=np.array(leaf, dtype=np.uint32), q_plan=np.array(plan, dtype=np.int32),
                 q_tie=np.array(tie, dtype=np.float32), q_nleaves=np.array(nl, dtype=np.uint32)) if use_plan else {}
       if use_plan and os.environ.get("FUZZ_TREES", "0") != "0":
@@ -123,6 +125,10 @@ def run_case(seed0, it, tuning=None):
           kw["q_nleaves"] = np.array(nl, dtype=np.uint32)
           kw.update(q_node_offsets=np.array(qno, dtype=np.uint32), node_kind=np.array(nk, dtype=np.int32),
                     node_tie=np.array(nt, dtype=np.float32), node_parent=np.array(npar, dtype=np.uint32))
+      mm = None
+      if MM:
+          mrng = np.random.default_rng(seed0 * 1000003 + it + 277)
+          mm = mrng.integers(0, 4, size=nq).astype(np.uint32)
       use_filter = rng.random() < 0.4
       if os.environ.get("FUZZ_NO_FILTER", "0") != "0":  # (debugging a keyed case: same draws, no filter)
           use_filter = False
@@ -133,8 +139,13 @@ def run_case(seed0, it, tuning=None):
               fid = ix.add_filter(masks)
               qf = np.array([fid if rng.random() < 0.6 else -1 for _ in range(nq)], dtype=np.int32)
           strat = int(rng.choice([sa.Bm25, sa.Wand, sa.Bmw]))
-          got = ix.search_plan(offs, terms, w, k, strategy=strat, q_filter=qf, **kw)
-      if use_filter:
+          got = ix.search_plan(offs, terms, w, k, strategy=strat, q_filter=qf,
+                               **(dict(kw, q_min_match=mm) if MM else kw))
+      if MM:
+          want = O.search_batch_min_match(segs, offs, terms, w, k, mm, strategy=O.BM25,
+                                          q_filter=np.where(qf >= 0, 0, -1) if use_filter else None,
+                                          filters=[masks] if use_filter else None, **kw)
+      elif use_filter:
           want = O.search_batch_filtered(segs, offs, terms, w, k, np.where(qf >= 0, 0, -1), [masks],
                                          strategy=O.BM25, **kw)
       else:
