@@ -689,7 +689,7 @@ score_uniform4_kernel(RoundScoreParams p_arg) {
             hi = f == 0u ? 0u : rl(qincl, (f < 64u ? f : 64u) - 1u);
           }
           float la = 0.0f;
-          uint32_t miss = ~0u;  // stays all ones while no sender of this leaf holds my doc
+          uint32_t lfirst = 64u;  // lowest sender of THIS leaf that holds my doc (64: none: the leaf is not present)
           // whole groups of 8 broadcast reads; the leaf's last group is predicated per sender (a uniform
           // compare) instead of a rolled loop over what remains: a rolled loop exposes the LDS latency of
           // every single sender (measured on the multi-field workload: the join was 54 % of the wave-cycles)
@@ -701,12 +701,12 @@ score_uniform4_kernel(RoundScoreParams p_arg) {
               const uint32_t diff = sq.x ^ me.x;
               const uint32_t nm = (0u - (diff < 1u ? diff : 1u)) | off;  // 0: same doc and inside the leaf
               la += __uint_as_float(sq.y & ~nm);
-              miss &= nm;
               const uint32_t cand = (g + l) | nm;
-              first = cand < first ? cand : first;
+              lfirst = cand < lfirst ? cand : lfirst;
             }
           }
-          present += miss == 0u ? 1u : 0u;
+          first = lfirst < first ? lfirst : first;
+          present += lfirst < 64u ? 1u : 0u;
           tot += la;
           mx = fmaxf(mx, la);
           if (t2 >= T) break;
