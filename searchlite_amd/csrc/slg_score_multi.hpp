@@ -58,8 +58,12 @@ constexpr int kMultiPlanLds = 2 * kMultiCap * 4;  // acc[] and max[] of the leaf
 // Separate instantiations: the extra code of one mode costs the others registers.
 // (the tree modes hold 18 / 26 KB of LDS per wave — 2 / 1.5 waves per SIMD — so they may as well have
 //  the registers of 2 waves per SIMD: no spills)
+#ifndef SLG_MULTI_WAVES
+#define SLG_MULTI_WAVES 4  // waves per SIMD of the flat / classified / flat-plan modes (114-126 VGPRs).  At 5 (96 VGPRs) the
+                           // compiler spills 24-35 registers to scratch: 0.40 against 0.29 ms on the multi-field workload
+#endif
 template <int KREGS, int MODE>
-__global__ void __launch_bounds__(64, (MODE >= 3 ? 2 : 4)) score_multi_kernel(RoundScoreParams p) {
+__global__ void __launch_bounds__(64, (MODE >= 3 ? 2 : SLG_MULTI_WAVES)) score_multi_kernel(RoundScoreParams p) {
   constexpr bool MS = MODE == 1;
   constexpr bool PL = MODE >= 2;
   constexpr bool NE = MODE >= 3;  // two-level plans (its own instantiation: the group close costs registers)
