@@ -178,3 +178,32 @@ def test_segfile_library_exports_its_header():
     assert "slf_postings_decode" in names and "slf_postings_scan" in names
     L = IF._load()
     assert not [n for n in names if not hasattr(L, n)]
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """The ctypes mirrors (searchlite_amd/_native.py) and the Rust mirrors (integration/.../ffi.rs) of the
+    header's public structs: sizes from a C program compiled against include/searchlite_gpu.h, field counts
+    from the sources (a struct that grows in the header must grow in both mirrors)."""
+    import ctypes as C
+    import re
+    import subprocess
+    from searchlite_amd import _native as N
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = {"slg_segment_desc": N.SegmentDesc, "slg_vector_field_desc": N.VectorFieldDesc, "slg_stats": N.Stats,
+             "slg_tuning": N.Tuning, "slg_score_plans": N.ScorePlans, "slg_ticket": N.Ticket, "slg_query": N.Query}
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "searchlite_gpu.h"\nint main(void) {\n' +
+                   "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in names) + "  return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    sizes = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for n, cls in names.items():
+        assert int(sizes[n]) == C.sizeof(cls), (n, sizes[n], C.sizeof(cls))
+    ffi = open(os.path.join(root, "integration", "searchlite-core", "src", "gpu", "ffi.rs")).read()
+    for n, cls in names.items():
+        m = re.search(r"pub struct %s \{(.*?)\}" % n, ffi, re.S)
+        if m is None:
+            continue  # (not every struct is bound by the shim)
+        body = re.sub(r"//[^\n]*", "", m.group(1))  # (comments may hold commas and colons)
+        n_rust = len(re.findall(r"pub\s+\w+\s*:", body))
+        assert n_rust == len(cls._fields_), (n, n_rust, len(cls._fields_))
