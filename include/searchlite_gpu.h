@@ -280,6 +280,14 @@ int slg_index_add_filter_range_i64(slg_index *index, const int64_t *const *seg_c
                                    int64_t hi);
 int slg_index_add_filter_range_f64(slg_index *index, const double *const *seg_columns, double lo,
                                    double hi);
+/* A filter from posting lists that are already on the device: the docs that hold NONE of the given terms
+ * (pass_if_absent != 0: the query-string matcher's not-terms, api/reader.rs:1499-1503 — a doc in any
+ * not-term group never matches) or at least one of them (pass_if_absent == 0).  term_ids: n_terms rows of
+ * one id per segment (SLG_NO_TERM: the segment does not have the term), as in slg_query.  and_bitmaps_or_null:
+ * pass bitmaps as in slg_index_add_filter, AND-ed with the above (the request's own filter), or NULL.
+ * Returns the filter id (>= 0) or an error code; use it like any other filter id. */
+int slg_index_add_filter_terms(slg_index *index, const uint32_t *term_ids, uint32_t n_terms, int pass_if_absent,
+                               const uint8_t *const *and_bitmaps_or_null);
 /* Unregisters the filter.  Batches already prepared with it keep their bitmaps (they belong to the
  * batch's index state) and may still run; the id may be handed out again by a later add. */
 int slg_index_remove_filter(slg_index *index, int filter_id);

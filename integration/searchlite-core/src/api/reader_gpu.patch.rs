@@ -43,8 +43,20 @@ let gpu_hits: Option<Vec<RankedHit>> = (|| {
   let (score_plan, n_leaves, min_match) = crate::gpu::gpu_eligible(
     req, &sort_plan, &query_plan, needs_score_hook, top_k, folded.len(),
   )?;
+  // term keys of the matcher's not-term groups (api/reader.rs:1499-1503): rejected on the device by a filter
+  // built from their posting lists
+  let not_keys: Vec<String> = match &query_plan.matcher {
+    QueryMatcher::QueryString(qs) => qs
+      .not_term_groups
+      .iter()
+      .filter_map(|i| term_groups.get(*i))
+      .flat_map(|g| g.keys.iter().cloned())
+      .collect(),
+    _ => Vec::new(),
+  };
   match crate::gpu::gpu_top_k(
-    gpu, &self.segments, &folded, &score_plan, n_leaves, min_match, req.filter.as_ref(), &req.execution, top_k,
+    gpu, &self.segments, &folded, &score_plan, n_leaves, min_match, req.filter.as_ref(), &not_keys,
+    &req.execution, top_k,
   ) {
     Ok((rows, scored)) => {
       // total_hits_estimate: the CPU path counts the docs `accept` saw (pruning-dependent under

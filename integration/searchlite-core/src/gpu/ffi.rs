@@ -106,6 +106,8 @@ extern "C" {
     pub fn slg_index_set_stream(index: *mut slg_index, hip_stream: *mut c_void) -> c_int;
     // doc filters: accept = !deleted && filter (api/reader.rs:3009-3018)
     pub fn slg_index_add_filter(index: *mut slg_index, seg_bitmaps: *const *const u8) -> c_int;
+    pub fn slg_index_add_filter_terms(index: *mut slg_index, term_ids: *const u32, n_terms: u32, pass_if_absent: c_int,
+                                      and_bitmaps_or_null: *const *const u8) -> c_int;
     pub fn slg_index_add_filter_range_i64(index: *mut slg_index, seg_columns: *const *const i64, lo: i64, hi: i64) -> c_int;
     pub fn slg_index_add_filter_range_f64(index: *mut slg_index, seg_columns: *const *const f64, lo: f64, hi: f64) -> c_int;
     pub fn slg_index_remove_filter(index: *mut slg_index, filter_id: c_int) -> c_int;

@@ -335,8 +335,28 @@ impl GpuSegments {
   /// `req.filter` as a doc bitmap per segment (accept = !deleted && filter, api/reader.rs:
   /// 3009-3018), evaluated once with the reference's own passes_filter and cached by the filter's
   /// serialized form.
-  fn filter_id(&self, segments: &[SegmentReader], filter: &Filter) -> Result<i32> {
-    let key = serde_json::to_string(filter)?;
+  ///
+  /// `not_keys`: the term keys ("field:term", as the term dictionaries hold them) of the matcher's not-term
+  /// groups (api/reader.rs:1499-1503: a doc that holds one of them never matches).  Their posting lists are
+  /// already on the device: the filter is built there (slg_index_add_filter_terms), AND-ed with `filter`.
+  fn filter_id(
+    &self,
+    segments: &[SegmentReader],
+    filter: Option<&Filter>,
+    not_keys: &[String],
+    dict: &[std::sync::Arc<HashMap<String, u32>>],
+  ) -> Result<i32> {
+    let mut key = match filter {
+      Some(f) => serde_json::to_string(f)?,
+      None => String::new(),
+    };
+    if !not_keys.is_empty() {
+      let mut sorted: Vec<&str> = not_keys.iter().map(|k| k.as_str()).collect();
+      sorted.sort_unstable();
+      sorted.dedup();
+      key.push('\u{1}');
+      key.push_str(&sorted.join("\u{1}"));
+    }
     // the lock is held across lookup, evaluation and insert: two threads that miss on the same
     // filter must not both register it (each registration is n_docs / 8 bytes of HBM per segment)
     let mut cache = self.filters.lock().unwrap();
@@ -355,21 +375,44 @@ impl GpuSegments {
         }
       }
     }
-    let bitmaps: Vec<Vec<u8>> = segments
-      .iter()
-      .map(|seg| {
-        let n = seg.meta.doc_count as usize;
-        let mut bm = vec![0u8; n.div_ceil(8)];
-        for d in 0..n as DocId {
-          if passes_filter(seg.fast_fields(), d, filter) {
-            bm[(d >> 3) as usize] |= 1u8 << (d & 7);
+    let bitmaps: Vec<Vec<u8>> = match filter {
+      Some(filter) => segments
+        .iter()
+        .map(|seg| {
+          let n = seg.meta.doc_count as usize;
+          let mut bm = vec![0u8; n.div_ceil(8)];
+          for d in 0..n as DocId {
+            if passes_filter(seg.fast_fields(), d, filter) {
+              bm[(d >> 3) as usize] |= 1u8 << (d & 7);
+            }
           }
-        }
-        bm
-      })
-      .collect();
+          bm
+        })
+        .collect(),
+      None => Vec::new(),
+    };
     let ptrs: Vec<*const u8> = bitmaps.iter().map(|b| b.as_ptr()).collect();
-    let id = unsafe { ffi::slg_index_add_filter(self.handle, ptrs.as_ptr()) };
+    let id = if not_keys.is_empty() {
+      unsafe { ffi::slg_index_add_filter(self.handle, ptrs.as_ptr()) }
+    } else {
+      // one row of per-segment term ids per not-term key (`dict`: the staged state's term dictionaries, which
+      // the caller reads under the state's lock)
+      let mut ids = Vec::with_capacity(not_keys.len() * dict.len());
+      for k in not_keys {
+        for d in dict.iter() {
+          ids.push(d.get(k).copied().unwrap_or(ffi::SLG_NO_TERM));
+        }
+      }
+      unsafe {
+        ffi::slg_index_add_filter_terms(
+          self.handle,
+          ids.as_ptr(),
+          not_keys.len() as u32,
+          1,
+          if ptrs.is_empty() { std::ptr::null() } else { ptrs.as_ptr() },
+        )
+      }
+    };
     if id < 0 {
       return Err(last_error());
     }
@@ -544,9 +587,8 @@ fn pure_disjunction(m: &QueryMatcher) -> bool {
 /// Some(1) for every other pure disjunction; None: a shape the device does not count (CPU scorer).
 fn min_should_match(m: &QueryMatcher) -> Option<u32> {
   match m {
-    QueryMatcher::QueryString(qs)
-      if !qs.term_groups.is_empty() && qs.phrase_groups.is_empty() && qs.not_term_groups.is_empty() =>
-    {
+    // (not-term groups reach the device as a filter built from their posting lists: not_term_keys below)
+    QueryMatcher::QueryString(qs) if !qs.term_groups.is_empty() && qs.phrase_groups.is_empty() => {
       let need = qs.minimum_should_match.unwrap_or(1);
       if need <= 255 { Some(need.max(1) as u32) } else { None }
     }
@@ -586,7 +628,12 @@ pub(crate) fn gpu_eligible(
     return None;
   }
   // every matching term group must also score, else a doc could match without a scored posting
-  if plan.term_groups.iter().any(|g| !g.score) {
+  // (the not-term groups of a top-level query string do not score and do not match: they only reject)
+  let not_groups: &[usize] = match &plan.matcher {
+    QueryMatcher::QueryString(qs) => &qs.not_term_groups,
+    _ => &[],
+  };
+  if plan.term_groups.iter().enumerate().any(|(i, g)| !g.score && !not_groups.contains(&i)) {
     return None;
   }
   let (shape, n_leaves) = plan_shape(plan)?;
@@ -610,6 +657,7 @@ pub(crate) fn gpu_top_k(
   n_leaves: u32,
   min_match: u32,
   filter: Option<&Filter>,
+  not_keys: &[String],
   execution: &ExecutionStrategy,
   top_k: usize,
 ) -> Result<(Vec<(u32, DocId, f32)>, u64)> {
@@ -685,9 +733,10 @@ pub(crate) fn gpu_top_k(
     },
     q_min_match: if min_match > 1 { &min_match } else { std::ptr::null() },
   };
-  let filter_id = match filter {
-    Some(f) => gpu.filter_id(segments, f)?,
-    None => -1,
+  let filter_id = if filter.is_some() || !not_keys.is_empty() {
+    gpu.filter_id(segments, filter, not_keys, &st.dict)?
+  } else {
+    -1
   };
   let strategy = match execution {
     ExecutionStrategy::Bm25 => ffi::SLG_STRATEGY_BM25,

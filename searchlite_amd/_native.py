@@ -149,6 +149,7 @@ def load():
         "slg_coalescer_phase_ms": (i32, [vp, vp, vp, vp, vp]),
         "slg_search_batch": (i32, [vp, vp, u32, u32, i32, vp, vp, vp, vp, vp]),
         "slg_index_add_filter": (i32, [vp, vp]),
+        "slg_index_add_filter_terms": (i32, [vp, vp, u32, i32, vp]),
         "slg_index_add_filter_range_i64": (i32, [vp, vp, C.c_int64, C.c_int64]),
         "slg_index_add_filter_range_f64": (i32, [vp, vp, C.c_double, C.c_double]),
         "slg_index_remove_filter": (i32, [vp, i32]),

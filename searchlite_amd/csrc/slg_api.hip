@@ -1022,7 +1022,8 @@ int slg_index_set_stream(slg_index *ix, void *hip_stream) {
 // ---- doc filters -------------------------------------------------------------
 namespace {
 int add_filter_impl(slg_index *ix, const uint8_t *const *seg_bitmaps, const void *const *seg_columns,
-                    int column_kind, long long lo_i, long long hi_i, double lo_f, double hi_f) {
+                    int column_kind, long long lo_i, long long hi_i, double lo_f, double hi_f,
+                    const uint32_t *term_ids = nullptr, uint32_t n_terms = 0, int pass_if_absent = 0) {
   int id = -1;
   int rc = guarded([&] {
     SLG_REQUIRE(ix != nullptr, "index is NULL");
@@ -1034,6 +1035,8 @@ int add_filter_impl(slg_index *ix, const uint8_t *const *seg_bitmaps, const void
     auto fd = std::make_shared<FilterData>();
     fd->per_seg.resize(n_segs);
     std::vector<DevBuf> tmp(n_segs);  // uploaded pass bitmaps / columns (freed on return)
+    std::vector<DevBuf> marked(n_segs);  // docs that hold one of the terms (slg_index_add_filter_terms)
+    SLG_REQUIRE(n_terms == 0 || term_ids != nullptr, "term_ids is NULL");
     for (size_t s = 0; s < n_segs; s++) {
       const SegHost &sh = *cur->segs[s];
       const size_t words = ((size_t)sh.n_docs + 31) / 32;
@@ -1060,6 +1063,30 @@ int add_filter_impl(slg_index *ix, const uint8_t *const *seg_bitmaps, const void
         tmp[s].alloc(w.size() * 4, &ix->pool);
         SLG_HIP(hipMemcpy(tmp[s].p, w.data(), w.size() * 4, hipMemcpyHostToDevice));
         fp.pass = tmp[s].as<uint32_t>();
+      }
+      if (term_ids) {
+        // the docs of the given posting lists, marked on the device (the lists are resident: nothing is
+        // uploaded but a bitmap's worth of zeros); a caller's bitmap, if any, is AND-ed as a second pass set
+        const PostingStore &ps = *sh.store;
+        marked[s].alloc((words ? words : 1) * 4, &ix->pool);
+        SLG_HIP(hipMemsetAsync(marked[s].p, 0, (words ? words : 1) * 4, st));
+        for (uint32_t t = 0; t < n_terms; t++) {
+          const uint32_t id = term_ids[(size_t)t * n_segs + s];
+          if (id == SLG_NO_TERM) continue;
+          SLG_REQUIRE(id < ps.n_terms, "term id out of range");
+          const uint64_t a = ps.term_offsets[id], b = ps.term_offsets[(size_t)id + 1];
+          if (b == a || sh.n_docs == 0) continue;
+          slg::PostingMarkParams mp{};
+          mp.docs = ps.d_docs.as<uint32_t>() + a + (uint64_t)slg::kListPad * id;
+          mp.df = (uint32_t)(b - a);
+          mp.n_docs = sh.n_docs;
+          mp.bitmap = marked[s].as<uint32_t>();
+          hipLaunchKernelGGL(slg::posting_mark_kernel, dim3((mp.df + 255) / 256), dim3(256), 0, st, mp);
+          SLG_HIP(hipGetLastError());
+        }
+        fp.pass2 = fp.pass;  // (the caller's bitmap, or nullptr)
+        fp.pass = marked[s].as<uint32_t>();
+        fp.invert_pass = pass_if_absent ? 1 : 0;
       }
       if (sh.n_docs) {
         hipLaunchKernelGGL(slg::filter_build_kernel, dim3((sh.n_docs + 255) / 256), dim3(256), 0, st, fp);
@@ -1092,6 +1119,15 @@ int slg_index_add_filter_range_i64(slg_index *ix, const int64_t *const *seg_colu
 }
 int slg_index_add_filter_range_f64(slg_index *ix, const double *const *seg_columns, double lo, double hi) {
   return add_filter_impl(ix, nullptr, reinterpret_cast<const void *const *>(seg_columns), 2, 0, 0, lo, hi);
+}
+int slg_index_add_filter_terms(slg_index *ix, const uint32_t *term_ids, uint32_t n_terms, int pass_if_absent,
+                               const uint8_t *const *and_bitmaps_or_null) {
+  if (!term_ids && n_terms) {
+    return guarded([&] { SLG_REQUIRE(false, "term_ids is NULL"); });
+  }
+  static const uint32_t none = SLG_NO_TERM;
+  return add_filter_impl(ix, and_bitmaps_or_null, nullptr, 0, 0, 0, 0.0, 0.0, term_ids ? term_ids : &none, n_terms,
+                         pass_if_absent);
 }
 int slg_index_remove_filter(slg_index *ix, int filter_id) {
   return guarded([&] {

@@ -616,7 +616,23 @@ struct FilterBuildParams {
   int column_kind;  // 0 none, 1 i64, 2 f64
   uint32_t n_docs;
   uint32_t *reject;  // out [ceil(n_docs/32)]
+  int invert_pass;        // the pass bitmap marks the docs to REJECT (docs that hold a not-term)
+  const uint32_t *pass2;  // a second pass bitmap, AND-ed (the request's own filter), or nullptr
 };
+
+// marks the docs of one posting list in a bitmap (slg_index_add_filter_terms: the matcher's not-terms)
+struct PostingMarkParams {
+  const uint32_t *docs;  // the list's first posting (padded layout: only [0, df) are read)
+  uint32_t df;
+  uint32_t n_docs;
+  uint32_t *bitmap;      // [ceil(n_docs/32)] zeroed before the first list
+};
+static __global__ void __launch_bounds__(256) posting_mark_kernel(PostingMarkParams p) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.df) return;
+  const uint32_t d = p.docs[i];
+  if (d < p.n_docs) atomicOr(&p.bitmap[d >> 5], 1u << (d & 31u));
+}
 
 static __global__ void __launch_bounds__(256) filter_build_kernel(FilterBuildParams p) {
   const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;  // one doc per lane
@@ -630,7 +646,8 @@ static __global__ void __launch_bounds__(256) filter_build_kernel(FilterBuildPar
       const double v = static_cast<const double *>(p.column)[d];
       pass = v >= p.lo_f && v <= p.hi_f;  // NaN never passes (query/filters.rs numeric range)
     } else {
-      pass = p.pass == nullptr || ((p.pass[d >> 5] >> (d & 31)) & 1u);
+      pass = p.pass == nullptr || ((((p.pass[d >> 5] >> (d & 31)) & 1u) != 0u) != (p.invert_pass != 0));
+      if (p.pass2 && !((p.pass2[d >> 5] >> (d & 31)) & 1u)) pass = false;
     }
     if (p.deleted && ((p.deleted[d >> 5] >> (d & 31)) & 1u)) pass = false;
   }

@@ -178,6 +178,24 @@ class GpuIndex:
             N.check(rc)
         return rc
 
+    def add_filter_terms(self, term_ids, pass_if_absent: bool = True, and_masks=None) -> int:
+        """Filter built on the device from resident posting lists (slg_index_add_filter_terms): the docs
+        that hold none (pass_if_absent) / at least one of the terms; term_ids [n_terms, n_segs];
+        and_masks: boolean masks per segment (or None) AND-ed with it."""
+        tid = np.ascontiguousarray(term_ids, dtype=np.uint32).reshape(-1, self.n_segs)
+        ptrs = None
+        packed = None
+        if and_masks is not None:
+            assert len(and_masks) == self.n_segs
+            packed = [None if m is None else np.packbits(np.asarray(m, dtype=bool), bitorder="little")
+                      for m in and_masks]
+            ptrs = (C.c_void_p * self.n_segs)(*[None if b is None else b.ctypes.data for b in packed])
+        rc = self._lib.slg_index_add_filter_terms(self._h, tid.ctypes.data if tid.size else None, tid.shape[0],
+                                                  int(bool(pass_if_absent)), ptrs)
+        if rc < 0:
+            N.check(rc)
+        return rc
+
     def remove_filter(self, filter_id: int) -> None:
         N.check(self._lib.slg_index_remove_filter(self._h, filter_id))
 

@@ -759,6 +759,42 @@ def test_minimum_should_match_shapes_the_device_does_not_take(gpu, oracle):
         assert e.value.code == N.ERR_UNSUPPORTED
 
 
+def test_filter_from_posting_lists_not_terms(gpu, oracle):
+    """slg_index_add_filter_terms: the query-string matcher's not-terms (api/reader.rs:1499-1503: a doc that
+    holds a not-term never matches) as a filter built on the device from the resident posting lists —
+    alone, AND-ed with a request filter, and the other polarity (docs that hold at least one of the terms);
+    two segments, tombstones, a term one segment does not have."""
+    rng = np.random.default_rng(77)
+    vocab = 30
+    segs = [random_segment(rng, 6000 + 1500 * i, vocab, 18, k1=0.9, b=0.4) for i in range(2)]
+    segs[1].set_deleted(list(range(2, segs[1].n_docs, 13)))
+    offs, terms, w = random_queries(rng, 20, 3, vocab, n_segs=2, weights=True)
+    nots = np.array([[4, 4], [9, 0xFFFFFFFF], [17, 17]], dtype=np.uint32)  # (term 9: segment 1 does not have it)
+    held = []
+    for s, sg in enumerate(segs):
+        m = np.zeros(sg.n_docs, dtype=bool)
+        for t in nots[:, s]:
+            if t != 0xFFFFFFFF:
+                m[sg.doc_ids[int(sg.term_offsets[t]):int(sg.term_offsets[t + 1])]] = True
+        held.append(m)
+    user = [rng.random(sg.n_docs) < 0.5 for sg in segs]
+    k = 11
+    with gpu.GpuIndex(segs) as ix:
+        cases = [(ix.add_filter_terms(nots, True), [~h for h in held]),
+                 (ix.add_filter_terms(nots, True, and_masks=user), [~h & u for h, u in zip(held, user)]),
+                 (ix.add_filter_terms(nots, False), held),
+                 (ix.add_filter_terms(np.zeros((0, 2), np.uint32), True), [np.ones(sg.n_docs, bool) for sg in segs])]
+        assert len({c[0] for c in cases}) == 4
+        for fid, masks in cases:
+            qf = np.full(20, fid, dtype=np.int32)
+            got = ix.search_batch(offs, terms, w, k, gpu.Wand, q_filter=qf)
+            want = oracle.search_batch_filtered(segs, offs, terms, w, k, np.zeros(20, np.int32), [masks],
+                                                strategy=oracle.BM25)
+            assert_same_hits(got, want, 0.0, f"filter {fid} from posting lists")
+        with pytest.raises(Exception):
+            ix.add_filter_terms(np.array([[9999, 0]], np.uint32), True)  # term id out of range
+
+
 def test_three_tiny_lists_share_one_slot(gpu, oracle):
     """Three lists inside one 64-posting slot with common docs: the strictly ordered claim path
     (sum order (a+b)+c matters in f32)."""
