@@ -5,7 +5,7 @@ TAG=${1:-r04}
 G=gpurun_out
 for c in c2 c3 c4 c5 mf mf_many_term_kernel; do [ -s $G/final/bench_$c.json ] && tail -1 $G/final/bench_$c.json > profiles/${TAG}_bench_$c.json; done
 [ -s $G/final/bench_c2_steps20.json ] && tail -1 $G/final/bench_c2_steps20.json > profiles/${TAG}_bench_c2_steps20.json
-for c in c2 c3 mf; do
+for c in c2 c3 mf c5; do
   [ -f $G/prof_${TAG}_$c/trace/run_kernel_stats.csv ] || continue
   cp $G/prof_${TAG}_$c/trace/run_kernel_stats.csv profiles/${TAG}_${c}_kernel_stats.csv
   cp $G/prof_${TAG}_$c/summary.txt profiles/${TAG}_${c}_rocprof_summary.txt
